@@ -1,0 +1,203 @@
+/*
+ * ref_driver.cpp -- harness around the REAL reference objects (test infrastructure).
+ *
+ * oracle/Makefile compiles const.cpp, names.cpp, reads.cpp, qualities.cpp and
+ * arithmetic.cpp straight from /root/reference (no copies, no shims) and links them
+ * with this file.  The harness only plays the role of main()/thread(): it sets the
+ * option globals that main.cpp defines, feeds records to the reference's own
+ * aho_search / output_name / output_read / output_quality / aho_trie_bucket /
+ * bin_prepare / ac_stat / ac_coder / ac_decoder, and dumps what they return.
+ *
+ * Not reachable without stand-ins (buffio.cpp needs bzlib.h, main.cpp needs
+ * sys/sysctl.h, neither is in this image): quality_mapping_init, ac_write/ac_read
+ * framing, bin_dump, compress(), decompress().  Those call f_gets/f_read/f_write,
+ * which stay unresolved in this binary and are never called.
+ *
+ * usage: ref_driver <fastq> <outdir> [-P patterns.txt] [-q qmap.txt] [-n]
+ *   -P  text core list (read_patterns_from_file) instead of the embedded patterns.bin
+ *   -q  file with 129 integers: offset, values[0..127]  (default: offset 33, identity)
+ *   -n  names off (-n lib)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "arithmetic.h"
+#include "const.h"
+#include "names.h"
+#include "qualities.h"
+#include "reads.h"
+
+/* option globals normally defined in main.cpp:62-80 and compress.cpp:61-63 */
+int _quality_sample_lines = 100000;
+int _quality_lossy_percentage = 0;
+char _use_second_file = 0;
+char _is_fasta = 0;
+char _use_names = 1;
+uint64_t _file_buffer_size = 128 * 1024 * 1024;
+uint64_t _max_bucket_set_size = 2ull * 1024 * 1024 * 1024;
+char _temp_directory[MAXLINE] = "__temp__";
+char _library_name[MAXLINE] = "";
+char _pattern_path[MAXLINE];
+int _split_reads = 0;
+int _compression_mode = IO_SYS;
+char _interleave = 0;
+int64_t _time_elapsed = 0;
+int _thread_count = 1;
+int _decompress = 0;
+int _no_ac = 0;
+int _compress_qualities = 1;
+int32_t read_length[2];
+int64_t reads_count = 0;
+
+void bin_prepare(aho_trie *t); /* reads.cpp:54 */
+extern char _binary_patterns_bin_start, _binary_patterns_bin_end; /* reads.cpp:327-328 */
+
+static void dump(const std::string &path, const void *p, size_t n) {
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f) { perror(path.c_str()); exit(2); }
+  fwrite(p, 1, n, f);
+  fclose(f);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) { fprintf(stderr, "usage: ref_driver <fastq> <outdir> [-P txt] [-q qmap] [-n]\n"); return 2; }
+  std::string fq = argv[1], out = argv[2];
+  const char *ptxt = 0, *qfile = 0;
+  for (int i = 3; i < argc; i++) {
+    if (!strcmp(argv[i], "-P") && i + 1 < argc) ptxt = argv[++i];
+    else if (!strcmp(argv[i], "-q") && i + 1 < argc) qfile = argv[++i];
+    else if (!strcmp(argv[i], "-n")) _use_names = 0;
+  }
+  quality_mapping qm;
+  qm.offset = 33;
+  for (int i = 0; i < 128; i++) qm.values[i] = i;
+  if (qfile) {
+    FILE *f = fopen(qfile, "r");
+    if (!f || fscanf(f, "%d", &qm.offset) != 1) { fprintf(stderr, "bad qmap\n"); return 2; }
+    for (int i = 0; i < 128; i++) if (fscanf(f, "%d", &qm.values[i]) != 1) { fprintf(stderr, "bad qmap\n"); return 2; }
+    fclose(f);
+  }
+
+  aho_trie *trie = ptxt ? read_patterns_from_file(ptxt) : read_patterns();
+
+  FILE *f = fopen(fq.c_str(), "r");
+  if (!f) { perror(fq.c_str()); return 2; }
+  static char name[MAXLINE], read[MAXLINE], plus[MAXLINE], qual[MAXLINE];
+  std::vector<int32_t> tok;
+  std::vector<uint8_t> packed, names, quals;
+  std::vector<bin_node *> nodes_in_order;
+  uint8_t outbuf[MAXLINE * 5];
+  int64_t N = 0;
+  int L = 0;
+  while (fgets(name, MAXLINE, f) && fgets(read, MAXLINE, f) && fgets(plus, MAXLINE, f) && fgets(qual, MAXLINE, f)) {
+    if (!L) { L = strlen(read) - 1; read_length[0] = L; }
+    /* the body of thread(), compress.cpp:673-706, single mate */
+    aho_trie *bucket;
+    read_data rd;
+    rd.data = outbuf;
+    int n = aho_search(read, trie, &bucket);
+    rd.sz = output_name(name, rd.data);
+    names.insert(names.end(), rd.data, rd.data + rd.sz);
+    int before = rd.sz;
+    if (n != -1) {
+      rd.sz += output_read(read, rd.data + rd.sz, n - bucket->level + 1, bucket->level);
+      rd.end = n + 1;
+    } else {
+      rd.sz += output_read(read, rd.data + rd.sz, 0, 0);
+      rd.end = 0;
+    }
+    packed.insert(packed.end(), rd.data + before, rd.data + rd.sz);
+    before = rd.sz;
+    rd.sz += output_quality(qual, read, &qm, rd.data + rd.sz, 0);
+    quals.insert(quals.end(), rd.data + before, rd.data + rd.sz);
+    rd.of = rd.sz;
+    rd.read_length = (int32_t)N; /* unused outside PACBIO builds: carries the input index */
+    bin_node *bn = aho_trie_bucket(bucket, &rd);
+    memcpy(bn->data.data, rd.data, rd.sz);
+    tok.push_back(bucket->output);
+    tok.push_back(rd.end);
+    N++;
+  }
+  fclose(f);
+  reads_count = N;
+
+  dump(out + "/tok.i32", tok.data(), tok.size() * 4);
+  dump(out + "/packed.bin", packed.data(), packed.size());
+  dump(out + "/names.bin", names.data(), names.size());
+  dump(out + "/qual.bin", quals.data(), quals.size());
+  dump(out + "/freq4.u64", ac_freq4[0], sizeof(uint64_t) * AC_DEPTH * AC_DEPTH * AC_DEPTH);
+
+  /* pattern -> BFS id (reads.cpp:296): walk each core through the automaton */
+  int np = 0;
+  if (ptxt) {
+    while (patterns[np]) np++; /* read_patterns_from_file zero-fills the array (reads.cpp:386) */
+  } else {                     /* embedded blob: sum the group counts (reads.cpp:342-351) */
+    const char *b = &_binary_patterns_bin_start, *e = &_binary_patterns_bin_end;
+    while (b < e) {
+      int16_t ln; int32_t cnt;
+      memcpy(&ln, b, 2); memcpy(&cnt, b + 2, 4);
+      b += 6 + (size_t)cnt * (ln / 4 + (ln % 4 != 0));
+      np += cnt;
+    }
+  }
+  std::vector<int32_t> ids(np);
+  for (int p = 0; p < np; p++) {
+    aho_trie *c = trie;
+    for (const char *s = patterns[p]; *s && *s != '\n'; s++) c = c->child[getval(*s)];
+    ids[p] = (c->output == p) ? c->id : -1;
+  }
+  dump(out + "/ids.i32", ids.data(), ids.size() * 4);
+
+  /* emission order: the traversal of aho_output (reads.cpp:466-499) with bin_dump
+   * replaced by a walk of the sorted list that bin_prepare leaves behind */
+  std::vector<int64_t> order;
+  {
+    std::vector<aho_trie *> q;
+    std::vector<char> seen(5000000 * 4, 0);
+    seen[trie->id] = 1;
+    for (int i = 0; i < 4; i++) { q.push_back(trie->child[i]); seen[trie->child[i]->id] = 1; }
+    for (size_t h = 0; h < q.size(); h++) {
+      aho_trie *cur = q[h];
+      if (cur->bin.size) {
+        bin_prepare(cur);
+        for (bin_node *b = cur->bin.first; b; b = b->next) order.push_back(b->data.read_length);
+      }
+      for (int i = 0; i < 4; i++)
+        if (cur->child[i] && !seen[cur->child[i]->id]) { q.push_back(cur->child[i]); seen[cur->child[i]->id] = 1; }
+    }
+    if (trie->bin.size) {
+      bin_prepare(trie);
+      for (bin_node *b = trie->bin.first; b; b = b->next) order.push_back(b->data.read_length);
+    }
+  }
+  dump(out + "/order.i64", order.data(), order.size() * 8);
+
+  /* arithmetic coder on the reordered quality stream, factor 1 (N*L < 2^32) */
+  std::vector<uint8_t> qs((size_t)N * L);
+  for (int64_t k = 0; k < N; k++) memcpy(&qs[(size_t)k * L], &quals[(size_t)order[k] * L], L);
+  static ac_stat as;
+  for (int i = 0; i < AC_DEPTH * AC_DEPTH * AC_DEPTH; i++) if (!ac_freq4[0][i]) ac_freq4[0][i] = 1;
+  as = ac_stat(ac_freq3[0], ac_freq4[0]);
+  const size_t BS = 10 * 1024 * 1024;
+  std::vector<uint8_t> enc, blk(BS * 2), dec(BS);
+  size_t bad = 0;
+  for (size_t off = 0; off < qs.size(); off += BS) {
+    size_t n = qs.size() - off < BS ? qs.size() - off : BS;
+    ac_coder ax(blk.data(), &as);
+    ax.write(&qs[off], (int)n);
+    ax.flush();
+    uint32_t sz = (uint32_t)(ax.output() - blk.data());
+    enc.insert(enc.end(), (uint8_t *)&sz, (uint8_t *)&sz + 4);
+    enc.insert(enc.end(), blk.data(), blk.data() + sz);
+    ac_decoder ad(&as, blk.data());
+    ad.read(dec.data(), (int)n);
+    if (memcmp(dec.data(), &qs[off], n)) bad++;
+  }
+  dump(out + "/ac.bin", enc.data(), enc.size());
+  fprintf(stderr, "ref_driver: %lld reads, L=%d, %d cores, %zu AC bytes, decode %s\n", (long long)N, L, np,
+          enc.size(), bad ? "MISMATCH" : "ok");
+  return bad ? 1 : 0;
+}
