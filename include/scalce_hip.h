@@ -1,0 +1,143 @@
+/*
+ * scalce_hip.h -- C ABI of the MI355X (gfx950) SCALCE hot path.
+ *
+ * The reference (sfu-compbio/scalce 2.8) has no plugin / FFI seam: it is one executable with
+ * global state, and its hot path is a set of per-read calls made from thread()
+ * (compress.cpp:673-706) and per-stream calls made from the final writer
+ * (compress.cpp:296-335,380-391,411-412).  Per-read signatures cannot be driven from a GPU,
+ * so every entry point below is the BATCHED equivalent of the reference functions it names.
+ * Plain C types, caller-visible integer status, no global state, one context per device.
+ *
+ * Pointers whose name starts with d_ are DEVICE pointers (HBM); `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  All calls are asynchronous on `stream`
+ * unless stated otherwise; scalce_batch_finish() synchronises and reports device-side errors.
+ */
+#ifndef SCALCE_HIP_H
+#define SCALCE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCALCE_OK 0
+#define SCALCE_ERR_ARG 1       /* bad argument / state */
+#define SCALCE_ERR_HIP 2       /* HIP runtime failure (message in scalce_last_error) */
+#define SCALCE_ERR_FORMAT 3    /* malformed input: the cases where the reference prints (ERROR) and exits */
+#define SCALCE_ERR_CAPACITY 4  /* batch larger than the capacity it was created with */
+
+#define SCALCE_AC_DEPTH 80                  /* arithmetic.h:47 */
+#define SCALCE_AC_BLOCK (10 * 1024 * 1024)  /* arithmetic.cpp:48 */
+#define SCALCE_ROOT_CORE 0x3FFFFFFF         /* MAXBIN-1: const.h:95, reads.cpp:161-164 */
+
+typedef struct scalce_ctx scalce_ctx;
+typedef struct scalce_batch scalce_batch;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int scalce_ctx_create(int device, scalce_ctx **out);
+void scalce_ctx_destroy(scalce_ctx *ctx);
+const char *scalce_last_error(const scalce_ctx *ctx);
+
+/* ---- core table: read_patterns (reads.cpp:330-377), read_patterns_from_file (:379-410),
+ *      pattern_insert (:253-267), prepare_aho_automata (:270-324).  Built on the host,
+ *      uploaded as a BFS-ordered DFA (state id == the reference's BFS `id`, root 0). ------- */
+int scalce_patterns_load_bin(scalce_ctx *ctx, const void *blob, size_t nbytes);
+int scalce_patterns_load_text(scalce_ctx *ctx, const char *text, size_t nbytes);
+int scalce_patterns_count(const scalce_ctx *ctx);   /* cores in file order (the index .scalcer stores) */
+int scalce_patterns_states(const scalce_ctx *ctx);  /* automaton states, root included */
+int scalce_patterns_buckets(const scalce_ctx *ctx); /* distinct cores = buckets, root excluded */
+/* core string / length by file-order index (decompress.cpp:269,341 use patterns[core]) */
+int scalce_pattern_length(const scalce_ctx *ctx, int pattern);
+const char *scalce_pattern_string(const scalce_ctx *ctx, int pattern);
+
+/* ---- quality model: quality_mapping_init (qualities.cpp:58-175), host only --------------- */
+typedef struct {
+  int32_t offset;      /* 33 or 64 */
+  int32_t values[128]; /* replacement table */
+} scalce_qmap;
+/* stat[c] = occurrences of quality character c in the sampled records */
+void scalce_qmap_init(scalce_qmap *q, const int32_t stat[128], int lossy_percentage);
+
+/* ---- batch: one FASTQ shard resident in HBM --------------------------------------------- */
+typedef struct {
+  int32_t read_len[2];       /* bases per read, mate 1 / mate 2 (read_length[], compress.cpp:61) */
+  int32_t paired;            /* -r */
+  int32_t use_names;         /* 0 under -n */
+  int32_t no_ac;             /* -A */
+  scalce_qmap qmap[2];
+  uint64_t bucket_set_size;  /* -B in bytes (spill rule, compress.cpp:702-715); 0 = never spill */
+  /* state carried in from earlier shards of the same run (multi-GPU / multi-file); NULL = none */
+  uint32_t qprev[2][2];      /* last two quality symbols before this shard, 500 = none (qualities.cpp:179) */
+} scalce_params;
+
+void scalce_params_default(scalce_params *p);
+/* Allocates every device buffer a shard of up to max_reads records / max_text bytes per mate
+ * needs.  Synchronous. */
+int scalce_batch_create(scalce_ctx *ctx, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
+                        scalce_batch **out);
+void scalce_batch_destroy(scalce_batch *b);
+
+/* record reader of thread() (compress.cpp:614-666): newline index of the FASTQ text of one
+ * mate, validation of the fixed read length, 2-bit packing of the bases (getval, const.cpp:47),
+ * name slicing (output_name, names.cpp:48-62).  d_text must stay valid until emit. */
+int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_text, uint64_t nbytes, void *stream);
+/* output_quality (qualities.cpp:177-204): q' = map[q]-offset (N -> 0) and the order-2 trigram
+ * counters ac_freq4 over the input-order stream of this shard. */
+int scalce_batch_quality(scalce_batch *b, void *stream);
+/* aho_search (reads.cpp:413-429) for every read, including the cumulative bin_size tie-break
+ * resolved exactly in input order (-T 1 semantics).  d_prior_counts: per-bucket counts of reads
+ * assigned by EARLIER shards (bucket order = scalce_bucket_*), or NULL. */
+int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior_counts, void *stream);
+/* aho_trie_bucket + aho_output + bin_prepare/_radix_sort (reads.cpp:233-250,466-499,547-634)
+ * + the merge order of spilled chunks (compress.cpp:104-159): the output permutation. */
+int scalce_batch_order(scalce_batch *b, void *stream);
+/* output_read (reads.cpp:432-461) + bin_dump (:91-180) + per-bucket headers
+ * (compress.cpp:364-379): the .scalcer / .scalcen payloads and the reordered quality stream. */
+int scalce_batch_emit(scalce_batch *b, void *stream);
+/* table scaling (compress.cpp:296-320), ac_stat (arithmetic.cpp:54-78) and ac_write /
+ * ac_coder (:85-169,318-363): [u32 size][bytes] per 10 MiB block of the reordered stream.
+ * d_table_override (512000 x u32 per mate, already scaled) replaces this shard's own
+ * statistics when the run-wide table was reduced across shards; NULL = use own. */
+int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream);
+/* all of the above in order */
+int scalce_batch_compress(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2,
+                          uint64_t n2, void *stream);
+/* Synchronises `stream`, checks the device error word, fills the host-side result sizes. */
+int scalce_batch_finish(scalce_batch *b, void *stream);
+
+/* results (device pointers owned by the batch; sizes valid after scalce_batch_finish) */
+enum {
+  SCALCE_OUT_READS = 0,     /* .scalcer payload after the 16-byte header, mate m            */
+  SCALCE_OUT_NAMES = 1,     /* .scalcen payload after magic+flag (empty under -n), mate 1    */
+  SCALCE_OUT_QUAL = 2,      /* .scalceq payload after header+table+total: AC blocks, or raw q' under -A */
+  SCALCE_OUT_TABLE = 3,     /* 512000 x u32 scaled frequency table (file order), mate m      */
+  SCALCE_OUT_FREQ4 = 4,     /* 512000 x u64 raw trigram counters of this shard, mate m       */
+  SCALCE_OUT_TOKENS = 5,    /* N x {int32 pattern (file order, -1 = none), int32 end}, input order */
+  SCALCE_OUT_PERM = 6,      /* N x u32: input index of the k-th emitted record               */
+  SCALCE_OUT_QSTREAM = 7,   /* N*L bytes: reordered q' stream, mate m                         */
+  SCALCE_OUT_BUCKET_COUNTS = 8, /* (buckets+1) x u64 reads per bucket, emission order, root last */
+  SCALCE_OUT_QINPUT = 9     /* N*L bytes: q' in input order, mate m                          */
+};
+int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes);
+uint64_t scalce_batch_reads(const scalce_batch *b);
+/* measurement hook for bench.py: accumulated device time (ms, hipEvent) and launch count of
+ * stage `which` (0 ingest,1 quality,2 tokenize,3 order,4 emit,5 entropy) since the last reset */
+int scalce_batch_stage_ms(scalce_batch *b, int which, float *ms, int *launches);
+void scalce_batch_stage_reset(scalce_batch *b, int enable);
+
+/* plumbing for hosts without a HIP binding of their own (ctypes, cgo): blocking copies */
+int scalce_memcpy_d2h(scalce_ctx *ctx, void *dst_host, const void *src_dev, uint64_t nbytes);
+int scalce_memcpy_h2d(scalce_ctx *ctx, void *dst_dev, const void *src_host, uint64_t nbytes);
+/* diagnostics of the last tokenize call: tie reads, candidate events, fixed-point iterations, spill chunks */
+int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]);
+
+/* ---- decode side (next row of SURVEY 8f-1): ac_read / ac_decoder (arithmetic.cpp:173-268,
+ *      365-400).  d_blocks = [u32 size][bytes]... as written by scalce_batch_entropy. ---------- */
+int scalce_ac_decode(scalce_ctx *ctx, const uint32_t *table_host, const uint8_t *d_blocks, uint64_t nbytes,
+                     uint64_t nsymbols, uint8_t *d_symbols_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCALCE_HIP_H */

@@ -1,0 +1,262 @@
+// kernels_ac.hpp -- static order-2 arithmetic coder over the reordered quality stream.
+// Reference: ac_stat (/root/reference/arithmetic.cpp:54-78), ac_coder::{reset,O,write,flush}
+// (:85-169), block framing of ac_write/thread_c (:280-287,318-363), table scaling
+// (compress.cpp:296-320), decoder (:173-268).
+//
+// Parallelism is the reference's own: independent 10 MiB blocks.  Inside a block the coder state
+// (lo, hi, underflow) is a serial chain, so one 64-lane wavefront owns one block:
+//   * all 64 lanes fetch the next 64 symbols, form their contexts and gather the two cumulative
+//     bounds of each symbol in parallel (the table lookups do not depend on the coder state);
+//   * the bounds are stored as 64-bit reciprocal fractions g = floor(c * 2^64 / total) + 1, so
+//     the two 64/32-bit divisions of arithmetic.cpp:131-132 become multiply-high:
+//       floor(range * c / total) == floor(range * g / 2^64)   for range <= 2^32, c < total < 2^32
+//     (error of g is at most 2^-64, times range at most 2^-32 < 1/total, so no integer is crossed);
+//   * the serial part then walks the 64 staged operands from LDS (broadcast reads) with the
+//     renormalisation loop of :133-152 in closed form (count-leading-zeros instead of bit steps).
+#pragma once
+#include "kernels_order.hpp"
+
+namespace scalce {
+
+constexpr int AC_D = 80;
+constexpr u32 AC_BLOCK_SYMS = 10u * 1024u * 1024u;
+
+// scaled table: max(1, (1 + count) / factor)  (all counters start at 1, qualities.cpp:191-196;
+// compress.cpp:310-313)
+__global__ __launch_bounds__(256) void ac_scale_k(const u64 *freq4, u32 factor, u32 *table) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= AC_D * AC_D * AC_D) return;
+  u64 p = (freq4[i] + 1) / factor;
+  table[i] = p ? (u32)p : 1u;
+}
+
+// per (context, symbol): {g(lo) low, g(lo) high, g(hi) low, g(hi) high}; g(hi) == 0 marks hi == total
+__device__ __forceinline__ u64 recip_frac(u32 c, u32 d) {
+  const u64 qh = ((u64)c << 32) / d;
+  const u64 rem = ((u64)c << 32) - qh * d;
+  const u64 ql = (rem << 32) / d;
+  return ((qh << 32) | ql) + 1;
+}
+__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/) {
+  const u32 ctx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ctx >= AC_D * AC_D) return;
+  const u32 *f = table + (u64)ctx * AC_D;
+  u32 tot = 0;
+  for (int s = 0; s < AC_D; s++) tot += f[s];
+  u32 run = 0;
+  u64 glo = 1;  // c == 0 -> quotient 0
+  cum[ctx * 81] = 0;
+  for (int s = 0; s < AC_D; s++) {
+    run += f[s];
+    cum[ctx * 81 + s + 1] = run;
+    const u64 ghi = (run == tot) ? 0ull : recip_frac(run, tot);
+    tab[(u64)ctx * AC_D + s] = make_uint4((u32)glo, (u32)(glo >> 32), (u32)ghi, (u32)(ghi >> 32));
+    glo = ghi;
+  }
+}
+
+struct AcEncArgs {
+  const u8 *sym;
+  u64 nsym;
+  const uint4 *tab;
+  u8 *out;          // block b writes at out + b * out_stride (multiple of 4)
+  u64 out_stride;
+  u32 out_cap;      // bytes a block may write (multiple of 4)
+  u32 *out_size;
+  DevErr *err;
+};
+
+struct BitSink {
+  u32 *dst;
+  u32 wpos, wcap;
+  u64 acc;
+  u32 nb;
+  bool over;
+  __device__ __forceinline__ void put(u32 bits, u32 n) {  // n <= 32, bits right-aligned
+    acc = (acc << n) | bits;
+    nb += n;
+    if (nb >= 32) {
+      const u32 w = (u32)(acc >> (nb - 32));
+      if (wpos < wcap) {
+        if (lane_id() == 0) dst[wpos] = __builtin_bswap32(w);
+      } else over = true;
+      wpos++;
+      nb -= 32;
+    }
+  }
+  __device__ __forceinline__ void run(u32 bit, u32 count) {
+    while (count) {
+      const u32 m = count < 32 ? count : 32;
+      put(bit ? (m == 32 ? 0xFFFFFFFFu : ((1u << m) - 1)) : 0u, m);
+      count -= m;
+    }
+  }
+};
+
+// floor((R + 1) * g / 2^64) for R < 2^32, g < 2^64
+__device__ __forceinline__ u32 mulfrac(u32 R, u32 g_lo, u32 g_hi) {
+  const u64 t0 = (u64)R * g_lo + g_lo;
+  const u64 t1 = (u64)R * g_hi + g_hi + (t0 >> 32);
+  return (u32)(t1 >> 32);
+}
+
+__global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
+  __shared__ uint4 ops[2][64];
+  const u32 blk = blockIdx.x;
+  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
+  const u8 *s = a.sym + boff;
+  const u32 n = (u32)((a.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.nsym - boff) : (u64)AC_BLOCK_SYMS);
+  const int lane = lane_id();
+  BitSink o;
+  o.dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
+  o.wpos = 0; o.wcap = a.out_cap / 4; o.acc = 0; o.nb = 0; o.over = false;
+  // the first two symbols travel raw (arithmetic.cpp:110-120)
+  o.put(s[0], 8);
+  o.put(n > 1 ? s[1] : 0u, 8);
+  u32 lo = 0, hi = 0xFFFFFFFFu, underflow = 0;
+
+  auto gather = [&](u32 base) -> uint4 {
+    const u32 i = base + lane;
+    if (i < 2 || i >= n) return make_uint4(0, 0, 0, 0);
+    const u32 p0 = s[i - 2], p1 = s[i - 1], c = s[i];
+    if (p0 >= AC_D || p1 >= AC_D || c >= AC_D) return make_uint4(0, 0, 0, 0);  // E_SYMBOL was raised at ingest
+    return a.tab[((u64)p0 * AC_D + p1) * AC_D + c];
+  };
+
+  uint4 cur = gather(0);
+  for (u32 base = 0; base < n; base += 64) {
+    const int buf = (base >> 6) & 1;
+    ops[buf][lane] = cur;
+    if (base + 64 < n) cur = gather(base + 64);  // in flight during the serial part below
+    const u32 cnt = (n - base) < 64 ? (n - base) : 64;
+    for (u32 j = (base == 0 ? 2u : 0u); j < cnt; j++) {
+      const uint4 g = ops[buf][j];
+      const u32 R = hi - lo;
+      const u32 qa = mulfrac(R, g.z, g.w);
+      const u32 qb = mulfrac(R, g.x, g.y);
+      const u32 nhi = ((g.z | g.w) == 0) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
+      lo = lo + qb;
+      hi = nhi;
+      // renormalisation, arithmetic.cpp:133-152 in closed form
+      const u32 x = lo ^ hi;
+      const u32 k = x ? (u32)__clz(x) : 32u;  // leading bits on which lo and hi agree
+      if (k) {
+        const u32 msb = hi >> 31;
+        o.put(msb, 1);
+        o.run(msb ^ 1, underflow);
+        underflow = 0;
+        if (k > 1) o.put((hi << 1) >> (33 - k), k - 1);
+        if (k == 32) { lo = 0; hi = 0xFFFFFFFFu; }
+        else { lo <<= k; hi = (hi << k) | ((1u << k) - 1); }
+      }
+      // "underflow ante portas": lo = 01.., hi = 10.. -> drop the second bit, remember it
+      const u32 y = (lo & ~hi) << 1;
+      const u32 u = (u32)__clz(~y);  // leading ones of y; y has bit 0 clear so u <= 31
+      if (u) {
+        underflow += u;
+        lo = (lo << u) & 0x7FFFFFFFu;
+        hi = (hi << u) | ((1u << u) - 1) | 0x80000000u;
+      }
+    }
+  }
+  // flush, arithmetic.cpp:160-169
+  const u32 b30 = (lo >> 30) & 1;
+  o.put(b30, 1);
+  o.run(b30 ^ 1, underflow + 1);
+  const u64 bits = (u64)o.wpos * 32 + o.nb;
+  const u32 bytes = (u32)((bits + 7) >> 3);
+  if (o.nb) {
+    const u32 w = (u32)(o.acc << (32 - o.nb));
+    if (o.wpos < o.wcap) {
+      if (lane == 0) o.dst[o.wpos] = __builtin_bswap32(w);
+    } else o.over = true;
+  }
+  if (lane == 0) {
+    a.out_size[blk] = bytes;
+    if (o.over) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
+  }
+}
+
+// [u32 size][bytes] framing (arithmetic.cpp:335-336,355-356): block b goes to dst_off[b]
+struct AcFrameLen {
+  const u32 *sizes;
+  __device__ u64 operator()(u64 b) const { return 4ull + sizes[b]; }
+};
+__global__ __launch_bounds__(256) void ac_frame_k(const u8 *blocks, u64 stride, const u32 *sizes, const u64 *dst_off,
+                                                 u8 *out) {
+  const u32 b = blockIdx.y;
+  const u32 sz = sizes[b];
+  u8 *dst = out + dst_off[b];
+  const u8 *src = blocks + (u64)b * stride;
+  const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i0 == 0)
+    for (int k = 0; k < 4; k++) dst[k] = (u8)(sz >> (8 * k));
+  for (u64 i = i0; i < i0 + 16 && i < sz; i++) dst[4 + i] = src[i];
+}
+
+// ---- decoder (next row): one wavefront per block; the symbol search of
+// read_single (arithmetic.cpp:205-209) is one ballot over the 80 cumulative bounds -----------
+struct AcDecArgs {
+  const u8 *in;          // framed stream
+  const u64 *blk_off;    // byte offset of each block's payload (after its size word)
+  const u32 *blk_size;
+  u64 nsym;
+  const u32 *cum;        // [6400][81]
+  u8 *out;
+};
+__global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
+  const u32 blk = blockIdx.x;
+  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
+  const u32 n = (u32)((a.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.nsym - boff) : (u64)AC_BLOCK_SYMS);
+  const u8 *in = a.in + a.blk_off[blk];
+  const u32 insz = a.blk_size[blk];
+  u8 *out = a.out + boff;
+  const int lane = lane_id();
+  u32 p0 = insz > 0 ? in[0] : 0, p1 = insz > 1 ? in[1] : 0;
+  if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
+  if (p0 >= AC_D) p0 = AC_D - 1;  // corrupt stream: stay inside the tables
+  if (p1 >= AC_D) p1 = AC_D - 1;
+  u64 bitpos = 16;
+  auto getbits = [&](u32 cnt) -> u32 {  // cnt <= 32, MSB first, zeros past the end
+    u64 v = 0;
+    const u64 byte = bitpos >> 3;
+    for (int k = 0; k < 6; k++) v = (v << 8) | (byte + k < insz ? in[byte + k] : 0u);
+    const u32 sh = 48 - (u32)(bitpos & 7) - cnt;
+    bitpos += cnt;
+    return cnt ? (u32)((v >> sh) & (cnt == 32 ? 0xFFFFFFFFull : ((1ull << cnt) - 1))) : 0u;
+  };
+  u32 lo = 0, hi = 0xFFFFFFFFu, code = getbits(32);
+  for (u32 i = 2; i < n; i++) {
+    const u32 *c = a.cum + (u64)(p0 * AC_D + p1) * 81;
+    const u32 tot = c[80];
+    const u64 range = (u64)(hi - lo) + 1;
+    const u32 count = (u32)((((u64)(code - lo) + 1) * tot - 1) / range);
+    // first symbol whose upper bound exceeds count: lanes test bounds lane+1 and lane+65
+    const u64 m0 = __ballot(count < c[lane + 1]);
+    const u64 m1 = __ballot(lane + 65 <= 80 && count < c[lane + 65 <= 80 ? lane + 65 : 80]);
+    const u32 k = m0 ? (u32)(__ffsll((long long)m0) - 1) : (m1 ? 64u + (u32)(__ffsll((long long)m1) - 1) : 79u);
+    const u32 chi = c[k + 1], clo = c[k];
+    hi = (u32)(lo + (range * chi) / tot - 1);
+    lo = (u32)(lo + (range * clo) / tot);
+    const u32 x = lo ^ hi;
+    const u32 kk = x ? (u32)__clz(x) : 32u;
+    if (kk) {
+      if (kk == 32) { lo = 0; hi = 0xFFFFFFFFu; code = getbits(32); }
+      else { lo <<= kk; hi = (hi << kk) | ((1u << kk) - 1); code = (code << kk) | getbits(kk); }
+    }
+    const u32 y = (lo & ~hi) << 1;
+    const u32 u = (u32)__clz(~y);
+    if (u) {  // each underflow step: code ^= 0x40000000 then shift in one bit (arithmetic.cpp:228-238)
+      lo = (lo << u) & 0x7FFFFFFFu;
+      hi = (hi << u) | ((1u << u) - 1) | 0x80000000u;
+      // u steps of code = ((code ^ 0x40000000) << 1) | bit: every step drops the top bit and promotes the
+      // inverted second bit, so after u steps the top bit is ~c[31-u] and the rest is code << u
+      code = ((code << u) ^ 0x80000000u) | getbits(u);
+    }
+    if (lane == 0) out[i] = (u8)k;
+    p0 = p1;
+    p1 = k;
+  }
+}
+
+}  // namespace scalce

@@ -1,0 +1,238 @@
+// kernels_ingest.hpp -- FASTQ text in HBM -> per-record structure-of-arrays.
+//   index:   newline positions of the text (the f_gets record reader of thread(),
+//            /root/reference/compress.cpp:614-666)
+//   unpack:  2-bit bases (getval, const.cpp:47-49), q' = map[q]-offset with N -> 0
+//            (output_quality, qualities.cpp:183), stored-name length (output_name, names.cpp:55-57)
+//   trigram: order-2 context counters over the input-order q' stream (qualities.cpp:185-198)
+// All three are streaming, HBM-bound kernels.
+#pragma once
+#include "prims.hpp"
+
+namespace scalce {
+
+enum DevErrCode : u32 {
+  E_NONE = 0,
+  E_LINES = 1,      // newline count not a multiple of 4 / text does not end in '\n'
+  E_READLEN = 2,    // a sequence or quality line whose length differs from read_length (compress.cpp:628-634)
+  E_NAMELEN = 3,    // stored name longer than 255 bytes (names.cpp:57 keeps the length in one byte)
+  E_SYMBOL = 4,     // quality symbol >= 80 with the arithmetic coder on (arithmetic.h:47, tables are 80 wide)
+  E_ACOVERFLOW = 5, // a coded block outgrew the reference's 10 MiB output buffer (arithmetic.cpp:101)
+  E_PAIRS = 6,      // mates have different record counts
+  E_INTERNAL = 7
+};
+struct DevErr {
+  u32 code;
+  u32 aux;
+  u64 where;
+};
+__device__ __forceinline__ void dev_fail(DevErr *e, u32 code, u64 where, u32 aux = 0) {
+  if (atomicCAS(&e->code, 0u, code) == 0u) {
+    e->where = where;
+    e->aux = aux;
+  }
+}
+
+// 0x80 in every byte of x that is zero, exact (no borrow artefacts)
+__device__ __forceinline__ u32 zero_bytes(u32 x) {
+  u32 t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ u32 newline_mask16(uint4 v) {  // bit i = byte i is '\n'
+  u32 m = 0;
+  u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    u32 z = zero_bytes(w[k] ^ 0x0A0A0A0Au);  // 0x80 flags at bits 7,15,23,31
+    u32 bits = ((z >> 7) & 1) | ((z >> 14) & 2) | ((z >> 21) & 4) | ((z >> 28) & 8);
+    m |= bits << (4 * k);
+  }
+  return m;
+}
+
+constexpr int IDX_THREADS = 256;
+constexpr int IDX_CHUNKS = 4;                            // 16-byte chunks per thread
+constexpr int IDX_TILE = IDX_THREADS * IDX_CHUNKS * 16;  // 16 KiB of text per workgroup
+
+__device__ __forceinline__ u64 text_mask64(const u8 *text, u64 n, u64 off) {
+  // newline bitmask of text[off, off+64); off is a multiple of 64, text 16-byte aligned
+  u64 m = 0;
+  if (off + 64 <= n) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(text + off);
+#pragma unroll
+    for (int c = 0; c < IDX_CHUNKS; c++) m |= (u64)newline_mask16(p[c]) << (16 * c);
+  } else {
+    for (u64 i = off; i < n; i++) m |= (u64)(text[i] == '\n') << (i - off);
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(IDX_THREADS) void index_count_k(const u8 *text, u64 n, u64 *tile_counts) {
+  __shared__ u32 sm[4];
+  const u64 off = (u64)blockIdx.x * IDX_TILE + (u64)threadIdx.x * 64;
+  u32 c = off < n ? (u32)__popcll(text_mask64(text, n, off)) : 0u;
+  u32 tot;
+  block_exclusive_sum<u32, 4>(c, &tot, sm);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(IDX_THREADS) void index_write_k(const u8 *text, u64 n, const u64 *tile_base,
+                                                            u64 *line_end, u64 max_lines) {
+  __shared__ u32 sm[4];
+  const u64 off = (u64)blockIdx.x * IDX_TILE + (u64)threadIdx.x * 64;
+  u64 m = off < n ? text_mask64(text, n, off) : 0ull;
+  u32 tot;
+  u64 g = tile_base[blockIdx.x] + block_exclusive_sum<u32, 4>((u32)__popcll(m), &tot, sm);
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    if (g < max_lines) line_end[g] = off + b;
+    g++;
+  }
+}
+
+// ---- per-record unpack ------------------------------------------------------------------------
+struct UnpackArgs {
+  const u8 *text;
+  u64 nbytes;
+  const u64 *line_end;  // 4 per record
+  u64 nrec;
+  int L, stride, mate, use_names, no_ac;
+  u8 *packed;     // nrec * stride, zero padded rows, base 4j..4j+3 in byte j, first base in bits 7-6
+  u8 *q;          // nrec * L
+  u8 *namelen;    // nrec (mate 0 only)
+  const u8 *qlut;  // 128 bytes: (values[c] - offset) & 255
+  DevErr *err;
+};
+
+// 2-bit codes of four ASCII bases packed in a little-endian word -> one byte, first base in bits 7-6.
+// Only C/c, G/g, T/t map to 1,2,3; every other byte is 0 (getval, const.cpp:47-49).
+__device__ __forceinline__ u32 pack4(u32 v) {
+  const u32 up = v & 0xDFDFDFDFu;                                // fold case
+  const u32 code = ((v >> 1) ^ (v >> 2)) & 0x03030303u;          // A0 C1 G2 T3 on the letters themselves
+  u32 ok = zero_bytes(up ^ 0x43434343u) | zero_bytes(up ^ 0x47474747u) | zero_bytes(up ^ 0x54545454u);
+  ok = (ok >> 7) * 3u;                                            // 0x80 flag -> 0x03 mask per byte
+  const u32 c = code & ok;
+  return ((c & 3u) << 6) | (((c >> 8) & 3u) << 4) | (((c >> 16) & 3u) << 2) | ((c >> 24) & 3u);
+}
+
+// aligned little-endian word; bytes at or past `n` read as 0
+__device__ __forceinline__ u32 load_word(const u8 *t, u64 a, u64 n) {
+  if (a + 4 <= n) return *reinterpret_cast<const u32 *>(t + a);
+  u32 v = 0;
+  for (int k = 0; k < 4; k++)
+    if (a + k < n) v |= (u32)t[a + k] << (8 * k);
+  return v;
+}
+// unaligned little-endian 32-bit fetch with a bound
+__device__ __forceinline__ u32 load_u32_unaligned(const u8 *t, u64 at, u64 n) {
+  const u64 a = at & ~3ull;
+  const u32 sh = (u32)(at & 3) * 8;
+  const u32 lo = load_word(t, a, n);
+  if (!sh) return lo;
+  const u32 hi = load_word(t, a + 4, n);
+  return (lo >> sh) | (hi << (32 - sh));
+}
+
+__global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
+  __shared__ u8 lut[128];
+  if (threadIdx.x < 128) lut[threadIdx.x] = a.qlut[threadIdx.x];
+  __syncthreads();
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.nrec) return;
+  const u64 p0 = a.line_end[4 * r], p1 = a.line_end[4 * r + 1], p2 = a.line_end[4 * r + 2], p3 = a.line_end[4 * r + 3];
+  if (p1 - p0 - 1 != (u64)a.L || p3 - p2 - 1 != (u64)a.L) {
+    dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
+    return;
+  }
+  const int L = a.L;
+  u8 *prow = a.packed + r * (u64)a.stride;
+  u8 *qrow = a.q + r * (u64)L;
+  const u64 sb = p0 + 1, sq = p2 + 1;
+  u32 acc = 0;
+  int nacc = 0, wout = 0;
+  bool bad = false;
+  for (int i = 0; i < L; i += 4) {
+    u32 vb = load_u32_unaligned(a.text, sb + i, a.nbytes);
+    u32 vq = load_u32_unaligned(a.text, sq + i, a.nbytes);
+    const int rem = L - i;
+    if (rem < 4) {  // last partial group: bytes beyond the line are not part of the read
+      const u32 keep = (1u << (8 * rem)) - 1;
+      vb &= keep;
+      vq &= keep;
+    }
+    acc |= pack4(vb) << (8 * nacc);
+    if (++nacc == 4) {
+      *reinterpret_cast<u32 *>(prow + 4 * wout) = acc;
+      wout++;
+      acc = 0;
+      nacc = 0;
+    }
+    // q' (qualities.cpp:183): exactly 'N' forces the offset, i.e. symbol 0
+    const u32 isN = (zero_bytes(vb ^ 0x4E4E4E4Eu) >> 7) * 0xFFu;
+    u32 qq = (u32)lut[vq & 127] | ((u32)lut[(vq >> 8) & 127] << 8) | ((u32)lut[(vq >> 16) & 127] << 16) |
+             ((u32)lut[(vq >> 24) & 127] << 24);
+    qq &= ~isN;
+    if (rem >= 4) {
+      if (((u64)qrow & 3) == 0)
+        *reinterpret_cast<u32 *>(qrow + i) = qq;
+      else {
+        qrow[i] = (u8)qq; qrow[i + 1] = (u8)(qq >> 8); qrow[i + 2] = (u8)(qq >> 16); qrow[i + 3] = (u8)(qq >> 24);
+      }
+      if (!a.no_ac && ((((qq & 0x7F7F7F7Fu) + 0x30303030u) | qq) & 0x80808080u)) bad = true;  // a byte >= 80
+    } else {
+      for (int k = 0; k < rem; k++) qrow[i + k] = (u8)(qq >> (8 * k));
+      qq &= (1u << (8 * rem)) - 1;
+      if (!a.no_ac && ((((qq & 0x7F7F7F7Fu) + 0x30303030u) | qq) & 0x80808080u)) bad = true;  // a byte >= 80
+    }
+  }
+  // flush the partial word and zero the rest of the row
+  for (int w = wout; w < a.stride / 4; w++) {
+    *reinterpret_cast<u32 *>(prow + 4 * w) = acc;
+    acc = 0;
+  }
+  if (bad) dev_fail(a.err, E_SYMBOL, r);
+  if (a.mate == 0) {
+    // output_name, names.cpp:55-57: characters after '@' up to the first space or the newline
+    const u64 ns = r ? a.line_end[4 * r - 1] + 1 : 0;
+    u32 len = 0;
+    if (a.use_names) {
+      u64 i = ns + 1;
+      while (i < p0 && a.text[i] != ' ') i++;
+      const u64 l = i - (ns + 1);
+      if (l > 255 || p0 <= ns) dev_fail(a.err, E_NAMELEN, r);
+      len = (u32)(l & 255);
+    }
+    a.namelen[r] = (u8)len;
+  }
+}
+
+// ---- trigram counters -------------------------------------------------------------------------
+// freq4[(p0*80+p1)*80+s] += 1 for every symbol of the flat input-order stream that has two
+// predecessors (cross-read predecessors included: the reference's prev[] is static,
+// qualities.cpp:179).  prev0/prev1 = the two symbols before this shard (500 = none).
+constexpr int TRI_PER_THREAD = 256;
+__global__ __launch_bounds__(256) void trigram_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u64 *freq4) {
+  const u64 start = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * TRI_PER_THREAD;
+  if (start >= n) return;
+  const u64 stop = start + TRI_PER_THREAD < n ? start + TRI_PER_THREAD : n;
+  u32 a = start >= 2 ? q[start - 2] : (start == 1 ? prev1 : prev0);
+  u32 b = start >= 1 ? q[start - 1] : prev1;
+  u32 lastkey = 0xFFFFFFFFu, run = 0;
+  for (u64 t = start; t < stop; t++) {
+    const u32 s = q[t];
+    if (a < 80 && b < 80 && s < 80) {
+      const u32 key = (a * 80 + b) * 80 + s;
+      if (key == lastkey) run++;
+      else {
+        if (run) atomicAdd(&freq4[lastkey], (u64)run);
+        lastkey = key;
+        run = 1;
+      }
+    }
+    a = b;
+    b = s;
+  }
+  if (run) atomicAdd(&freq4[lastkey], (u64)run);
+}
+
+}  // namespace scalce

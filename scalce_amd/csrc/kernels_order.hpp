@@ -1,0 +1,185 @@
+// kernels_order.hpp -- bucket/reorder and stream emission.
+//   order: the permutation aho_output + bin_prepare produce (/root/reference/reads.cpp:466-499,
+//          547-634): buckets by BFS id, root last; inside a bucket, spill chunks in order
+//          (merhamet_merge, compress.cpp:104-159); inside a chunk a stable sort on the suffix that
+//          follows the core, right-padded with A (_POS, reads.cpp:557-558).
+//          Done as LSD radix passes (prims.hpp) over u32 read indices: key digits from the least
+//          significant, then the chunk id, then the bucket id.
+//   emit:  rotated 2-bit records with their end marker and the per-bucket headers of .scalcer
+//          (output_read reads.cpp:432-461, bin_dump :114-131, compress.cpp:364-379), the name
+//          stream, and the quality stream in output order.
+#pragma once
+#include "kernels_token.hpp"
+
+namespace scalce {
+
+// digit d of the sort key of read v: stored bases 4d..4d+3 of the rotated read, i.e. original
+// bases end+4d .. end+4d+3, each replaced by 0 (A) once it runs past the read (reads.cpp:557-558)
+struct KeyDigit {
+  const u8 *packed;
+  const u16 *end;
+  int L, stride, d;
+  __device__ u32 operator()(u32 v) const {
+    const int s = (int)end[v] + 4 * d;  // first original base of this digit
+    if (s >= L) return 0u;
+    const u8 *row = packed + (u64)v * stride;
+    const int byte = s >> 2, sh = (s & 3) * 2;
+    u32 w = ((u32)row[byte] << 8) | (u32)row[byte + 1];  // rows are zero padded past SZ_READ(L)
+    u32 dig = (w >> (8 - sh)) & 0xFFu;
+    const int valid = L - s;  // bases of this digit that exist
+    if (valid < 4) dig &= (0xFFu << (2 * (4 - valid))) & 0xFFu;
+    return dig;
+  }
+};
+
+// spill chunks (compress.cpp:702-715): running size of the records since the last dump; when it
+// reaches -B the current read closes the chunk.  rec_size is scanned inclusively into S; the
+// boundaries are found by one thread with binary searches (there are few chunks).
+struct RecSize {
+  const u32 *bucket;
+  const u32 *bucket_level;
+  const u8 *namelen;
+  int L0, L1, paired, use_names, has_qual;
+  __device__ u64 operator()(u64 r) const {
+    const int lv = (int)bucket_level[bucket[r]];
+    u64 sz = (use_names ? 1u + namelen[r] : 1u) + (u64)((L0 - lv + 3) >> 2) + (has_qual ? L0 : 0);
+    if (paired) sz += (u64)((L1 + 3) >> 2) + (has_qual ? L1 : 0);
+    return sz + 40;  // + sizeof(bin_node), compress.cpp:702
+  }
+};
+__global__ void chunk_bounds_k(const u64 *S /*exclusive prefix, S[n] = total*/, u64 n, u64 limit, u32 max_chunks,
+                               u64 *chunk_start /*[max_chunks+1]*/, u32 *nchunks) {
+  if (threadIdx.x || blockIdx.x) return;
+  u32 c = 0;
+  u64 start = 0;
+  chunk_start[0] = 0;
+  while (start < n && c + 1 < max_chunks) {
+    // smallest r >= start with S[r+1] - S[start] >= limit; the chunk is [start, r]
+    const u64 need = S[start] + limit;
+    u64 lo = start, hi = n;  // search r in [start, n)
+    while (lo < hi) {
+      const u64 mid = (lo + hi) >> 1;
+      if (S[mid + 1] >= need) hi = mid; else lo = mid + 1;
+    }
+    if (lo >= n) break;  // the tail never reaches the limit: last chunk runs to n
+    start = lo + 1;
+    chunk_start[++c] = start;
+  }
+  if (chunk_start[c] < n || c == 0) c++;  // trailing partial chunk (compress.cpp:799-801)
+  chunk_start[c] = n;
+  *nchunks = c;
+}
+__global__ __launch_bounds__(256) void chunk_assign_k(u64 n, const u64 *chunk_start, const u32 *nchunks, u32 *chunk) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  u32 lo = 0, hi = *nchunks;  // largest c with chunk_start[c] <= r
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (chunk_start[mid] <= r) lo = mid; else hi = mid;
+  }
+  chunk[r] = lo;
+}
+
+// ---- emission ---------------------------------------------------------------------------------
+// per bucket: first output position and byte offset of its header in the .scalcer payload
+struct BucketBytes {
+  const u64 *counts;
+  const u32 *bucket_level;
+  int L, sz_meta;
+  __device__ u64 operator()(u64 b) const {
+    const u64 c = counts[b];
+    return c ? 12 + c * (u64)(((L - (int)bucket_level[b] + 3) >> 2) + sz_meta) : 0;
+  }
+};
+
+struct EmitArgs {
+  u64 nrec;
+  const u32 *perm;
+  const u32 *bucket;
+  const u16 *end;
+  const u8 *packed;
+  int L, stride, sz_meta;
+  const u32 *bucket_level;
+  const int32_t *bucket_pattern;
+  const u64 *bucket_first;  // exclusive scan of counts
+  const u64 *bucket_off;    // exclusive scan of BucketBytes
+  const u64 *counts;
+  u8 *out;
+};
+__global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
+  const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.nrec) return;
+  const u32 r = a.perm[k];
+  const u32 b = a.bucket[r];
+  const int lv = (int)a.bucket_level[b];
+  const int e = a.end[r];
+  const int recsz = ((a.L - lv + 3) >> 2) + a.sz_meta;
+  const u64 first = a.bucket_first[b];
+  u8 *dst = a.out + a.bucket_off[b];
+  if (k == first) {  // [int32 core][int64 count], compress.cpp:365-378
+    const u32 core = (u32)a.bucket_pattern[b];
+    const u64 cnt = a.counts[b];
+    for (int i = 0; i < 4; i++) dst[i] = (u8)(core >> (8 * i));
+    for (int i = 0; i < 8; i++) dst[4 + i] = (u8)(cnt >> (8 * i));
+  }
+  dst += 12 + (k - first) * (u64)recsz;
+  // output_read(line, dest, n = e - lv, l = lv): bases [e, L) then [0, e - lv)
+  const u8 *row = a.packed + (u64)r * a.stride;
+  const int n = e ? e - lv : 0;
+  const int tail = a.L - e;       // bases after the core
+  const int total = tail + n;     // == L - lv when a core exists, L otherwise
+  int j = 0;
+  for (int o = 0; o < total; o += 4) {
+    u32 byte = 0;
+    for (int t = 0; t < 4; t++) {
+      const int q = o + t;
+      u32 c = 0;
+      if (q < total) {
+        const int src = q < tail ? e + q : q - tail;
+        c = base_at(row, src);
+      }
+      byte = (byte << 2) | c;
+    }
+    dst[j++] = (u8)byte;
+  }
+  dst[j] = (u8)e;  // end marker, reads.cpp:130
+  if (a.sz_meta == 2) dst[j + 1] = (u8)(e >> 8);
+}
+
+struct NameLenOut {  // bytes of the k-th emitted name record
+  const u32 *perm;
+  const u8 *namelen;
+  __device__ u64 operator()(u64 k) const { return 1ull + namelen[perm[k]]; }
+};
+__global__ __launch_bounds__(256) void emit_names_k(u64 nrec, const u32 *perm, const u8 *namelen, const u64 *line_end,
+                                                   const u8 *text, const u64 *name_off, u8 *out) {
+  const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec) return;
+  const u32 r = perm[k];
+  const u32 n = namelen[r];
+  const u64 src = (r ? line_end[4 * (u64)r - 1] + 1 : 0) + 1;  // skip '@'
+  u8 *dst = out + name_off[k];
+  dst[0] = (u8)n;
+  for (u32 i = 0; i < n; i++) dst[1 + i] = text[src + i];
+}
+
+// row gather: out[k] = rows[perm[k]], `width` bytes per row, row stride `stride` in the source
+__global__ __launch_bounds__(256) void gather_rows_k(u64 nrec, const u32 *perm, const u8 *rows, u64 stride, u32 width,
+                                                    u8 *out) {
+  // one thread per 4-byte word of the output when width % 4 == 0, else per byte
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((width & 3) == 0 && (stride & 3) == 0) {
+    const u32 wpr = width >> 2;
+    const u64 k = i / wpr;
+    if (k >= nrec) return;
+    const u32 w = (u32)(i - k * wpr);
+    reinterpret_cast<u32 *>(out)[i] = reinterpret_cast<const u32 *>(rows + (u64)perm[k] * stride)[w];
+  } else {
+    const u64 k = i / width;
+    if (k >= nrec) return;
+    const u32 w = (u32)(i - k * width);
+    out[i] = rows[(u64)perm[k] * stride + w];
+  }
+}
+
+}  // namespace scalce

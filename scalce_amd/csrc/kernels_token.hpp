@@ -1,0 +1,274 @@
+// kernels_token.hpp -- LCE tokenizer: longest core per read against the DFA, and the exact
+// resolution of the reference's order-dependent tie-break.
+//
+// aho_search (/root/reference/reads.cpp:413-429) keeps, among the longest cores found in a
+// read, the first one whose bucket currently holds the most reads (strict >), where "currently"
+// means all earlier reads of the run (bin_size is cumulative, reads.cpp:246).  Per read the scan
+// is independent; only reads that see two different cores of the same maximal length ("tie
+// reads") depend on earlier decisions.  The resolution here is a Jacobi fixed point over the
+// tie reads: every read's decision is re-evaluated in parallel from prefix counts of the current
+// decisions until nothing changes.  By induction on the input order the fixed point is unique
+// and equals the sequential result (the earliest undecided tie read only depends on settled
+// ones), so the outcome is bit-exact with -T 1.
+#pragma once
+#include "kernels_ingest.hpp"
+
+namespace scalce {
+
+constexpr u32 kNoOutD = 0xFFFFFFFFu;
+constexpr int kLevelShiftD = 25;
+constexpr u32 kBucketMaskD = (1u << kLevelShiftD) - 1;
+
+// Top of the automaton staged in LDS: states are numbered in BFS order, so ids < LDS_STATES are
+// the shallowest (most visited) ones.  20 bytes per state.
+constexpr int TOK_THREADS = 256;
+
+struct TokArgs {
+  const uint4 *next;    // 4 x u32 per state
+  const u32 *outinfo;   // level<<25 | bucket, or kNoOutD
+  u32 n_states;
+  u32 lds_states;       // how many leading states to stage (0 = none)
+  const u8 *packed;
+  u64 nrec;
+  int L, stride;
+  u32 root_bucket;      // bucket id of "no core" (== number of real buckets)
+  u32 *tok_bucket;      // first longest core (bucket id), or root_bucket
+  u32 *tok_pos;         // bits 0-15: index of the core's last base; bits 16-30: hits at max level; bit 31: tie
+};
+
+__device__ __forceinline__ u32 base_at(const u8 *row, int i) { return (row[i >> 2] >> (6 - 2 * (i & 3))) & 3u; }
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(TOK_THREADS) void tokenize_k(TokArgs a) {
+  extern __shared__ uint4 lds_dyn[];
+  uint4 *l_next = lds_dyn;
+  u32 *l_out = reinterpret_cast<u32 *>(lds_dyn + a.lds_states);
+  if (USE_LDS) {
+    for (u32 i = threadIdx.x; i < a.lds_states; i += TOK_THREADS) {
+      l_next[i] = a.next[i];
+      l_out[i] = a.outinfo[i];
+    }
+    __syncthreads();
+  }
+  const u64 r = (u64)blockIdx.x * TOK_THREADS + threadIdx.x;
+  if (r >= a.nrec) return;
+  const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
+  u32 state = 0, best_lv = 0, best_b = a.root_bucket, best_pos = 0, hits = 0, tie = 0;
+  const int nw = (a.L + 15) >> 4;
+  for (int w = 0; w < nw; w++) {
+    const u32 word = row[w];  // byte j of the row = bases 4j..4j+3, first base in bits 7-6
+    const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
+    for (int k = 0; k < cnt; k++) {
+      const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
+      uint4 nx;
+      if (USE_LDS && state < a.lds_states) nx = l_next[state]; else nx = a.next[state];
+      state = c == 0 ? nx.x : (c == 1 ? nx.y : (c == 2 ? nx.z : nx.w));
+      u32 info;
+      if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state];
+      if (info != kNoOutD) {
+        const u32 lv = info >> kLevelShiftD, b = info & kBucketMaskD;
+        if (lv > best_lv) {
+          best_lv = lv; best_b = b; best_pos = 16 * w + k; hits = 1; tie = 0;
+        } else if (lv == best_lv) {
+          hits++;
+          if (b != best_b) tie = 1;
+        }
+      }
+    }
+  }
+  a.tok_bucket[r] = best_b;
+  a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
+}
+
+// second walk, tie reads only: the distinct cores of maximal length in order of first appearance
+struct TieArgs {
+  const uint4 *next;
+  const u32 *outinfo;
+  const u8 *packed;
+  int L, stride;
+  u32 ntie;
+  const u32 *tie_read;   // tie index -> read index
+  const u32 *tie_off;    // tie index -> first slot in cand_* (capacity = hits at max level)
+  const u32 *bucket_level;
+  const u32 *tok_bucket;
+  u32 *cand_bucket, *cand_pos;
+  u32 *tie_ncand;
+};
+
+__global__ __launch_bounds__(256) void tie_candidates_k(TieArgs a) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.ntie) return;
+  const u32 r = a.tie_read[t];
+  const u32 off = a.tie_off[t];
+  const u32 lvmax = a.bucket_level[a.tok_bucket[r]];
+  const u8 *row = a.packed + (u64)r * a.stride;
+  u32 state = 0, k = 0;
+  for (int i = 0; i < a.L; i++) {
+    const uint4 nx = a.next[state];
+    const u32 c = base_at(row, i);
+    state = c == 0 ? nx.x : (c == 1 ? nx.y : (c == 2 ? nx.z : nx.w));
+    const u32 info = a.outinfo[state];
+    if (info != kNoOutD && (info >> kLevelShiftD) == lvmax) {
+      const u32 b = info & kBucketMaskD;
+      bool seen = false;
+      for (u32 j = 0; j < k; j++) seen |= (a.cand_bucket[off + j] == b);
+      if (!seen) {
+        a.cand_bucket[off + k] = b;
+        a.cand_pos[off + k] = (u32)i;
+        k++;
+      }
+    }
+  }
+  a.tie_ncand[t] = k;
+}
+
+// events: one per fixed read (its bucket) and one per (tie read, candidate).  ev_off[r] = first
+// event of read r.  Events are created in read order, so a stable sort by bucket leaves every
+// bucket's events in input order.
+struct EventArgs {
+  u64 nrec;
+  const u32 *tok_bucket, *tok_pos;
+  const u32 *tie_index;  // read -> tie index (valid when tie bit set)
+  const u32 *tie_off, *tie_ncand, *cand_bucket;
+  const u32 *ev_off;
+  u32 *ev_bucket;
+  u8 *ev_init;           // initial "chosen" flag: fixed reads 1, first candidate 1, others 0
+};
+__global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.nrec) return;
+  const u32 e = a.ev_off[r];
+  if (a.tok_pos[r] >> 31) {
+    const u32 t = a.tie_index[r], off = a.tie_off[t], k = a.tie_ncand[t];
+    for (u32 j = 0; j < k; j++) {
+      a.ev_bucket[e + j] = a.cand_bucket[off + j];
+      a.ev_init[e + j] = j == 0;
+    }
+  } else {
+    a.ev_bucket[e] = a.tok_bucket[r];
+    a.ev_init[e] = 1;
+  }
+}
+
+struct EvCount {  // events per read
+  const u32 *tok_pos, *tie_index, *tie_ncand;
+  __device__ u32 operator()(u64 r) const { return (tok_pos[r] >> 31) ? tie_ncand[tie_index[r]] : 1u; }
+};
+struct TieFlag {
+  const u32 *tok_pos;
+  __device__ u32 operator()(u64 r) const { return tok_pos[r] >> 31; }
+};
+struct TieHits {  // candidate capacity of a tie read
+  const u32 *tok_pos;
+  const u32 *tie_read;
+  __device__ u32 operator()(u64 t) const { return (tok_pos[tie_read[t]] >> 16) & 0x7FFFu; }
+};
+struct TieCompact {  // scatter of the tie-flag scan: read -> tie index and back
+  const u32 *tok_pos;
+  u32 *tie_index, *tie_read;
+  __device__ void operator()(u64 r, u32 idx) const {
+    tie_index[r] = idx;
+    if (tok_pos[r] >> 31) tie_read[idx] = (u32)r;
+  }
+};
+
+struct DigitOfArray {  // digit functor for radix_pass: byte `shift/8` of key[payload]
+  const u32 *key;
+  int shift;
+  __device__ u32 operator()(u32 v) const { return (key[v] >> shift) & 255u; }
+};
+
+// after the sort: where did each event land, and the initial chosen flags in sorted order
+__global__ __launch_bounds__(256) void events_place_k(u32 nev, const u32 *sorted, const u8 *ev_init, u32 *ev_place,
+                                                     u8 *chosen) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nev) return;
+  const u32 e = sorted[i];
+  ev_place[e] = i;
+  chosen[i] = ev_init[e];
+}
+
+// segment starts of the sorted event array: seg[b] = first position of bucket b (seg[nb] = nev)
+__global__ __launch_bounds__(256) void events_segments_k(u32 nev, const u32 *sorted, const u32 *ev_bucket, u32 nb,
+                                                        u32 *seg) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nev) return;
+  const u32 cur = i < nev ? ev_bucket[sorted[i]] : nb;
+  const u32 prev = i ? ev_bucket[sorted[i - 1]] : 0xFFFFFFFFu;
+  if (i == 0) {
+    for (u32 b = 0; b <= cur && b <= nb; b++) seg[b] = 0;
+  } else if (cur != prev) {
+    for (u32 b = prev + 1; b <= cur && b <= nb; b++) seg[b] = i;
+  }
+}
+
+struct JacobiArgs {
+  u32 ntie;
+  const u32 *tie_read, *tie_off, *tie_ncand, *cand_bucket;
+  const u32 *ev_off, *ev_place;
+  const u32 *G;         // exclusive prefix of `chosen` over the sorted events (G[nev] = total)
+  const u32 *seg;
+  const u64 *prior;     // reads already in each bucket before this shard, or null
+  u32 *choice;          // tie index -> chosen candidate ordinal
+  u8 *chosen;
+  u32 *changed;         // [0] any change, [1] lowest tie index that changed
+};
+__global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.ntie) return;
+  const u32 off = a.tie_off[t], k = a.tie_ncand[t], e0 = a.ev_off[a.tie_read[t]];
+  u32 best = 0;
+  u64 bestc = 0;
+  for (u32 j = 0; j < k; j++) {
+    const u32 b = a.cand_bucket[off + j];
+    const u32 i = a.ev_place[e0 + j];
+    const u64 c = (a.prior ? a.prior[b] : 0ull) + (u64)(a.G[i] - a.G[a.seg[b]]);
+    if (j == 0 || c > bestc) {  // strict: an earlier candidate keeps the bucket on equal counts
+      best = j;
+      bestc = c;
+    }
+  }
+  const u32 old = a.choice[t];
+  if (best != old) {
+    a.chosen[a.ev_place[e0 + old]] = 0;
+    a.chosen[a.ev_place[e0 + best]] = 1;
+    a.choice[t] = best;
+    a.changed[0] = 1;
+    atomicMin(&a.changed[1], t);
+  }
+}
+
+// final (bucket, end) per read + API view (pattern index in file order, end)
+struct FinalizeArgs {
+  u64 nrec;
+  const u32 *tok_bucket, *tok_pos, *tie_index, *tie_off, *choice, *cand_bucket, *cand_pos;
+  const int32_t *bucket_pattern;
+  u32 root_bucket;
+  u32 *bucket;     // final bucket id per read
+  u16 *end;        // end marker: index of the core's last base + 1, 0 = no core (compress.cpp:682,685)
+  int32_t *tokens; // 2 per read: pattern (or -1), end
+};
+__global__ __launch_bounds__(256) void finalize_k(FinalizeArgs a) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.nrec) return;
+  u32 b = a.tok_bucket[r], pos = a.tok_pos[r] & 0xFFFFu;
+  if (a.tok_pos[r] >> 31) {
+    const u32 t = a.tie_index[r], j = a.choice[t];
+    b = a.cand_bucket[a.tie_off[t] + j];
+    pos = a.cand_pos[a.tie_off[t] + j];
+  }
+  const u32 e = b == a.root_bucket ? 0u : pos + 1;
+  a.bucket[r] = b;
+  a.end[r] = (u16)e;
+  a.tokens[2 * r] = b == a.root_bucket ? -1 : a.bucket_pattern[b];
+  a.tokens[2 * r + 1] = (int32_t)e;
+}
+
+// reads per bucket from the converged prefix sums
+__global__ __launch_bounds__(256) void bucket_counts_k(u32 nb1, const u32 *G, const u32 *seg, u64 *counts) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb1) return;
+  counts[b] = (u64)(G[seg[b + 1]] - G[seg[b]]);
+}
+
+}  // namespace scalce

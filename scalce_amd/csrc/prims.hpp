@@ -1,0 +1,214 @@
+// prims.hpp -- device primitives shared by the stage kernels: wave/block scans, a generic
+// reduce-then-scan exclusive prefix sum, and one stable 8-bit LSD radix pass built on
+// wavefront ballots (64-wide) with per-wave digit counters in LDS.
+// gfx950 only: wave size is hard-coded to 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace scalce {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T t = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += t;
+  }
+  return v;
+}
+
+// Exclusive prefix over a block of NW waves.  smem must hold NW entries.  Ends with a barrier,
+// so smem may be reused right after.
+template <typename T, int NW>
+__device__ __forceinline__ T block_exclusive_sum(T v, T *total, T *smem) {
+  const int w = wave_id();
+  T inc = wave_inclusive_sum(v);
+  if (lane_id() == 63) smem[w] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) {
+    T s = smem[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan: out(i) = sum_{j<i} f(j).  Three launches: per-tile sums, spine, downsweep.
+// Each thread owns SCAN_ITEMS consecutive elements (one 64-byte run for u32 input).
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+template <typename T, typename F>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_k(F f, u64 n, T *tile_sums) {
+  __shared__ T sm[4];
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++)
+    if (base + i < n) s += f(base + i);
+  T tot;
+  block_exclusive_sum<T, 4>(s, &tot, sm);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void scan_spine_k(T *sums, u32 nb, T *total_out) {
+  __shared__ T sm[16];
+  T carry = 0;
+  for (u32 base = 0; base < nb; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    T v = i < nb ? sums[i] : T(0);
+    T tot;
+    T ex = block_exclusive_sum<T, 16>(v, &tot, sm);
+    if (i < nb) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+template <typename T, typename F, typename O>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_down_k(F f, u64 n, const T *tile_offs, O out) {
+  __shared__ T sm[4];
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  T v[SCAN_ITEMS];
+  T s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    v[i] = (base + i < n) ? f(base + i) : T(0);
+    s += v[i];
+  }
+  T tot;
+  T run = tile_offs[blockIdx.x] + block_exclusive_sum<T, 4>(s, &tot, sm);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    if (base + i < n) out(base + i, run);
+    run += v[i];
+  }
+}
+
+// Host driver.  tile_ws must hold ceil(n / SCAN_TILE) elements of T.  total_out (device) may be
+// null.  n == 0 writes *total_out = 0 through the spine kernel.
+template <typename T, typename F, typename O>
+inline void exclusive_scan(F f, u64 n, O out, T *tile_ws, T *total_out, hipStream_t st) {
+  const u32 nb = (u32)((n + SCAN_TILE - 1) / SCAN_TILE);
+  if (nb) hipLaunchKernelGGL((scan_reduce_k<T, F>), dim3(nb), dim3(SCAN_THREADS), 0, st, f, n, tile_ws);
+  hipLaunchKernelGGL((scan_spine_k<T>), dim3(1), dim3(1024), 0, st, tile_ws, nb, total_out);
+  if (nb) hipLaunchKernelGGL((scan_down_k<T, F, O>), dim3(nb), dim3(SCAN_THREADS), 0, st, f, n, tile_ws, out);
+}
+
+template <typename S, typename T>
+struct LoadAs {
+  const S *p;
+  __device__ T operator()(u64 i) const { return (T)p[i]; }
+};
+template <typename T>
+struct StoreTo {
+  T *p;
+  __device__ void operator()(u64 i, T v) const { p[i] = v; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// one stable LSD radix pass over an array of u32 payloads; the 8-bit digit of a payload is
+// given by a functor (it may gather from anywhere).  hist layout: [256][ntiles] so that a flat
+// exclusive scan yields the global base of (digit, tile).
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+
+template <typename D>
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_k(const u32 *in, u32 n, D digit, u32 *hist, u32 ntiles) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 base = blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; i++) {
+    const u32 idx = base + i * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[digit(in ? in[idx] : idx)], 1u);
+  }
+  __syncthreads();
+  hist[(u64)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename D>
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_k(const u32 *in, u32 *out, u32 n, D digit,
+                                                             const u32 *offs, u32 ntiles) {
+  __shared__ u32 wh[4][256];
+  for (int i = threadIdx.x; i < 4 * 256; i += RS_THREADS) (&wh[0][0])[i] = 0;
+  __syncthreads();
+  const int w = wave_id(), lane = lane_id();
+  const u64 lt = (1ull << lane) - 1;
+  const u32 base = blockIdx.x * RS_TILE + w * (64 * RS_ITEMS);
+  u32 val[RS_ITEMS], pos[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const u32 idx = base + r * 64 + lane;
+    const bool valid = idx < n;
+    const u32 v = valid ? (in ? in[idx] : idx) : 0u;
+    const u32 d = valid ? (u32)digit(v) : 0u;
+    u64 peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1;
+      const u64 bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const u32 rank = __popcll(peers & lt);
+    u32 pre = 0;
+    if (valid && rank == 0) {  // lowest lane of each digit group bumps this wave's counter
+      pre = wh[w][d];
+      wh[w][d] = pre + (u32)__popcll(peers);
+    }
+    const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+    pre = __shfl(pre, leader, 64);
+    val[r] = v;
+    pos[r] = valid ? ((d << 16) | (pre + rank)) : 0xFFFFFFFFu;  // tile <= 2048 items: rank fits 16 bits
+  }
+  __syncthreads();
+  {
+    const u32 d = threadIdx.x;
+    const u32 c0 = wh[0][d], c1 = wh[1][d], c2 = wh[2][d];
+    const u32 g = offs[(u64)d * ntiles + blockIdx.x];
+    wh[0][d] = g;
+    wh[1][d] = g + c0;
+    wh[2][d] = g + c0 + c1;
+    wh[3][d] = g + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++)
+    if (pos[r] != 0xFFFFFFFFu) out[wh[w][pos[r] >> 16] + (pos[r] & 0xFFFFu)] = val[r];
+}
+
+// in == nullptr means the identity permutation 0..n-1.  hist_ws: 256*ntiles u32; tile_ws: scan
+// workspace for 256*ntiles elements.
+template <typename D>
+inline void radix_pass(const u32 *in, u32 *out, u32 n, D digit, u32 *hist_ws, u32 *tile_ws, hipStream_t st) {
+  if (!n) return;
+  const u32 ntiles = (n + RS_TILE - 1) / RS_TILE;
+  hipLaunchKernelGGL((radix_hist_k<D>), dim3(ntiles), dim3(RS_THREADS), 0, st, in, n, digit, hist_ws, ntiles);
+  exclusive_scan<u32>(LoadAs<u32, u32>{hist_ws}, (u64)256 * ntiles, StoreTo<u32>{hist_ws}, tile_ws, (u32 *)nullptr, st);
+  hipLaunchKernelGGL((radix_scatter_k<D>), dim3(ntiles), dim3(RS_THREADS), 0, st, in, out, n, digit, hist_ws, ntiles);
+}
+
+inline u64 scan_ws_elems(u64 n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
+inline u64 radix_hist_elems(u64 n) { return 256 * ((n + RS_TILE - 1) / RS_TILE) + 256; }
+
+}  // namespace scalce

@@ -1,0 +1,784 @@
+// scalce_hip.hip -- C ABI (include/scalce_hip.h) over the gfx950 kernels.
+// Host side of the hot path: owns the device buffers of a shard, sequences the kernels on the
+// caller's stream and reads back the handful of counters that size the next launches.
+// There is NO CPU fallback: every stage runs on the device or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scalce_hip.h"
+#include "automaton.hpp"
+#include "kernels_ac.hpp"
+
+using namespace scalce;
+
+struct scalce_ctx {
+  int device = 0;
+  std::string err;
+  Automaton A;
+  bool have_patterns = false;
+  uint4 *d_next = nullptr;
+  u32 *d_outinfo = nullptr;
+  int32_t *d_bucket_pattern = nullptr;
+  u32 *d_bucket_level = nullptr;
+  int tok_lds_states = 0;
+};
+
+static void set_err(scalce_ctx *c, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  c->err = buf;
+}
+
+#define HIP_TRY(ctx, expr)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      set_err(ctx, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return SCALCE_ERR_HIP;                                                             \
+    }                                                                                    \
+  } while (0)
+
+extern "C" int scalce_ctx_create(int device, scalce_ctx **out) {
+  if (!out) return SCALCE_ERR_ARG;
+  scalce_ctx *c = new scalce_ctx();
+  c->device = device;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    // keep the context so the caller can read the message
+    set_err(c, "no HIP device %d (found %d): this library has no CPU path", device, n);
+    *out = c;
+    return SCALCE_ERR_HIP;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    set_err(c, "hipSetDevice(%d) failed", device);
+    *out = c;
+    return SCALCE_ERR_HIP;
+  }
+  *out = c;
+  return SCALCE_OK;
+}
+
+static void free_tables(scalce_ctx *c) {
+  if (c->d_next) hipFree(c->d_next);
+  if (c->d_outinfo) hipFree(c->d_outinfo);
+  if (c->d_bucket_pattern) hipFree(c->d_bucket_pattern);
+  if (c->d_bucket_level) hipFree(c->d_bucket_level);
+  c->d_next = nullptr; c->d_outinfo = nullptr; c->d_bucket_pattern = nullptr; c->d_bucket_level = nullptr;
+}
+
+extern "C" void scalce_ctx_destroy(scalce_ctx *c) {
+  if (!c) return;
+  free_tables(c);
+  delete c;
+}
+extern "C" const char *scalce_last_error(const scalce_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+static int upload_tables(scalce_ctx *c) {
+  free_tables(c);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const Automaton &A = c->A;
+  HIP_TRY(c, hipMalloc(&c->d_next, sizeof(uint4) * (size_t)A.n_states));
+  HIP_TRY(c, hipMalloc(&c->d_outinfo, sizeof(u32) * (size_t)A.n_states));
+  HIP_TRY(c, hipMalloc(&c->d_bucket_pattern, sizeof(int32_t) * A.bucket_pattern.size()));
+  HIP_TRY(c, hipMalloc(&c->d_bucket_level, sizeof(u32) * A.bucket_level.size()));
+  HIP_TRY(c, hipMemcpy(c->d_next, A.next.data(), sizeof(u32) * A.next.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_outinfo, A.outinfo.data(), sizeof(u32) * A.outinfo.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_bucket_pattern, A.bucket_pattern.data(), sizeof(int32_t) * A.bucket_pattern.size(),
+                       hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_bucket_level, A.bucket_level.data(), sizeof(u32) * A.bucket_level.size(),
+                       hipMemcpyHostToDevice));
+  // stage as many leading (shallow) states as fit in 60 KiB of LDS: 2 workgroups per CU stay resident
+  int cap = (60 * 1024) / 20;
+  c->tok_lds_states = A.n_states < cap ? A.n_states : cap;
+  c->have_patterns = true;
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_patterns_load_bin(scalce_ctx *c, const void *blob, size_t n) {
+  if (!c || !blob) return SCALCE_ERR_ARG;
+  if (!c->A.load_bin(blob, n)) { c->err = c->A.error; return SCALCE_ERR_FORMAT; }
+  return upload_tables(c);
+}
+extern "C" int scalce_patterns_load_text(scalce_ctx *c, const char *text, size_t n) {
+  if (!c || !text) return SCALCE_ERR_ARG;
+  if (!c->A.load_text(text, n)) { c->err = c->A.error; return SCALCE_ERR_FORMAT; }
+  return upload_tables(c);
+}
+extern "C" int scalce_patterns_count(const scalce_ctx *c) { return c ? (int)c->A.patterns.size() : 0; }
+extern "C" int scalce_patterns_states(const scalce_ctx *c) { return c ? c->A.n_states : 0; }
+extern "C" int scalce_patterns_buckets(const scalce_ctx *c) { return c ? c->A.n_buckets : 0; }
+extern "C" int scalce_pattern_length(const scalce_ctx *c, int p) {
+  return (c && p >= 0 && p < (int)c->A.patterns.size()) ? (int)c->A.patterns[p].size() : -1;
+}
+extern "C" const char *scalce_pattern_string(const scalce_ctx *c, int p) {
+  return (c && p >= 0 && p < (int)c->A.patterns.size()) ? c->A.patterns[p].c_str() : nullptr;
+}
+
+extern "C" void scalce_params_default(scalce_params *p) {
+  std::memset(p, 0, sizeof *p);
+  p->use_names = 1;
+  for (int m = 0; m < 2; m++) {
+    p->qmap[m].offset = 33;
+    for (int i = 0; i < 128; i++) p->qmap[m].values[i] = i;
+    p->qprev[m][0] = p->qprev[m][1] = 500;
+  }
+  p->bucket_set_size = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct DBuf {  // grow-only device buffer
+  void *p = nullptr;
+  size_t cap = 0;
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+enum { ST_INGEST = 0, ST_QUALITY, ST_TOKENIZE, ST_ORDER, ST_EMIT, ST_ENTROPY, ST_COUNT };
+
+struct scalce_batch {
+  scalce_ctx *ctx = nullptr;
+  scalce_params p;
+  u64 max_reads = 0, max_text = 0;
+  int nm = 1;
+  int L[2] = {0, 0}, stride[2] = {0, 0}, szr[2] = {0, 0}, sz_meta = 1;
+  u64 N = 0;                 // records in the current shard
+  const u8 *d_text[2] = {nullptr, nullptr};
+  u64 text_bytes[2] = {0, 0};
+  bool ingested[2] = {false, false};
+  // device state
+  DevErr *d_err = nullptr;
+  u32 *d_small = nullptr;    // scratch counters: [0..15]
+  u64 *d_small64 = nullptr;
+  u8 *d_qlut[2] = {nullptr, nullptr};
+  DBuf line_end[2], packed[2], q[2], namelen, freq4[2], table[2], qs[2];
+  DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
+  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg;
+  DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
+  DBuf perm_a, perm_b, hist, scan_ws, S;
+  DBuf out_reads[2], out_names, name_off, ac_tab, ac_cum, ac_blocks, ac_sizes, ac_off, out_qual[2];
+  u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
+  // host-side results
+  u64 out_reads_bytes[2] = {0, 0}, out_names_bytes = 0, out_qual_bytes[2] = {0, 0};
+  u32 ntie = 0, nev = 0, ncand_cap = 0, jacobi_iters = 0, nchunks = 1;
+  // stage timing
+  bool timing = false;
+  float stage_ms[ST_COUNT] = {0};
+  int stage_launches[ST_COUNT] = {0};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
+  if (bytes <= d.cap) return SCALCE_OK;
+  if (d.p) hipFree(d.p);
+  d.p = nullptr; d.cap = 0;
+  bytes = (bytes + 255) & ~size_t(255);
+  hipError_t e = hipMalloc(&d.p, bytes);
+  if (e != hipSuccess) {
+    set_err(b->ctx, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return SCALCE_ERR_HIP;
+  }
+  d.cap = bytes;
+  return SCALCE_OK;
+}
+#define ENSURE(b, buf, bytes) do { int rc_ = ensure(b, buf, bytes); if (rc_) return rc_; } while (0)
+
+static void free_all(scalce_batch *b) {
+  DBuf *all[] = {&b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen,
+                 &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
+                 &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
+                 &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
+                 &b->chosen, &b->G, &b->seg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
+                 &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S,
+                 &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab, &b->ac_cum,
+                 &b->ac_blocks, &b->ac_sizes, &b->ac_off, &b->out_qual[0], &b->out_qual[1]};
+  for (DBuf *d : all)
+    if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
+  if (b->d_err) hipFree(b->d_err);
+  if (b->d_small) hipFree(b->d_small);
+  if (b->d_small64) hipFree(b->d_small64);
+  for (int m = 0; m < 2; m++) if (b->d_qlut[m]) hipFree(b->d_qlut[m]);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+}
+
+static inline int sz_read(int l) { return (l + 3) / 4; }
+
+extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
+                                   scalce_batch **out) {
+  if (!c || !p || !out) return SCALCE_ERR_ARG;
+  if (!c->have_patterns) { set_err(c, "load a core table first"); return SCALCE_ERR_ARG; }
+  if (p->read_len[0] <= 0 || p->read_len[0] > 2498 || (p->paired && (p->read_len[1] <= 0 || p->read_len[1] > 2498))) {
+    set_err(c, "read_len must be set (1..2498: the reference reads lines into MAXLINE = 2500 bytes, const.h:87)");
+    return SCALCE_ERR_ARG;
+  }
+  if (max_reads >= (1ull << 32) - 64) { set_err(c, "a shard holds fewer than 2^32 reads"); return SCALCE_ERR_CAPACITY; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  scalce_batch *b = new scalce_batch();
+  b->ctx = c;
+  b->p = *p;
+  b->max_reads = max_reads;
+  b->max_text = max_text;
+  b->nm = p->paired ? 2 : 1;
+  for (int m = 0; m < b->nm; m++) {
+    b->L[m] = p->read_len[m];
+    b->szr[m] = sz_read(b->L[m]);
+    b->stride[m] = ((b->szr[m] + 1 + 15) / 16) * 16;  // one spare zero byte for 16-bit digit windows
+  }
+  b->sz_meta = b->L[0] > 255 ? 2 : 1;  // reads.cpp:106-108
+  *out = b;
+  HIP_TRY(c, hipMalloc(&b->d_err, sizeof(DevErr)));
+  HIP_TRY(c, hipMemset(b->d_err, 0, sizeof(DevErr)));
+  HIP_TRY(c, hipMalloc(&b->d_small, 64 * sizeof(u32)));
+  HIP_TRY(c, hipMalloc(&b->d_small64, 64 * sizeof(u64)));
+  HIP_TRY(c, hipEventCreate(&b->ev0));
+  HIP_TRY(c, hipEventCreate(&b->ev1));
+  for (int m = 0; m < b->nm; m++) {
+    u8 lut[128];
+    for (int i = 0; i < 128; i++) lut[i] = (u8)((p->qmap[m].values[i] - p->qmap[m].offset) & 255);
+    HIP_TRY(c, hipMalloc(&b->d_qlut[m], 128));
+    HIP_TRY(c, hipMemcpy(b->d_qlut[m], lut, 128, hipMemcpyHostToDevice));
+    ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (max_reads + 1));
+    ENSURE(b, b->packed[m], (size_t)b->stride[m] * max_reads + 64);
+    ENSURE(b, b->q[m], (size_t)b->L[m] * max_reads + 64);
+    ENSURE(b, b->qs[m], (size_t)b->L[m] * max_reads + 64);
+    ENSURE(b, b->freq4[m], sizeof(u64) * 512000);
+    ENSURE(b, b->table[m], sizeof(u32) * 512000);
+  }
+  ENSURE(b, b->namelen, max_reads + 64);
+  ENSURE(b, b->scan_ws, sizeof(u64) * (max_text / IDX_TILE + scan_ws_elems(4 * max_reads + 1024) + 4096));
+  return SCALCE_OK;
+}
+
+extern "C" void scalce_batch_destroy(scalce_batch *b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  free_all(b);
+  delete b;
+}
+
+struct StageTimer {
+  scalce_batch *b;
+  int st;
+  hipStream_t s;
+  StageTimer(scalce_batch *b_, int st_, hipStream_t s_) : b(b_), st(st_), s(s_) {
+    if (b->timing) hipEventRecord(b->ev0, s);
+  }
+  ~StageTimer() {
+    if (b->timing) {
+      hipEventRecord(b->ev1, s);
+      hipEventSynchronize(b->ev1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, b->ev0, b->ev1);
+      b->stage_ms[st] += ms;
+      b->stage_launches[st]++;
+    }
+  }
+};
+
+static int read_u32(scalce_batch *b, const u32 *d, u32 *h, int n, hipStream_t s) {
+  HIP_TRY(b->ctx, hipMemcpyAsync(h, d, sizeof(u32) * n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(b->ctx, hipStreamSynchronize(s));
+  return SCALCE_OK;
+}
+static int read_u64(scalce_batch *b, const u64 *d, u64 *h, int n, hipStream_t s) {
+  HIP_TRY(b->ctx, hipMemcpyAsync(h, d, sizeof(u64) * n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(b->ctx, hipStreamSynchronize(s));
+  return SCALCE_OK;
+}
+
+static int check_device_error(scalce_batch *b, hipStream_t s) {
+  DevErr e;
+  HIP_TRY(b->ctx, hipMemcpyAsync(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost, s));
+  HIP_TRY(b->ctx, hipStreamSynchronize(s));
+  if (e.code == E_NONE) return SCALCE_OK;
+  static const char *names[] = {"", "line count is not a multiple of 4 or the text does not end in a newline",
+                                "read or quality line length differs from read_length (compress.cpp:628-634)",
+                                "read name longer than 255 bytes or empty name line",
+                                "quality symbol >= 80 after mapping (arithmetic.h:47)",
+                                "arithmetic-coded block larger than the reference's 10 MiB buffer (arithmetic.cpp:101)",
+                                "mates have different record counts", "internal"};
+  set_err(b->ctx, "(ERROR) %s [record/block %llu, aux %u]", names[e.code < 8 ? e.code : 7],
+          (unsigned long long)e.where, e.aux);
+  hipMemsetAsync(b->d_err, 0, sizeof(DevErr), s);
+  return SCALCE_ERR_FORMAT;
+}
+
+#define LAUNCH(kernel, grid, block, shmem, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
+static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+
+// ---- stage 0: ingest ------------------------------------------------------------------------------
+extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_text, uint64_t nbytes, void *stream) {
+  if (!b || mate < 0 || mate >= b->nm || !d_text) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (((uintptr_t)d_text & 15) != 0) { set_err(c, "FASTQ text must be 16-byte aligned"); return SCALCE_ERR_ARG; }
+  if (nbytes > b->max_text) { set_err(c, "text larger than the batch capacity"); return SCALCE_ERR_CAPACITY; }
+  StageTimer tm(b, ST_INGEST, s);
+  b->d_text[mate] = d_text;
+  b->text_bytes[mate] = nbytes;
+  const u32 ntiles = cdiv(nbytes, IDX_TILE);
+  ENSURE(b, b->scan_ws, (ntiles + 8 + scan_ws_elems(ntiles) + 64) * sizeof(u64));
+  u64 *tile = b->scan_ws.as<u64>();                 // [ntiles] counts -> bases
+  u64 *ws = tile + ntiles + 8;                      // scan workspace behind it
+  u64 nlines = 0;
+  if (ntiles) {
+    LAUNCH(index_count_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, tile);
+    exclusive_scan<u64>(LoadAs<u64, u64>{tile}, ntiles, StoreTo<u64>{tile}, ws, b->d_small64, s);
+    int rc = read_u64(b, b->d_small64, &nlines, 1, s);
+    if (rc) return rc;
+  }
+  u8 last = '\n';
+  if (nbytes) HIP_TRY(c, hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, s));
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if ((nlines & 3) || last != '\n') {
+    set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)nlines);
+    return SCALCE_ERR_FORMAT;
+  }
+  const u64 nrec = nlines / 4;
+  if (nrec > b->max_reads) { set_err(c, "%llu records exceed the batch capacity", (unsigned long long)nrec); return SCALCE_ERR_CAPACITY; }
+  if (mate == 0) b->N = nrec;
+  else if (nrec != b->N) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
+  if (ntiles) LAUNCH(index_write_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, tile, b->line_end[mate].as<u64>(), nlines);
+  if (nrec) {
+    UnpackArgs a;
+    a.text = d_text; a.nbytes = nbytes; a.line_end = b->line_end[mate].as<u64>(); a.nrec = nrec;
+    a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
+    a.packed = b->packed[mate].as<u8>(); a.q = b->q[mate].as<u8>(); a.namelen = b->namelen.as<u8>();
+    a.qlut = b->d_qlut[mate]; a.err = b->d_err;
+    LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
+  }
+  b->ingested[mate] = true;
+  return SCALCE_OK;
+}
+
+// ---- stage 1: quality statistics -------------------------------------------------------------------
+extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_QUALITY, s);
+  for (int m = 0; m < b->nm; m++) {
+    if (!b->ingested[m]) { set_err(c, "ingest mate %d first", m + 1); return SCALCE_ERR_ARG; }
+    HIP_TRY(c, hipMemsetAsync(b->freq4[m].p, 0, sizeof(u64) * 512000, s));
+    if (b->p.no_ac) continue;  // statistics are skipped under -A (qualities.cpp:185)
+    const u64 n = b->N * (u64)b->L[m];
+    if (n) LAUNCH(trigram_k, cdiv(n, (u64)256 * TRI_PER_THREAD), 256, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0],
+                  b->p.qprev[m][1], b->freq4[m].as<u64>());
+  }
+  return SCALCE_OK;
+}
+
+// ---- stage 2: tokenize ------------------------------------------------------------------------------
+extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, void *stream) {
+  if (!b || !b->ingested[0]) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_TOKENIZE, s);
+  const u64 N = b->N;
+  const u32 nb1 = (u32)c->A.n_buckets + 1;  // buckets incl. root
+  ENSURE(b, b->tok_bucket, sizeof(u32) * (N + 1));
+  ENSURE(b, b->tok_pos, sizeof(u32) * (N + 1));
+  ENSURE(b, b->tie_index, sizeof(u32) * (N + 1));
+  ENSURE(b, b->ev_off, sizeof(u32) * (N + 1));
+  ENSURE(b, b->bucket, sizeof(u32) * (N + 1));
+  ENSURE(b, b->endv, sizeof(u16) * (N + 1));
+  ENSURE(b, b->tokens, sizeof(int32_t) * 2 * (N + 1));
+  ENSURE(b, b->counts, sizeof(u64) * (nb1 + 1));
+  ENSURE(b, b->seg, sizeof(u32) * (nb1 + 2));
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(2 * N + 1024) + 1024));
+  u32 *ws32 = b->scan_ws.as<u32>();
+  if (!N) {
+    HIP_TRY(c, hipMemsetAsync(b->counts.p, 0, sizeof(u64) * (nb1 + 1), s));
+    b->ntie = b->nev = 0;
+    return SCALCE_OK;
+  }
+  // pass A: every read
+  {
+    TokArgs a;
+    a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
+    a.packed = b->packed[0].as<u8>(); a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
+    a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
+    const size_t sh = (size_t)a.lds_states * 20;
+    if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
+    else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+  }
+  // tie reads: compact, then size the candidate lists by their hit counts
+  ENSURE(b, b->tie_read, sizeof(u32) * (N + 1));
+  exclusive_scan<u32>(TieFlag{b->tok_pos.as<u32>()}, N,
+                      TieCompact{b->tok_pos.as<u32>(), b->tie_index.as<u32>(), b->tie_read.as<u32>()}, ws32, b->d_small, s);
+  u32 ntie = 0;
+  { int rc = read_u32(b, b->d_small, &ntie, 1, s); if (rc) return rc; }
+  b->ntie = ntie;
+  ENSURE(b, b->tie_off, sizeof(u32) * (ntie + 2));
+  ENSURE(b, b->tie_ncand, sizeof(u32) * (ntie + 2));
+  ENSURE(b, b->choice, sizeof(u32) * (ntie + 2));
+  u32 ncap = 0;
+  if (ntie) {
+    exclusive_scan<u32>(TieHits{b->tok_pos.as<u32>(), b->tie_read.as<u32>()}, ntie, StoreTo<u32>{b->tie_off.as<u32>()}, ws32,
+                        b->d_small + 1, s);
+    int rc = read_u32(b, b->d_small + 1, &ncap, 1, s);
+    if (rc) return rc;
+  }
+  b->ncand_cap = ncap;
+  ENSURE(b, b->cand_bucket, sizeof(u32) * (ncap + 2));
+  ENSURE(b, b->cand_pos, sizeof(u32) * (ncap + 2));
+  if (ntie) {
+    TieArgs a;
+    a.next = c->d_next; a.outinfo = c->d_outinfo; a.packed = b->packed[0].as<u8>(); a.L = b->L[0]; a.stride = b->stride[0];
+    a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.bucket_level = c->d_bucket_level;
+    a.tok_bucket = b->tok_bucket.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_pos = b->cand_pos.as<u32>();
+    a.tie_ncand = b->tie_ncand.as<u32>();
+    LAUNCH(tie_candidates_k, cdiv(ntie, 256), 256, 0, s, a);
+    HIP_TRY(c, hipMemsetAsync(b->choice.p, 0, sizeof(u32) * ntie, s));
+  }
+  // events in read order, stable-sorted by bucket
+  exclusive_scan<u32>(EvCount{b->tok_pos.as<u32>(), b->tie_index.as<u32>(), b->tie_ncand.as<u32>()}, N,
+                      StoreTo<u32>{b->ev_off.as<u32>()}, ws32, b->d_small + 2, s);
+  u32 nev = 0;
+  { int rc = read_u32(b, b->d_small + 2, &nev, 1, s); if (rc) return rc; }
+  b->nev = nev;
+  ENSURE(b, b->ev_bucket, sizeof(u32) * (nev + 2));
+  ENSURE(b, b->ev_init, nev + 64);
+  ENSURE(b, b->ev_sorted, sizeof(u32) * (nev + 2));
+  ENSURE(b, b->ev_tmp, sizeof(u32) * (nev + 2));
+  ENSURE(b, b->ev_place, sizeof(u32) * (nev + 2));
+  ENSURE(b, b->chosen, nev + 64);
+  ENSURE(b, b->G, sizeof(u32) * (nev + 2));
+  ENSURE(b, b->hist, sizeof(u32) * radix_hist_elems(nev > N ? nev : N));
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(radix_hist_elems(nev > N ? nev : N)) + scan_ws_elems(nev) + 1024));
+  ws32 = b->scan_ws.as<u32>();
+  {
+    EventArgs a;
+    a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
+    a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
+    a.ev_off = b->ev_off.as<u32>(); a.ev_bucket = b->ev_bucket.as<u32>(); a.ev_init = b->ev_init.as<u8>();
+    LAUNCH(events_fill_k, cdiv(N, 256), 256, 0, s, a);
+  }
+  int bits = 1;
+  while ((1u << bits) < nb1 && bits < 31) bits++;
+  const u32 *src = nullptr;  // identity
+  u32 *dst = b->ev_sorted.as<u32>(), *alt = b->ev_tmp.as<u32>();
+  for (int sh = 0; sh < bits; sh += 8) {
+    radix_pass(src, dst, nev, DigitOfArray{b->ev_bucket.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+    src = dst;
+    u32 *t = dst; dst = alt; alt = t;
+  }
+  const u32 *sorted = src;
+  LAUNCH(events_place_k, cdiv(nev, 256), 256, 0, s, nev, sorted, b->ev_init.as<u8>(), b->ev_place.as<u32>(), b->chosen.as<u8>());
+  LAUNCH(events_segments_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, sorted, b->ev_bucket.as<u32>(), nb1, b->seg.as<u32>());
+  // Jacobi iterations to the fixed point
+  u32 *G = b->G.as<u32>();
+  b->jacobi_iters = 0;
+  for (;;) {
+    exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, ws32, G + nev, s);
+    if (!ntie) break;
+    static const u32 init[2] = {0u, 0xFFFFFFFFu};
+    HIP_TRY(c, hipMemcpyAsync(b->d_small + 4, init, sizeof init, hipMemcpyHostToDevice, s));
+    JacobiArgs a;
+    a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
+    a.cand_bucket = b->cand_bucket.as<u32>(); a.ev_off = b->ev_off.as<u32>(); a.ev_place = b->ev_place.as<u32>(); a.G = G;
+    a.seg = b->seg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
+    a.changed = b->d_small + 4;
+    LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
+    u32 ch[2];
+    int rc = read_u32(b, b->d_small + 4, ch, 2, s);
+    if (rc) return rc;
+    b->jacobi_iters++;
+    if (!ch[0]) break;
+    if (b->jacobi_iters > ntie + 1) { set_err(c, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
+  }
+  {
+    FinalizeArgs a;
+    a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
+    a.tie_off = b->tie_off.as<u32>(); a.choice = b->choice.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
+    a.cand_pos = b->cand_pos.as<u32>(); a.bucket_pattern = c->d_bucket_pattern; a.root_bucket = (u32)c->A.n_buckets;
+    a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>(); a.tokens = b->tokens.as<int32_t>();
+    LAUNCH(finalize_k, cdiv(N, 256), 256, 0, s, a);
+  }
+  LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>());
+  return SCALCE_OK;
+}
+
+// ---- stage 3: order ----------------------------------------------------------------------------------
+extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_ORDER, s);
+  const u64 N = b->N;
+  const u32 nb1 = (u32)c->A.n_buckets + 1;
+  ENSURE(b, b->perm_a, sizeof(u32) * (N + 2));
+  ENSURE(b, b->perm_b, sizeof(u32) * (N + 2));
+  ENSURE(b, b->hist, sizeof(u32) * radix_hist_elems(N));
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(radix_hist_elems(N)) + scan_ws_elems(N + 1) + 1024));
+  b->perm = b->perm_a.as<u32>();
+  b->nchunks = 1;
+  if (!N) return SCALCE_OK;
+  u32 *ws32 = b->scan_ws.as<u32>();
+  // spill chunks under -B
+  if (b->p.bucket_set_size) {
+    ENSURE(b, b->S, sizeof(u64) * (N + 2));
+    ENSURE(b, b->chunk, sizeof(u32) * (N + 2));
+    const u32 max_chunks = 4096;
+    ENSURE(b, b->chunk_start, sizeof(u64) * (max_chunks + 2));
+    RecSize rs{b->bucket.as<u32>(), c->d_bucket_level, b->namelen.as<u8>(), b->L[0], b->L[1], b->p.paired, b->p.use_names, 1};
+    u64 *S = b->S.as<u64>();
+    exclusive_scan<u64>(rs, N, StoreTo<u64>{S}, b->scan_ws.as<u64>(), S + N, s);
+    LAUNCH(chunk_bounds_k, 1, 1, 0, s, S, N, (u64)b->p.bucket_set_size, max_chunks, b->chunk_start.as<u64>(), b->d_small + 8);
+    int rc = read_u32(b, b->d_small + 8, &b->nchunks, 1, s);
+    if (rc) return rc;
+    if (b->nchunks > 1)
+      LAUNCH(chunk_assign_k, cdiv(N, 256), 256, 0, s, N, b->chunk_start.as<u64>(), b->d_small + 8, b->chunk.as<u32>());
+  }
+  const u32 *src = nullptr;
+  u32 *dst = b->perm_a.as<u32>(), *alt = b->perm_b.as<u32>();
+  auto flip = [&]() { src = dst; u32 *t = dst; dst = alt; alt = t; };
+  const int ndig = (b->L[0] + 3) / 4;
+  for (int d = ndig - 1; d >= 0; d--) {
+    radix_pass(src, dst, (u32)N, KeyDigit{b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], d}, b->hist.as<u32>(),
+               ws32, s);
+    flip();
+  }
+  if (b->nchunks > 1)
+    for (int sh = 0; (1u << sh) < b->nchunks; sh += 8) {
+      radix_pass(src, dst, (u32)N, DigitOfArray{b->chunk.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+      flip();
+    }
+  int bits = 1;
+  while ((1u << bits) < nb1 && bits < 31) bits++;
+  for (int sh = 0; sh < bits; sh += 8) {
+    radix_pass(src, dst, (u32)N, DigitOfArray{b->bucket.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+    flip();
+  }
+  b->perm = const_cast<u32 *>(src);
+  return SCALCE_OK;
+}
+
+// ---- stage 4: emit -----------------------------------------------------------------------------------
+extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_EMIT, s);
+  const u64 N = b->N;
+  const u32 nb1 = (u32)c->A.n_buckets + 1;
+  ENSURE(b, b->bucket_first, sizeof(u64) * (nb1 + 2));
+  ENSURE(b, b->bucket_off, sizeof(u64) * (nb1 + 2));
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nb1) + scan_ws_elems(N + 1) + 1024));
+  u64 *ws = b->scan_ws.as<u64>();
+  u64 *counts = b->counts.as<u64>();
+  exclusive_scan<u64>(LoadAs<u64, u64>{counts}, nb1, StoreTo<u64>{b->bucket_first.as<u64>()}, ws, b->d_small64 + 1, s);
+  exclusive_scan<u64>(BucketBytes{counts, c->d_bucket_level, b->L[0], b->sz_meta}, nb1, StoreTo<u64>{b->bucket_off.as<u64>()}, ws,
+                      b->d_small64 + 2, s);
+  if (b->p.use_names) {
+    ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
+    exclusive_scan<u64>(NameLenOut{b->perm, b->namelen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
+  }
+  u64 h[4] = {0, 0, 0, 0};
+  { int rc = read_u64(b, b->d_small64, h, 4, s); if (rc) return rc; }
+  b->out_reads_bytes[0] = h[2];
+  b->out_names_bytes = b->p.use_names ? h[3] : 0;
+  ENSURE(b, b->out_reads[0], h[2] + 64);
+  ENSURE(b, b->out_names, b->out_names_bytes + 64);
+  if (N) {
+    EmitArgs a;
+    a.nrec = N; a.perm = b->perm; a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>(); a.packed = b->packed[0].as<u8>();
+    a.L = b->L[0]; a.stride = b->stride[0]; a.sz_meta = b->sz_meta; a.bucket_level = c->d_bucket_level;
+    a.bucket_pattern = c->d_bucket_pattern; a.bucket_first = b->bucket_first.as<u64>(); a.bucket_off = b->bucket_off.as<u64>();
+    a.counts = counts; a.out = b->out_reads[0].as<u8>();
+    LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
+    if (b->p.use_names)
+      LAUNCH(emit_names_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->line_end[0].as<u64>(), b->d_text[0],
+             b->name_off.as<u64>(), b->out_names.as<u8>());
+    for (int m = 0; m < b->nm; m++) {
+      const u32 w = (u32)b->L[m];
+      const u64 items = ((w & 3) == 0) ? N * (w / 4) : N * w;
+      LAUNCH(gather_rows_k, cdiv(items, 256), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
+    }
+    if (b->nm == 2) {  // mate 2: bare packed reads in the same order (compress.cpp:380-383 with fR = file 4)
+      const u32 w = (u32)b->szr[1];
+      b->out_reads_bytes[1] = N * w;
+      ENSURE(b, b->out_reads[1], N * w + 64);
+      const u64 items2 = ((w & 3) == 0) ? N * (w / 4) : N * w;
+      LAUNCH(gather_rows_k, cdiv(items2, 256), 256, 0, s, N, b->perm, b->packed[1].as<u8>(), (u64)b->stride[1], w,
+             b->out_reads[1].as<u8>());
+    }
+  } else if (b->nm == 2) b->out_reads_bytes[1] = 0;
+  return SCALCE_OK;
+}
+
+// ---- stage 5: entropy ---------------------------------------------------------------------------------
+extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_ENTROPY, s);
+  const u64 N = b->N;
+  for (int m = 0; m < b->nm; m++) {
+    const u64 nsym = N * (u64)b->L[m];
+    if (b->p.no_ac) {  // -A: raw q' bytes (compress.cpp:389-390)
+      b->out_qual_bytes[m] = nsym;
+      continue;
+    }
+    u32 *table = b->table[m].as<u32>();
+    if (d_table_override) {
+      HIP_TRY(c, hipMemcpyAsync(table, d_table_override + (size_t)m * 512000, sizeof(u32) * 512000, hipMemcpyDeviceToDevice, s));
+    } else {
+      const u32 factor = 1 + (u32)(nsym / 0xFFFFFFFFull);  // compress.cpp:297-303
+      LAUNCH(ac_scale_k, cdiv(512000, 256), 256, 0, s, b->freq4[m].as<u64>(), factor, table);
+    }
+    ENSURE(b, b->ac_tab, sizeof(uint4) * 512000);
+    ENSURE(b, b->ac_cum, sizeof(u32) * 6400 * 81);
+    LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab.as<uint4>(), b->ac_cum.as<u32>());
+    const u32 nblk = cdiv(nsym, AC_BLOCK_SYMS);
+    const u64 stride = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
+    ENSURE(b, b->ac_blocks, (size_t)nblk * stride + 64);
+    ENSURE(b, b->ac_sizes, sizeof(u32) * (nblk + 2));
+    ENSURE(b, b->ac_off, sizeof(u64) * (nblk + 2));
+    if (!nblk) { b->out_qual_bytes[m] = 0; continue; }
+    AcEncArgs a;
+    a.sym = b->qs[m].as<u8>(); a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
+    a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
+    LAUNCH(ac_encode_k, nblk, 64, 0, s, a);
+    exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
+                        b->d_small64 + 8, s);
+    u64 total = 0;
+    { int rc = read_u64(b, b->d_small64 + 8, &total, 1, s); if (rc) return rc; }
+    b->out_qual_bytes[m] = total;
+    ENSURE(b, b->out_qual[m], total + 64);
+    LAUNCH(ac_frame_k, dim3(cdiv(stride, 16 * 256), nblk), 256, 0, s, b->ac_blocks.as<u8>(), stride, b->ac_sizes.as<u32>(),
+           b->ac_off.as<u64>(), b->out_qual[m].as<u8>());
+  }
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_compress(scalce_batch *b, const uint8_t *t1, uint64_t n1, const uint8_t *t2, uint64_t n2, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  int rc;
+  if ((rc = scalce_batch_ingest(b, 0, t1, n1, stream))) return rc;
+  if (b->nm == 2 && (rc = scalce_batch_ingest(b, 1, t2, n2, stream))) return rc;
+  if ((rc = scalce_batch_quality(b, stream))) return rc;
+  if ((rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
+  if ((rc = scalce_batch_order(b, stream))) return rc;
+  if ((rc = scalce_batch_emit(b, stream))) return rc;
+  if ((rc = scalce_batch_entropy(b, nullptr, stream))) return rc;
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_finish(scalce_batch *b, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  HIP_TRY(b->ctx, hipStreamSynchronize(s));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_err(b->ctx, "kernel launch failed: %s", hipGetErrorString(e)); return SCALCE_ERR_HIP; }
+  return check_device_error(b, s);
+}
+
+extern "C" uint64_t scalce_batch_reads(const scalce_batch *b) { return b ? b->N : 0; }
+
+extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes) {
+  if (!b || !d_ptr || !nbytes || mate < 0 || mate >= b->nm) return SCALCE_ERR_ARG;
+  const u32 nb1 = (u32)b->ctx->A.n_buckets + 1;
+  switch (which) {
+    case SCALCE_OUT_READS: *d_ptr = b->out_reads[mate].p; *nbytes = b->out_reads_bytes[mate]; break;
+    case SCALCE_OUT_NAMES: *d_ptr = b->out_names.p; *nbytes = b->out_names_bytes; break;
+    case SCALCE_OUT_QUAL:
+      *d_ptr = b->p.no_ac ? b->qs[mate].p : b->out_qual[mate].p;
+      *nbytes = b->out_qual_bytes[mate];
+      break;
+    case SCALCE_OUT_TABLE: *d_ptr = b->table[mate].p; *nbytes = sizeof(u32) * 512000; break;
+    case SCALCE_OUT_FREQ4: *d_ptr = b->freq4[mate].p; *nbytes = sizeof(u64) * 512000; break;
+    case SCALCE_OUT_TOKENS: *d_ptr = b->tokens.p; *nbytes = sizeof(int32_t) * 2 * b->N; break;
+    case SCALCE_OUT_PERM: *d_ptr = b->perm; *nbytes = sizeof(u32) * b->N; break;
+    case SCALCE_OUT_QSTREAM: *d_ptr = b->qs[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
+    case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->counts.p; *nbytes = sizeof(u64) * nb1; break;
+    case SCALCE_OUT_QINPUT: *d_ptr = b->q[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
+    default: return SCALCE_ERR_ARG;
+  }
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_stage_ms(scalce_batch *b, int which, float *ms, int *launches) {
+  if (!b || which < 0 || which >= ST_COUNT) return SCALCE_ERR_ARG;
+  if (ms) *ms = b->stage_ms[which];
+  if (launches) *launches = b->stage_launches[which];
+  return SCALCE_OK;
+}
+extern "C" void scalce_batch_stage_reset(scalce_batch *b, int enable) {
+  if (!b) return;
+  b->timing = enable != 0;
+  for (int i = 0; i < ST_COUNT; i++) { b->stage_ms[i] = 0; b->stage_launches[i] = 0; }
+}
+
+extern "C" int scalce_memcpy_d2h(scalce_ctx *c, void *dst, const void *src, uint64_t n) {
+  if (!c) return SCALCE_ERR_ARG;
+  if (!n) return SCALCE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+  return SCALCE_OK;
+}
+extern "C" int scalce_memcpy_h2d(scalce_ctx *c, void *dst, const void *src, uint64_t n) {
+  if (!c) return SCALCE_ERR_ARG;
+  if (!n) return SCALCE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+  return SCALCE_OK;
+}
+extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]) {
+  if (!b || !out) return SCALCE_ERR_ARG;
+  out[0] = b->ntie; out[1] = b->nev; out[2] = b->jacobi_iters; out[3] = b->nchunks;
+  return SCALCE_OK;
+}
+
+// ---- decode ---------------------------------------------------------------------------------------------
+extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const uint8_t *d_blocks, uint64_t nbytes,
+                                uint64_t nsym, uint8_t *d_out, void *stream) {
+  if (!c || !table_host || !d_blocks || !d_out) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const u32 nblk = cdiv(nsym, AC_BLOCK_SYMS);
+  if (!nblk) return SCALCE_OK;
+  // walk the [u32 size][bytes] frames on the host: sizes are 4 bytes each, the walk is serial by nature
+  std::vector<u64> off(nblk);
+  std::vector<u32> sz(nblk);
+  u64 pos = 0;
+  for (u32 i = 0; i < nblk; i++) {
+    if (pos + 4 > nbytes) { set_err(c, "(ERROR) truncated quality stream"); return SCALCE_ERR_FORMAT; }
+    HIP_TRY(c, hipMemcpy(&sz[i], d_blocks + pos, 4, hipMemcpyDeviceToHost));
+    off[i] = pos + 4;
+    pos += 4 + (u64)sz[i];
+    if (pos > nbytes) { set_err(c, "(ERROR) truncated quality stream"); return SCALCE_ERR_FORMAT; }
+  }
+  u32 *d_table = nullptr, *d_cum = nullptr, *d_sz = nullptr;
+  uint4 *d_tab = nullptr;
+  u64 *d_off = nullptr;
+  HIP_TRY(c, hipMalloc(&d_table, sizeof(u32) * 512000));
+  HIP_TRY(c, hipMalloc(&d_cum, sizeof(u32) * 6400 * 81));
+  HIP_TRY(c, hipMalloc(&d_tab, sizeof(uint4) * 512000));
+  HIP_TRY(c, hipMalloc(&d_off, sizeof(u64) * nblk));
+  HIP_TRY(c, hipMalloc(&d_sz, sizeof(u32) * nblk));
+  HIP_TRY(c, hipMemcpyAsync(d_table, table_host, sizeof(u32) * 512000, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(d_off, off.data(), sizeof(u64) * nblk, hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipMemcpyAsync(d_sz, sz.data(), sizeof(u32) * nblk, hipMemcpyHostToDevice, s));
+  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, d_table, d_tab, d_cum);
+  AcDecArgs a;
+  a.in = d_blocks; a.blk_off = d_off; a.blk_size = d_sz; a.nsym = nsym; a.cum = d_cum; a.out = d_out;
+  LAUNCH(ac_decode_k, nblk, 64, 0, s, a);
+  HIP_TRY(c, hipStreamSynchronize(s));
+  hipFree(d_table); hipFree(d_cum); hipFree(d_tab); hipFree(d_off); hipFree(d_sz);
+  return SCALCE_OK;
+}

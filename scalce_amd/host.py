@@ -1,0 +1,244 @@
+"""ctypes host over include/scalce_hip.h.
+
+Names follow the reference's seam: a Context carries the core table
+(read_patterns / prepare_aho_automata), a Batch is one FASTQ shard resident in HBM, and its stage
+methods are the batched forms of aho_search / output_read / output_quality / aho_trie_bucket /
+aho_output / set_ac_stat / ac_write.  PyTorch is only used by callers for device memory; this
+module takes raw device pointers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OUT_READS, OUT_NAMES, OUT_QUAL, OUT_TABLE, OUT_FREQ4, OUT_TOKENS, OUT_PERM, OUT_QSTREAM, OUT_BUCKET_COUNTS, OUT_QINPUT = range(10)
+STAGES = ("ingest", "quality", "tokenize", "order", "emit", "entropy")
+ROOT_CORE = 0x3FFFFFFF
+
+
+class ScalceError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libscalce_hip.so")
+
+
+class QMap(C.Structure):
+    _fields_ = [("offset", C.c_int32), ("values", C.c_int32 * 128)]
+
+
+class Params(C.Structure):
+    _fields_ = [("read_len", C.c_int32 * 2), ("paired", C.c_int32), ("use_names", C.c_int32), ("no_ac", C.c_int32),
+                ("qmap", QMap * 2), ("bucket_set_size", C.c_uint64), ("qprev", (C.c_uint32 * 2) * 2)]
+
+
+def lib():
+    """Load the HIP library; fail loudly when it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ScalceError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). scalce_amd has no CPU implementation.")
+    L = C.CDLL(path)
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    L.scalce_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.scalce_ctx_destroy.argtypes = [vp]
+    L.scalce_last_error.argtypes = [vp]
+    L.scalce_last_error.restype = C.c_char_p
+    L.scalce_patterns_load_bin.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.scalce_patterns_load_text.argtypes = [vp, C.c_char_p, C.c_size_t]
+    for f in ("scalce_patterns_count", "scalce_patterns_states", "scalce_patterns_buckets"):
+        getattr(L, f).argtypes = [vp]
+    L.scalce_pattern_length.argtypes = [vp, i32]
+    L.scalce_pattern_string.argtypes = [vp, i32]
+    L.scalce_pattern_string.restype = C.c_char_p
+    L.scalce_qmap_init.argtypes = [C.POINTER(QMap), C.POINTER(C.c_int32), i32]
+    L.scalce_qmap_init.restype = None
+    L.scalce_params_default.argtypes = [C.POINTER(Params)]
+    L.scalce_params_default.restype = None
+    L.scalce_batch_create.argtypes = [vp, C.POINTER(Params), u64, u64, C.POINTER(vp)]
+    L.scalce_batch_destroy.argtypes = [vp]
+    L.scalce_batch_ingest.argtypes = [vp, i32, vp, u64, vp]
+    L.scalce_batch_quality.argtypes = [vp, vp]
+    L.scalce_batch_tokenize.argtypes = [vp, vp, vp]
+    L.scalce_batch_order.argtypes = [vp, vp]
+    L.scalce_batch_emit.argtypes = [vp, vp]
+    L.scalce_batch_entropy.argtypes = [vp, vp, vp]
+    L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
+    L.scalce_batch_finish.argtypes = [vp, vp]
+    L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.scalce_batch_reads.argtypes = [vp]
+    L.scalce_batch_reads.restype = u64
+    L.scalce_batch_stage_ms.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(i32)]
+    L.scalce_batch_stage_reset.argtypes = [vp, i32]
+    L.scalce_batch_stage_reset.restype = None
+    L.scalce_batch_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.scalce_memcpy_d2h.argtypes = [vp, vp, vp, u64]
+    L.scalce_memcpy_h2d.argtypes = [vp, vp, vp, u64]
+    L.scalce_ac_decode.argtypes = [vp, vp, vp, u64, u64, vp, vp]
+    _LIB = L
+    return L
+
+
+def qmap_init(stat, lossy_percentage):
+    """quality_mapping_init after sampling (qualities.cpp:99-174) -> (offset, values[128])."""
+    q = QMap()
+    st = (C.c_int32 * 128)(*[int(x) for x in stat[:128]])
+    lib().scalce_qmap_init(C.byref(q), st, int(lossy_percentage))
+    return q.offset, np.array(list(q.values), dtype=np.int32)
+
+
+class Context:
+    def __init__(self, device=0, patterns_bin=None, patterns_text=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.scalce_ctx_create(int(device), C.byref(self.h))
+        if rc:
+            msg = self.L.scalce_last_error(self.h).decode() if self.h else "scalce_ctx_create failed"
+            raise ScalceError(msg)
+        if patterns_bin is not None:
+            self._check(self.L.scalce_patterns_load_bin(self.h, patterns_bin, len(patterns_bin)))
+        elif patterns_text is not None:
+            self._check(self.L.scalce_patterns_load_text(self.h, patterns_text, len(patterns_text)))
+
+    def _check(self, rc):
+        if rc:
+            raise ScalceError(f"[{rc}] " + self.L.scalce_last_error(self.h).decode())
+
+    @property
+    def n_patterns(self):
+        return self.L.scalce_patterns_count(self.h)
+
+    @property
+    def n_states(self):
+        return self.L.scalce_patterns_states(self.h)
+
+    @property
+    def n_buckets(self):
+        return self.L.scalce_patterns_buckets(self.h)
+
+    def pattern(self, p):
+        return self.L.scalce_pattern_string(self.h, p)
+
+    def to_host(self, d_ptr, nbytes, dtype=np.uint8):
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        if nbytes:
+            self._check(self.L.scalce_memcpy_d2h(self.h, out.ctypes.data, d_ptr, int(nbytes)))
+        return out.view(dtype)
+
+    def ac_decode(self, table_u32, d_blocks, nbytes, nsym, d_out, stream=0):
+        t = np.ascontiguousarray(table_u32, dtype=np.uint32)
+        self._check(self.L.scalce_ac_decode(self.h, t.ctypes.data, d_blocks, int(nbytes), int(nsym), d_out, stream))
+
+    def close(self):
+        if self.h:
+            self.L.scalce_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """One FASTQ shard in HBM (scalce_batch)."""
+
+    def __init__(self, ctx, read_len, max_reads, max_text, paired=False, use_names=True, no_ac=False, qmap=None,
+                 bucket_set_size=0, read_len2=0, qprev=None):
+        self.ctx = ctx
+        self.L = ctx.L
+        p = Params()
+        self.L.scalce_params_default(C.byref(p))
+        p.read_len[0] = int(read_len)
+        p.read_len[1] = int(read_len2 or read_len) if paired else 0
+        p.paired, p.use_names, p.no_ac = int(paired), int(use_names), int(no_ac)
+        p.bucket_set_size = int(bucket_set_size)
+        if qmap is not None:  # [(offset, values)] per mate
+            for m, (off, vals) in enumerate(qmap):
+                p.qmap[m].offset = int(off)
+                for i in range(128):
+                    p.qmap[m].values[i] = int(vals[i])
+        if qprev is not None:
+            for m in range(2):
+                for i in range(2):
+                    p.qprev[m][i] = int(qprev[m][i])
+        self.params = p
+        self.h = C.c_void_p()
+        rc = self.L.scalce_batch_create(ctx.h, C.byref(p), int(max_reads), int(max_text), C.byref(self.h))
+        if rc:
+            raise ScalceError(f"[{rc}] " + self.L.scalce_last_error(ctx.h).decode())
+
+    def _check(self, rc):
+        self.ctx._check(rc)
+
+    def ingest(self, mate, d_text, nbytes, stream=0):
+        self._check(self.L.scalce_batch_ingest(self.h, mate, d_text, int(nbytes), stream))
+
+    def quality(self, stream=0):
+        self._check(self.L.scalce_batch_quality(self.h, stream))
+
+    def tokenize(self, d_prior_counts=None, stream=0):
+        self._check(self.L.scalce_batch_tokenize(self.h, d_prior_counts, stream))
+
+    def order(self, stream=0):
+        self._check(self.L.scalce_batch_order(self.h, stream))
+
+    def emit(self, stream=0):
+        self._check(self.L.scalce_batch_emit(self.h, stream))
+
+    def entropy(self, d_table_override=None, stream=0):
+        self._check(self.L.scalce_batch_entropy(self.h, d_table_override, stream))
+
+    def compress(self, d_text1, n1, d_text2=None, n2=0, stream=0):
+        self._check(self.L.scalce_batch_compress(self.h, d_text1, int(n1), d_text2, int(n2), stream))
+
+    def finish(self, stream=0):
+        self._check(self.L.scalce_batch_finish(self.h, stream))
+
+    @property
+    def n_reads(self):
+        return int(self.L.scalce_batch_reads(self.h))
+
+    def output_ptr(self, which, mate=0):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self.L.scalce_batch_output(self.h, which, mate, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def output(self, which, mate=0, dtype=np.uint8):
+        p, n = self.output_ptr(which, mate)
+        return self.ctx.to_host(p, n, dtype)
+
+    def stats(self):
+        a = (C.c_uint32 * 4)()
+        self._check(self.L.scalce_batch_stats(self.h, a))
+        return dict(tie_reads=a[0], events=a[1], jacobi_iters=a[2], chunks=a[3])
+
+    def stage_reset(self, enable=True):
+        self.L.scalce_batch_stage_reset(self.h, int(enable))
+
+    def stage_ms(self):
+        out = {}
+        for i, name in enumerate(STAGES):
+            ms, n = C.c_float(), C.c_int()
+            self.L.scalce_batch_stage_ms(self.h, i, C.byref(ms), C.byref(n))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.scalce_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,212 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bit-exact everywhere: tokens (core, end) incl. the cumulative tie-break, output permutation, 2-bit
+records, names, q' symbols, trigram table, arithmetic-coder bytes, and finally the decompressed FASTQ.
+"""
+import hashlib
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from scalce_amd import format as fmt
+from scalce_amd import host, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx(patterns_blob):
+    return host.Context(0, patterns_bin=patterns_blob)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def check_against_oracle(ctx, trie, bases, quals, qoff=33, qvals=None, label=""):
+    from gpu_util import hip_compress, oracle_streams
+    n, L = bases.shape
+    fq = synth.fastq_bytes_fast(bases, quals)
+    qm = None if qvals is None else [(qoff, qvals), (qoff, qvals)]
+    b = hip_compress(ctx, fq, L, qmap=qm)
+    ref = oracle_streams(trie, bases, quals, qoff, qvals)
+    st = b.stats()
+    tok = b.output(host.OUT_TOKENS, 0, np.int32).reshape(-1, 2)
+    bad = np.flatnonzero((tok[:, 0] != ref["pat"]) | (tok[:, 1] != ref["end"]))
+    assert len(bad) == 0, f"{label}: {len(bad)} token mismatches, first at read {bad[:5]}: hip {tok[bad[:5]]} " \
+                          f"oracle {ref['pat'][bad[:5]]},{ref['end'][bad[:5]]} stats {st}"
+    perm = b.output(host.OUT_PERM, 0, np.uint32)
+    badp = np.flatnonzero(perm != ref["perm"])
+    assert len(badp) == 0, f"{label}: permutation differs at {len(badp)} of {n} positions, first {badp[:5]}"
+    qin = b.output(host.OUT_QINPUT, 0).reshape(n, L)
+    assert (qin == ref["qp"]).all(), f"{label}: q' mismatch"
+    f4 = b.output(host.OUT_FREQ4, 0, np.uint64)
+    assert (f4 + 1 == ref["f4"]).all(), f"{label}: trigram table mismatch at {np.flatnonzero(f4 + 1 != ref['f4'])[:5]}"
+    table = b.output(host.OUT_TABLE, 0, np.uint32)
+    assert (table == O.ac_scale(ref["f4"], 1)).all(), f"{label}: scaled table mismatch"
+    qs = b.output(host.OUT_QSTREAM, 0)
+    want_qs = ref["qp"][ref["perm"]].reshape(-1)
+    assert (qs == want_qs).all(), f"{label}: reordered quality stream mismatch"
+    enc = b.output(host.OUT_QUAL, 0)
+    want = O.AcStat(table).encode_stream(want_qs)
+    assert len(enc) == len(want), f"{label}: AC length {len(enc)} vs {len(want)}"
+    neq = np.flatnonzero(enc != want)
+    assert len(neq) == 0, f"{label}: AC bytes differ first at {neq[:5]} of {len(want)}"
+    return b, ref, st
+
+
+@pytest.mark.parametrize("name", ["se100", "se100_lossy", "se150_text", "se36_ties"])
+def test_golden_cases(name, patterns_blob):
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    kw = eval(str(g["kw"]))  # noqa: S307
+    bases, quals = synth.reads_and_quals(int(g["n"]), int(g["L"]), seed=int(g["seed"]), **kw)
+    if "ptxt" in g:
+        txt = str(g["ptxt"]).encode()
+        c, trie = host.Context(0, patterns_text=txt), O.Trie(text=txt)
+    else:
+        c, trie = host.Context(0, patterns_bin=patterns_blob), O.Trie(blob=patterns_blob)
+    qoff, qvals = (int(g["lut"][0]), g["lut"][1:]) if "lut" in g else (33, None)
+    b, ref, st = check_against_oracle(c, trie, bases, quals, qoff, qvals, label=name)
+    print(name, st)
+    # and directly against the vectors produced by the reference objects
+    tok = b.output(host.OUT_TOKENS, 0, np.int32).reshape(-1, 2)
+    assert sha(tok) == str(g["sha_tok"])
+    assert sha(b.output(host.OUT_PERM, 0, np.uint32).astype(np.int64)) == str(g["sha_order"])
+    assert sha(b.output(host.OUT_QINPUT, 0)) == str(g["sha_qual"])
+    assert sha(b.output(host.OUT_FREQ4, 0, np.uint64) + 1) == str(g["sha_freq4"])
+    assert sha(b.output(host.OUT_QUAL, 0)) == str(g["sha_ac"])
+    # .scalcer records (headers stripped) == concatenated output_read bytes in emission order
+    lens = trie.pattern_lens()
+    reads = b.output(host.OUT_READS, 0)
+    perm, pos, packed_in_order = ref["perm"], 0, []
+    L = int(g["L"])
+    goldp = g["packed"]
+    offs = np.zeros(len(bases) + 1, dtype=np.int64)
+    for r in range(len(bases)):
+        lvl = int(lens[ref["pat"][r]]) if ref["pat"][r] >= 0 else 0
+        offs[r + 1] = offs[r] + (L - lvl + 3) // 4
+    k = 0
+    while k < len(perm):
+        core, cnt = struct.unpack_from("<iq", reads, pos)
+        pos += 12
+        p = ref["pat"][perm[k]]
+        assert core == (p if p >= 0 else host.ROOT_CORE)
+        for i in range(cnt):
+            r = perm[k + i]
+            nb = offs[r + 1] - offs[r]
+            assert (reads[pos:pos + nb] == goldp[offs[r]:offs[r + 1]]).all(), f"record {k + i}"
+            assert reads[pos + nb] == ref["end"][r]
+            pos += nb + 1
+        k += cnt
+    assert pos == len(reads)
+
+
+def test_two_ac_blocks_and_decode(ctx, oracle_trie):
+    g = np.load(os.path.join(GOLD, "se100_110k.npz"), allow_pickle=False)
+    bases, quals = synth.reads_and_quals(int(g["n"]), int(g["L"]), seed=int(g["seed"]))
+    b, ref, st = check_against_oracle(ctx, oracle_trie, bases, quals, label="110k")
+    print("110k", st)
+    assert sha(b.output(host.OUT_QUAL, 0)) == str(g["sha_ac"])
+    assert sha(b.output(host.OUT_PERM, 0, np.uint32).astype(np.int64)) == str(g["sha_order"])
+    # GPU decoder inverts the GPU encoder
+    import torch
+    nsym = bases.size
+    out = torch.zeros(nsym, dtype=torch.uint8, device="cuda:0")
+    p, nbytes = b.output_ptr(host.OUT_QUAL, 0)
+    ctx.ac_decode(b.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nsym, out.data_ptr())
+    assert (out.cpu().numpy() == b.output(host.OUT_QSTREAM, 0)).all()
+
+
+@pytest.mark.parametrize("case", ["plain", "lossy", "noac", "nonames", "paired", "chunks", "odd_len"])
+def test_files_match_oracle_and_roundtrip(case, tmp_path, ctx, patterns_blob):
+    """Byte-identical .scalce{n,r,q} versus the oracle's writer, and the oracle's decompressor
+    restores the FASTQ from the files written from the GPU streams."""
+    from gpu_util import hip_compress
+    pbin = os.path.join(GOLD, "patterns.bin")
+    L = 75 if case == "odd_len" else 100
+    n = 6000
+    paired = case == "paired"
+    b1, q1 = synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=21, n_frac=0.004, dup_frac=0.15,
+                               paired_suffix="/1" if paired else None)
+    fq1 = open(tmp_path / "in_1.fq", "rb").read()
+    fq2 = None
+    if paired:
+        synth.write_fastq(str(tmp_path / "in_2.fq"), n, L, seed=22, paired_suffix="/2")
+        fq2 = open(tmp_path / "in_2.fq", "rb").read()
+    extra, kw = [], {}
+    lossy = 30 if case == "lossy" else 0
+    off, vals, Ls = fmt.sample_qmap(fq1, lossy=lossy)
+    assert Ls == L
+    qm = [(off, vals)]
+    if paired:
+        off2, vals2, _ = fmt.sample_qmap(fq2, lossy=lossy)
+        qm.append((off2, vals2))
+        extra.append("-r")
+    else:
+        qm.append((off, vals))
+    if lossy:
+        extra += ["-p", "30"]
+    if case == "noac":
+        extra.append("-A"); kw["no_ac"] = True
+    if case == "nonames":
+        extra += ["-n", "lib"]; kw["use_names"] = False
+    if case == "chunks":
+        extra += ["-B", "200000"]; kw["bucket_set_size"] = 200000
+    O.orc_cli("compress", pbin, tmp_path / "in_1.fq", tmp_path / "orc", *extra)
+    b = hip_compress(ctx, fq1, L, fastq2=fq2, L2=L, qmap=qm, **kw)
+    if case == "chunks":
+        assert b.stats()["chunks"] > 1
+    fmt.write_archive(str(tmp_path / "hip"), b, off, library="lib")
+    for m in ((1, 2) if paired else (1,)):
+        for ext in "nrq":
+            a = open(tmp_path / f"orc_{m}.scalce{ext}", "rb").read()
+            h = open(tmp_path / f"hip_{m}.scalce{ext}", "rb").read()
+            assert len(a) == len(h), f"{case} .scalce{ext} mate {m}: {len(h)} vs oracle {len(a)} bytes"
+            assert a == h, f"{case} .scalce{ext} mate {m} differs at byte {next(i for i in range(len(a)) if a[i] != h[i])}"
+    dextra = (["-r"] if paired else []) + (["-n", "lib"] if case == "nonames" else [])
+    O.orc_cli("decompress", pbin, tmp_path / "hip_1.scalcen", tmp_path / "back", *dextra)
+    if not lossy and case != "nonames":
+        for m in ((1, 2) if paired else (1,)):
+            src = open(tmp_path / f"in_{m}.fq", "rb").read().split(b"\n")
+            got = open(tmp_path / f"back_{m}.fastq", "rb").read().split(b"\n")
+
+            def canon(Ls_):
+                return sorted((Ls_[i], Ls_[i + 1], Ls_[i + 2], bytes(33 if x == 78 else y for x, y in zip(Ls_[i + 1], Ls_[i + 3])))
+                              for i in range(0, len(Ls_) - 1, 4))
+            assert canon(src) == canon(got)
+
+
+def test_malformed_input_is_an_error(ctx):
+    from gpu_util import device_bytes
+    b1, q1 = synth.reads_and_quals(50, 40, seed=3)
+    fq = bytearray(synth.fastq_bytes_fast(b1, q1))
+    bad = bytes(fq[:200]) + b"ACGT\n" + bytes(fq[200:])  # breaks the 4-line structure
+    t = device_bytes(bad)
+    b = host.Batch(ctx, 40, 100, len(bad) + 64)
+    with pytest.raises(host.ScalceError):
+        b.compress(t.data_ptr(), len(bad))
+        b.finish()
+    # one read shorter than the others (the reference exits: compress.cpp:628-634)
+    lines = bytes(fq).split(b"\n")
+    lines[5] = lines[5][:-1]
+    lines[7] = lines[7][:-1]
+    bad2 = b"\n".join(lines)
+    t2 = device_bytes(bad2)
+    b2 = host.Batch(ctx, 40, 100, len(bad2) + 64)
+    with pytest.raises(host.ScalceError):
+        b2.compress(t2.data_ptr(), len(bad2))
+        b2.finish()
+
+
+def test_empty_shard(ctx):
+    import torch
+    t = torch.zeros(16, dtype=torch.uint8, device="cuda:0")
+    b = host.Batch(ctx, 100, 16, 1024)
+    b.compress(t.data_ptr(), 0)
+    b.finish()
+    assert b.n_reads == 0
+    assert len(b.output(host.OUT_READS, 0)) == 0
