@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- input FASTQ MB/s of the SCALCE hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the whole hot path (ingest -> quality statistics -> tokenize with exact tie-break
+-> bucket/reorder -> emit -> arithmetic coder) over one synthetic shard that is already resident in HBM.
+N = 1 runs BASELINE.json configs[1]: 50 M x 100 bp single-end, arithmetic-coded qualities.  N > 1 is weak
+scaling: every rank holds a shard of the same size (one process per GPU, torch.distributed / RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (ac_encode_k): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (a port of the reference, single thread) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
+    ap.add_argument("--length", type=int, default=100)
+    ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="records of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--stage-times", action="store_true", help="also print per-stage HIP-event times to stderr")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from scalce_amd import host, synth_gpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n, L = args.reads, args.length
+    blob = open(os.path.join(ROOT, "tests", "golden", "patterns.bin"), "rb").read()
+    ctx = host.Context(local, patterns_bin=blob)
+    text = synth_gpu.fastq_on_device(n, L, dev, seed=20261003 + rank, first_index=rank * n)
+    nbytes = text.numel()
+    # quality model from the first 100 000 records of the shard (quality_mapping_init's sample)
+    head = text[: min(nbytes, 100000 * (2 * L + 20))].cpu().numpy().tobytes()
+    from scalce_amd import format as fmt
+    off, vals, Ls = fmt.sample_qmap(head)
+    assert Ls == L
+    batch = host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    state = {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if world == 1:
+            batch.compress(text.data_ptr(), nbytes, None, 0, stream)
+        else:
+            sharded_step(batch, ctx, text, nbytes, stream, dist, dev, n * L * world, state)
+        batch.finish(stream)
+
+    for _ in range(args.warmup):
+        step()
+    batch.kernel_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k = batch.kernel_ms()
+    stats = batch.stats()
+    out_bytes = sum(batch.output_ptr(w, 0)[1] for w in (host.OUT_READS, host.OUT_NAMES, host.OUT_QUAL))
+
+    if args.stage_times and rank == 0:
+        batch.stage_reset(True)
+        step()
+        print("stage ms:", {s: round(v[0], 2) for s, v in batch.stage_ms().items()}, stats, file=sys.stderr)
+        batch.stage_reset(False)
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cpu = cpu_baseline(text, n, L, args.cpu_sample)
+
+    if rank == 0:
+        total_in = nbytes * world
+        ms_per_step = dt / args.steps * 1e3
+        value = total_in * args.steps / dt / 1e6
+        per_launch_ms = k["total_ms"] / max(k["launches"], 1)
+        alg_bytes = (k["bytes_in"] + k["bytes_out"]) / max(k["launches"], 1)
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        line = {
+            "metric": "input FASTQ MB/s compressed, 100 bp reads, bit-exact decompress",
+            "value": round(value, 2),
+            "unit": "MB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{n} x {L} bp single-end synthetic FASTQ per GPU, arithmetic-coded qualities "
+                                   "(BASELINE.json configs[1])", "reads_per_gpu": n, "read_length": L,
+                       "input_bytes_per_gpu": nbytes, "output_bytes_per_gpu": int(out_bytes),
+                       "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}",
+                       "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"]},
+            "roofline": {"bound": "hbm", "kernel": "ac_encode_k", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "launch_ms": round(per_launch_ms, 3), "alg_bytes_per_launch": int(alg_bytes),
+                         "note": "serial chain per 10 MiB block: latency-bound, one wavefront per block"},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def sharded_step(batch, ctx, text, nbytes, stream, dist, dev, total_symbols, state):
+    """One step of the N > 1 path (DESIGN.md "Multi-GPU"): read ranges are sharded over ranks; the quality
+    model is run-wide -- the 80^3 trigram counters are summed with an RCCL all-reduce (plus the two
+    cross-shard trigrams per shard boundary), as are the per-core bucket counts; tokenisation, order and
+    coding then run per shard against the shared table."""
+    import torch
+    from scalce_amd import host
+    batch.ingest(0, text.data_ptr(), nbytes, stream)
+    batch.quality(stream)
+    if "f4" not in state:
+        state["f4"] = torch.empty(512000, dtype=torch.int64, device=dev)
+        state["edge"] = torch.empty(4, dtype=torch.int64, device=dev)
+    f4 = state["f4"]
+    p, nb = batch.output_ptr(host.OUT_FREQ4, 0)
+    ctx.copy_d2d(f4.data_ptr(), p, nb, stream)
+    dist.all_reduce(f4, op=dist.ReduceOp.SUM)
+    # shard-boundary trigrams: (a, b | c) and (b | c, d) with a,b the last symbols of the previous shard
+    qp, qn = batch.output_ptr(host.OUT_QINPUT, 0)
+    q = state["edge"]
+    qb = torch.empty(4, dtype=torch.uint8, device=dev)
+    ctx.copy_d2d(qb.data_ptr(), qp, 2, stream)
+    ctx.copy_d2d(qb.data_ptr() + 2, qp + qn - 2, 2, stream)
+    torch.cuda.synchronize()
+    world = dist.get_world_size()
+    edges = [torch.empty(4, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(edges, qb)
+    e = torch.stack(edges).cpu().numpy().astype("int64")
+    for r in range(1, world):
+        a, b = e[r - 1][2], e[r - 1][3]
+        c, d = e[r][0], e[r][1]
+        f4[(a * 80 + b) * 80 + c] += 1
+        f4[(b * 80 + c) * 80 + d] += 1
+    factor = 1 + total_symbols // 0xFFFFFFFF
+    table = torch.clamp_min((f4 + 1) // factor, 1).to(torch.int32)  # same bits as u32
+    state["table"] = table
+    batch.tokenize(None, stream)
+    cp, cn = batch.output_ptr(host.OUT_BUCKET_COUNTS, 0)
+    if "counts" not in state:
+        state["counts"] = torch.empty(cn // 8, dtype=torch.int64, device=dev)
+    ctx.copy_d2d(state["counts"].data_ptr(), cp, cn, stream)
+    dist.all_reduce(state["counts"], op=dist.ReduceOp.SUM)  # run-wide reads per core bucket
+    batch.order(stream)
+    batch.emit(stream)
+    batch.entropy(table.data_ptr(), stream)
+
+
+def cpu_baseline(text, n, L, sample):
+    """Time the CPU oracle (port of the reference, -T 1 -c no) on the first `sample` records."""
+    import numpy as np
+    sample = min(sample, n)
+    approx = sample * (2 * L + 8 + len(str(sample)))
+    head = text[: min(text.numel(), approx + 4096)].cpu().numpy()
+    nl = np.flatnonzero(head == 10)
+    sample = min(sample, len(nl) // 4)
+    end = int(nl[4 * sample - 1]) + 1
+    exe = os.path.join(ROOT, "oracle", "orc_cli")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    with tempfile.TemporaryDirectory() as d:
+        fq = os.path.join(d, "s_1.fq")
+        head[:end].tofile(fq)
+        t0 = time.perf_counter()
+        subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
+                        os.path.join(d, "o"), "-c", "no", "-T", "1"], check=True, capture_output=True)
+        dt = time.perf_counter() - t0
+    return {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} records ({end} bytes) of the same shard, orc_cli compress -c no -T 1, "
+                      f"{dt:.2f} s wall incl. file I/O", "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

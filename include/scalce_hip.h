@@ -126,9 +126,16 @@ uint64_t scalce_batch_reads(const scalce_batch *b);
 int scalce_batch_stage_ms(scalce_batch *b, int which, float *ms, int *launches);
 void scalce_batch_stage_reset(scalce_batch *b, int enable);
 
+/* HIP-event pairs around every launch of the dominant kernel (ac_encode_k) on the caller's stream.
+ * kernel_timing(1) arms and clears; kernel_ms synchronises the recorded events and returns the summed
+ * duration, the launch count and the algorithmic bytes (symbols read, coded bytes written). */
+void scalce_batch_kernel_timing(scalce_batch *b, int enable);
+int scalce_batch_kernel_ms(scalce_batch *b, double *total_ms, int *launches, uint64_t *bytes_in, uint64_t *bytes_out);
+
 /* plumbing for hosts without a HIP binding of their own (ctypes, cgo): blocking copies */
 int scalce_memcpy_d2h(scalce_ctx *ctx, void *dst_host, const void *src_dev, uint64_t nbytes);
 int scalce_memcpy_h2d(scalce_ctx *ctx, void *dst_dev, const void *src_host, uint64_t nbytes);
+int scalce_memcpy_d2d(scalce_ctx *ctx, void *dst_dev, const void *src_dev, uint64_t nbytes, void *stream); /* async */
 /* diagnostics of the last tokenize call: tie reads, candidate events, fixed-point iterations, spill chunks */
 int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]);
 

@@ -172,6 +172,11 @@ struct scalce_batch {
   float stage_ms[ST_COUNT] = {0};
   int stage_launches[ST_COUNT] = {0};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // HIP-event pairs around every ac_encode_k launch (the dominant kernel); read by scalce_batch_kernel_ms
+  bool ktiming = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+  size_t kev_used = 0;
+  u64 k_in_bytes = 0, k_out_bytes = 0;
 };
 
 static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
@@ -206,6 +211,7 @@ static void free_all(scalce_batch *b) {
   for (int m = 0; m < 2; m++) if (b->d_qlut[m]) hipFree(b->d_qlut[m]);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
+  for (auto &pr : b->kev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static inline int sz_read(int l) { return (l + 3) / 4; }
@@ -652,12 +658,27 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
     AcEncArgs a;
     a.sym = b->qs[m].as<u8>(); a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
     a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
+    hipEvent_t ke0 = nullptr, ke1 = nullptr;
+    if (b->ktiming) {
+      if (b->kev_used == b->kev.size()) {
+        hipEvent_t x, y;
+        HIP_TRY(c, hipEventCreate(&x));
+        HIP_TRY(c, hipEventCreate(&y));
+        b->kev.emplace_back(x, y);
+      }
+      ke0 = b->kev[b->kev_used].first; ke1 = b->kev[b->kev_used].second;
+      b->kev_used++;
+      hipEventRecord(ke0, s);
+    }
     LAUNCH(ac_encode_k, nblk, 64, 0, s, a);
+    if (ke1) hipEventRecord(ke1, s);
+    b->k_in_bytes += nsym;
     exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
                         b->d_small64 + 8, s);
     u64 total = 0;
     { int rc = read_u64(b, b->d_small64 + 8, &total, 1, s); if (rc) return rc; }
     b->out_qual_bytes[m] = total;
+    b->k_out_bytes += total - 4ull * nblk;
     ENSURE(b, b->out_qual[m], total + 64);
     LAUNCH(ac_frame_k, dim3(cdiv(stride, 16 * 256), nblk), 256, 0, s, b->ac_blocks.as<u8>(), stride, b->ac_sizes.as<u32>(),
            b->ac_off.as<u64>(), b->out_qual[m].as<u8>());
@@ -724,6 +745,29 @@ extern "C" void scalce_batch_stage_reset(scalce_batch *b, int enable) {
   for (int i = 0; i < ST_COUNT; i++) { b->stage_ms[i] = 0; b->stage_launches[i] = 0; }
 }
 
+extern "C" void scalce_batch_kernel_timing(scalce_batch *b, int enable) {
+  if (!b) return;
+  b->ktiming = enable != 0;
+  b->kev_used = 0;
+  b->k_in_bytes = b->k_out_bytes = 0;
+}
+extern "C" int scalce_batch_kernel_ms(scalce_batch *b, double *total_ms, int *launches, uint64_t *bytes_in,
+                                      uint64_t *bytes_out) {
+  if (!b) return SCALCE_ERR_ARG;
+  double tot = 0;
+  for (size_t i = 0; i < b->kev_used; i++) {
+    float ms = 0;
+    HIP_TRY(b->ctx, hipEventSynchronize(b->kev[i].second));
+    HIP_TRY(b->ctx, hipEventElapsedTime(&ms, b->kev[i].first, b->kev[i].second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int)b->kev_used;
+  if (bytes_in) *bytes_in = b->k_in_bytes;
+  if (bytes_out) *bytes_out = b->k_out_bytes;
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_memcpy_d2h(scalce_ctx *c, void *dst, const void *src, uint64_t n) {
   if (!c) return SCALCE_ERR_ARG;
   if (!n) return SCALCE_OK;
@@ -736,6 +780,13 @@ extern "C" int scalce_memcpy_h2d(scalce_ctx *c, void *dst, const void *src, uint
   if (!n) return SCALCE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpy(dst, src, n, hipMemcpyHostToDevice));
+  return SCALCE_OK;
+}
+extern "C" int scalce_memcpy_d2d(scalce_ctx *c, void *dst, const void *src, uint64_t n, void *stream) {
+  if (!c) return SCALCE_ERR_ARG;
+  if (!n) return SCALCE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SCALCE_OK;
 }
 extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]) {

@@ -45,6 +45,13 @@ def lib():
     if not os.path.exists(path):
         raise ScalceError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). scalce_amd has no CPU implementation.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; if the
+    # system copy gets loaded first (through this library's NEEDED entry) torch later finds no GPU.  Loading
+    # torch first makes the dynamic linker resolve our libamdhip64.so.7 to the copy torch already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     L.scalce_ctx_create.argtypes = [i32, C.POINTER(vp)]
@@ -79,8 +86,12 @@ def lib():
     L.scalce_batch_stage_reset.argtypes = [vp, i32]
     L.scalce_batch_stage_reset.restype = None
     L.scalce_batch_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.scalce_batch_kernel_timing.argtypes = [vp, i32]
+    L.scalce_batch_kernel_timing.restype = None
+    L.scalce_batch_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(u64), C.POINTER(u64)]
     L.scalce_memcpy_d2h.argtypes = [vp, vp, vp, u64]
     L.scalce_memcpy_h2d.argtypes = [vp, vp, vp, u64]
+    L.scalce_memcpy_d2d.argtypes = [vp, vp, vp, u64, vp]
     L.scalce_ac_decode.argtypes = [vp, vp, vp, u64, u64, vp, vp]
     _LIB = L
     return L
@@ -131,6 +142,9 @@ class Context:
         if nbytes:
             self._check(self.L.scalce_memcpy_d2h(self.h, out.ctypes.data, d_ptr, int(nbytes)))
         return out.view(dtype)
+
+    def copy_d2d(self, dst, src, nbytes, stream=0):
+        self._check(self.L.scalce_memcpy_d2d(self.h, dst, src, int(nbytes), stream))
 
     def ac_decode(self, table_u32, d_blocks, nbytes, nsym, d_out, stream=0):
         t = np.ascontiguousarray(table_u32, dtype=np.uint32)
@@ -231,6 +245,14 @@ class Batch:
             self.L.scalce_batch_stage_ms(self.h, i, C.byref(ms), C.byref(n))
             out[name] = (ms.value, n.value)
         return out
+
+    def kernel_timing(self, enable=True):
+        self.L.scalce_batch_kernel_timing(self.h, int(enable))
+
+    def kernel_ms(self):
+        ms, n, bi, bo = C.c_double(), C.c_int(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.scalce_batch_kernel_ms(self.h, C.byref(ms), C.byref(n), C.byref(bi), C.byref(bo)))
+        return dict(total_ms=ms.value, launches=n.value, bytes_in=bi.value, bytes_out=bo.value)
 
     def close(self):
         if self.h:
