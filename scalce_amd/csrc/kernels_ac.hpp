@@ -66,33 +66,6 @@ struct AcEncArgs {
   DevErr *err;
 };
 
-struct BitSink {
-  u32 *dst;
-  u32 wpos, wcap;
-  u64 acc;
-  u32 nb;
-  bool over;
-  __device__ __forceinline__ void put(u32 bits, u32 n) {  // n <= 32, bits right-aligned
-    acc = (acc << n) | bits;
-    nb += n;
-    if (nb >= 32) {
-      const u32 w = (u32)(acc >> (nb - 32));
-      if (wpos < wcap) {
-        if (lane_id() == 0) dst[wpos] = __builtin_bswap32(w);
-      } else over = true;
-      wpos++;
-      nb -= 32;
-    }
-  }
-  __device__ __forceinline__ void run(u32 bit, u32 count) {
-    while (count) {
-      const u32 m = count < 32 ? count : 32;
-      put(bit ? (m == 32 ? 0xFFFFFFFFu : ((1u << m) - 1)) : 0u, m);
-      count -= m;
-    }
-  }
-};
-
 // floor((R + 1) * g / 2^64) for R < 2^32, g < 2^64
 __device__ __forceinline__ u32 mulfrac(u32 R, u32 g_lo, u32 g_hi) {
   const u64 t0 = (u64)R * g_lo + g_lo;
@@ -100,20 +73,40 @@ __device__ __forceinline__ u32 mulfrac(u32 R, u32 g_lo, u32 g_hi) {
   return (u32)(t1 >> 32);
 }
 
+// ---- encoder -----------------------------------------------------------------------------------
+// One wavefront per 10 MiB block, 64 symbols per round:
+//   gather  (64 lanes)  operands of the NEXT round: context -> {g(lo), g(hi)} from the table
+//   chain   (scalar)    the coder state walks the 64 symbols; operands arrive by v_readlane, the
+//                       per-symbol outcome (hi before the shift, k = agreed leading bits, u =
+//                       underflow steps) is dropped into lane j with v_writelane.  No bit output here.
+//   pack    (64 lanes)  all 64 outcomes are turned into bits at once: a segmented scan resolves the
+//                       pending-underflow counts (arithmetic.cpp:136-139), a prefix sum gives every
+//                       symbol its bit offset, the bits are OR-ed into an LDS word buffer and the
+//                       finished words leave with one coalesced store.
+constexpr int AC_BUF_WORDS = 136;  // 31 carried bits + 64 symbols x 64 bits
+
+__device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos) {  // n in 1..32
+  const u32 s = bitpos & 31, w = bitpos >> 5;
+  const u64 x = (u64)bits << (64 - s - n);
+  atomicOr(&buf[w], (u32)(x >> 32));
+  if (s + n > 32) atomicOr(&buf[w + 1], (u32)x);
+}
+
 __global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
-  __shared__ uint4 ops[2][64];
+  __shared__ u32 buf[AC_BUF_WORDS];
   const u32 blk = blockIdx.x;
   const u64 boff = (u64)blk * AC_BLOCK_SYMS;
   const u8 *s = a.sym + boff;
   const u32 n = (u32)((a.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.nsym - boff) : (u64)AC_BLOCK_SYMS);
   const int lane = lane_id();
-  BitSink o;
-  o.dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
-  o.wpos = 0; o.wcap = a.out_cap / 4; o.acc = 0; o.nb = 0; o.over = false;
-  // the first two symbols travel raw (arithmetic.cpp:110-120)
-  o.put(s[0], 8);
-  o.put(n > 1 ? s[1] : 0u, 8);
-  u32 lo = 0, hi = 0xFFFFFFFFu, underflow = 0;
+  u32 *dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
+  const u32 wcap = a.out_cap / 4;
+  u32 gw = 0;          // words already stored
+  u32 c0 = 16;         // bits pending in `carry` (left aligned)
+  u32 carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
+  u32 pend = 0;        // underflow steps not yet materialised as bits
+  bool over = false;
+  u32 lo = 0, hi = 0xFFFFFFFFu;
 
   auto gather = [&](u32 base) -> uint4 {
     const u32 i = base + lane;
@@ -123,57 +116,138 @@ __global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
     return a.tab[((u64)p0 * AC_D + p1) * AC_D + c];
   };
 
+  // uniform append of nb <= 32 bits (every lane passes the same values): used by the rare slow path
+  // and by the final flush
+  auto emit_u = [&](u32 v, u32 nb) {
+    for (int w = lane; w < 4; w += 64) buf[w] = (w == 0) ? carry : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) lds_place(buf, v, nb, c0);
+    __builtin_amdgcn_wave_barrier();
+    const u32 endbits = c0 + nb;
+    const u32 nfull = endbits >> 5;  // 0 or 1
+    if (nfull && lane == 0) {
+      if (gw < wcap) dst[gw] = __builtin_bswap32(buf[0]);
+      else over = true;
+    }
+    carry = buf[nfull];
+    __builtin_amdgcn_wave_barrier();
+    c0 = endbits & 31;
+    gw += nfull;
+  };
+  auto emit_run_u = [&](u32 bit, u32 count) {
+    while (count) {
+      const u32 m = count < 32 ? count : 32;
+      emit_u(bit ? (m == 32 ? 0xFFFFFFFFu : ((1u << m) - 1)) : 0u, m);
+      count -= m;
+    }
+  };
+
+  // pack: rH = hi before the shift, rK = k | u << 8 per lane (0 for lanes without a symbol)
+  auto pack = [&](u32 rH, u32 rK) {
+    const u32 k = rK & 0xFF, u = rK >> 8;
+    const bool flag = k != 0;
+    // pending underflow before each symbol: segmented running sum of u, restarted by every emitting symbol
+    const u32 S = wave_inclusive_sum(u);
+    const u64 fm = __ballot(flag);
+    const u64 upto = fm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));  // flags at lanes <= lane
+    const int f = upto ? 63 - __clzll((long long)upto) : -1;             // last emitting lane <= lane
+    const u32 sbase = __shfl(S - u, f < 0 ? 0 : f, 64);                   // sum before that lane
+    const u32 U = f < 0 ? pend + S : S - sbase;                           // pending after this lane
+    u32 P = __shfl_up(U, 1, 64);
+    if (lane == 0) P = pend;
+    const u32 top = flag ? (k == 32 ? rH : (rH >> (32 - k))) : 0u;        // the k agreed bits
+    const u32 msb = flag ? (top >> (k - 1)) : 0u;
+    const u32 rest = (k > 1) ? (top & ((1u << (k - 1)) - 1)) : 0u;
+    const u32 pend_out = __shfl(U, 63, 64);
+    if (__any(flag && P > 32)) {
+      // an underflow run longer than 32 bits (about once per 2^32 symbols): walk the round serially
+      for (int j = 0; j < 64; j++) {
+        const u32 kj = __builtin_amdgcn_readlane(k, j);
+        if (!kj) continue;
+        const u32 Pj = __builtin_amdgcn_readlane(P, j), mj = __builtin_amdgcn_readlane(msb, j);
+        const u32 rj = __builtin_amdgcn_readlane(rest, j);
+        emit_u(mj, 1);
+        emit_run_u(mj ^ 1, Pj);
+        if (kj > 1) emit_u(rj, kj - 1);
+      }
+      pend = pend_out;
+      return;
+    }
+    const u32 nbits = flag ? k + P : 0u;
+    const u32 incl = wave_inclusive_sum(nbits);
+    const u32 total = __shfl(incl, 63, 64);
+    const u32 o = c0 + incl - nbits;
+    for (int w = lane; w < AC_BUF_WORDS; w += 64) buf[w] = (w == 0) ? carry : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (flag) {
+      const u32 run = (msb || P == 0) ? 0u : (P == 32 ? 0xFFFFFFFFu : ((1u << P) - 1));
+      const u64 v = ((u64)msb << (P + k - 1)) | ((u64)run << (k - 1)) | rest;
+      if (nbits > 32) {
+        lds_place(buf, (u32)(v >> 32), nbits - 32, o);
+        lds_place(buf, (u32)v, 32, o + nbits - 32);
+      } else {
+        lds_place(buf, (u32)v, nbits, o);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u32 endbits = c0 + total;
+    const u32 nfull = endbits >> 5;
+    for (u32 w = lane; w < nfull; w += 64) {
+      if (gw + w < wcap) dst[gw + w] = __builtin_bswap32(buf[w]);
+      else over = true;
+    }
+    carry = buf[nfull];
+    __builtin_amdgcn_wave_barrier();
+    c0 = endbits & 31;
+    gw += nfull;
+    pend = pend_out;
+  };
+
   uint4 cur = gather(0);
   for (u32 base = 0; base < n; base += 64) {
-    const int buf = (base >> 6) & 1;
-    ops[buf][lane] = cur;
-    if (base + 64 < n) cur = gather(base + 64);  // in flight during the serial part below
+    const uint4 ops = cur;
+    if (base + 64 < n) cur = gather(base + 64);  // in flight during the scalar chain below
     const u32 cnt = (n - base) < 64 ? (n - base) : 64;
+    u32 rH = 0, rK = 0;
     for (u32 j = (base == 0 ? 2u : 0u); j < cnt; j++) {
-      const uint4 g = ops[buf][j];
+      const u32 glo0 = __builtin_amdgcn_readlane(ops.x, j), glo1 = __builtin_amdgcn_readlane(ops.y, j);
+      const u32 ghi0 = __builtin_amdgcn_readlane(ops.z, j), ghi1 = __builtin_amdgcn_readlane(ops.w, j);
       const u32 R = hi - lo;
-      const u32 qa = mulfrac(R, g.z, g.w);
-      const u32 qb = mulfrac(R, g.x, g.y);
-      const u32 nhi = ((g.z | g.w) == 0) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
+      const u32 qa = mulfrac(R, ghi0, ghi1);
+      const u32 qb = mulfrac(R, glo0, glo1);
+      const u32 nhi = ((ghi0 | ghi1) == 0) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
       lo = lo + qb;
       hi = nhi;
       // renormalisation, arithmetic.cpp:133-152 in closed form
       const u32 x = lo ^ hi;
       const u32 k = x ? (u32)__clz(x) : 32u;  // leading bits on which lo and hi agree
-      if (k) {
-        const u32 msb = hi >> 31;
-        o.put(msb, 1);
-        o.run(msb ^ 1, underflow);
-        underflow = 0;
-        if (k > 1) o.put((hi << 1) >> (33 - k), k - 1);
-        if (k == 32) { lo = 0; hi = 0xFFFFFFFFu; }
-        else { lo <<= k; hi = (hi << k) | ((1u << k) - 1); }
-      }
+      const u32 hbefore = hi;
+      if (k == 32) { lo = 0; hi = 0xFFFFFFFFu; }
+      else { lo <<= k; hi = (hi << k) | ((1u << k) - 1); }
       // "underflow ante portas": lo = 01.., hi = 10.. -> drop the second bit, remember it
       const u32 y = (lo & ~hi) << 1;
       const u32 u = (u32)__clz(~y);  // leading ones of y; y has bit 0 clear so u <= 31
-      if (u) {
-        underflow += u;
-        lo = (lo << u) & 0x7FFFFFFFu;
-        hi = (hi << u) | ((1u << u) - 1) | 0x80000000u;
-      }
+      lo = ((lo << u) & 0x7FFFFFFFu) | (u ? 0u : (lo & 0x80000000u));
+      hi = u ? ((hi << u) | ((1u << u) - 1) | 0x80000000u) : hi;
+      const bool mine = (u32)lane == j;  // drop the outcome into lane j (v_cmp + 2 v_cndmask)
+      rH = mine ? hbefore : rH;
+      rK = mine ? (k | (u << 8)) : rK;
     }
+    pack(rH, rK);
   }
-  // flush, arithmetic.cpp:160-169
-  const u32 b30 = (lo >> 30) & 1;
-  o.put(b30, 1);
-  o.run(b30 ^ 1, underflow + 1);
-  const u64 bits = (u64)o.wpos * 32 + o.nb;
-  const u32 bytes = (u32)((bits + 7) >> 3);
-  if (o.nb) {
-    const u32 w = (u32)(o.acc << (32 - o.nb));
-    if (o.wpos < o.wcap) {
-      if (lane == 0) o.dst[o.wpos] = __builtin_bswap32(w);
-    } else o.over = true;
-  }
-  if (lane == 0) {
-    a.out_size[blk] = bytes;
-    if (o.over) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
+  // flush, arithmetic.cpp:160-169: bit 30 of lo, then pend+1 inverted copies, zero padding to a byte
+  {
+    const u32 b30 = (lo >> 30) & 1;
+    emit_u(b30, 1);
+    emit_run_u(b30 ^ 1, pend + 1);
+    const u64 bits = (u64)gw * 32 + c0;
+    if (c0) {
+      if (gw < wcap) { if (lane == 0) dst[gw] = __builtin_bswap32(carry); }
+      else over = true;
+    }
+    const u32 bytes = (u32)((bits + 7) >> 3);
+    if (lane == 0) a.out_size[blk] = bytes;
+    if (__any(over) && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
   }
 }
 
