@@ -64,6 +64,7 @@ struct AcEncArgs {
   u32 out_cap;      // bytes a block may write (multiple of 4)
   u32 *out_size;
   DevErr *err;
+  u32 slow_threshold;  // 32; tests lower it to drive every pending underflow through the serial path
 };
 
 // floor((R + 1) * g / 2^64) for R < 2^32, g < 2^64
@@ -74,15 +75,20 @@ __device__ __forceinline__ u32 mulfrac(u32 R, u32 g_lo, u32 g_hi) {
 }
 
 // ---- encoder -----------------------------------------------------------------------------------
-// One wavefront per 10 MiB block, 64 symbols per round:
-//   gather  (64 lanes)  operands of the NEXT round: context -> {g(lo), g(hi)} from the table
-//   chain   (scalar)    the coder state walks the 64 symbols; operands arrive by v_readlane, the
-//                       per-symbol outcome (hi before the shift, k = agreed leading bits, u =
-//                       underflow steps) is dropped into lane j with v_writelane.  No bit output here.
-//   pack    (64 lanes)  all 64 outcomes are turned into bits at once: a segmented scan resolves the
-//                       pending-underflow counts (arithmetic.cpp:136-139), a prefix sum gives every
-//                       symbol its bit offset, the bits are OR-ed into an LDS word buffer and the
-//                       finished words leave with one coalesced store.
+// One workgroup of two wavefronts per 10 MiB block, 64 symbols per round:
+//   wave 1, gather  (64 lanes)  operands of round r+1: context -> {g(lo), g(hi)} from the table -> LDS
+//   wave 0, chain   (1 lane)    the coder state walks the 64 symbols of round r: operands come from LDS,
+//                               the per-symbol outcome (hi before the shift, k = agreed leading bits,
+//                               u = underflow steps) goes back to LDS.  No bit output on this path.
+//                               Measured (tools/ubench_chain.hip): the chain costs ~90 ns per symbol as
+//                               vector code against ~145 ns as scalar code, because v_mad_u64_u32 does in
+//                               one instruction what takes five scalar ones, and issue is ~5-6 cycles per
+//                               dependent instruction either way.
+//   wave 1, pack    (64 lanes)  the 64 outcomes of round r-1 become bits at once: a segmented scan
+//                               resolves the pending-underflow counts (arithmetic.cpp:136-139), a prefix
+//                               sum gives every symbol its bit offset, the bits are OR-ed into an LDS
+//                               word buffer and the finished words leave with one coalesced store.
+// The two waves meet at one barrier per round, so gather and pack are off the chain's critical path.
 constexpr int AC_BUF_WORDS = 136;  // 31 carried bits + 64 symbols x 64 bits
 
 __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos) {  // n in 1..32
@@ -92,20 +98,28 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
   if (s + n > 32) atomicOr(&buf[w + 1], (u32)x);
 }
 
-__global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
+__global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
+  __shared__ uint4 ops[2][64];
+  __shared__ uint2 rec[2][64];
   __shared__ u32 buf[AC_BUF_WORDS];
+  __shared__ u32 final_lo;
   const u32 blk = blockIdx.x;
   const u64 boff = (u64)blk * AC_BLOCK_SYMS;
   const u8 *s = a.sym + boff;
   const u32 n = (u32)((a.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.nsym - boff) : (u64)AC_BLOCK_SYMS);
   const int lane = lane_id();
+  const bool chain_wave = wave_id() == 0;
+  const u32 nrounds = (n + 63) >> 6;
+
+  // ---- helper-wave state (bit sink) ----
   u32 *dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
   const u32 wcap = a.out_cap / 4;
   u32 gw = 0;          // words already stored
   u32 c0 = 16;         // bits pending in `carry` (left aligned)
-  u32 carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
+  u32 carry = 0;
   u32 pend = 0;        // underflow steps not yet materialised as bits
   bool over = false;
+  // ---- chain-wave state ----
   u32 lo = 0, hi = 0xFFFFFFFFu;
 
   auto gather = [&](u32 base) -> uint4 {
@@ -116,8 +130,8 @@ __global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
     return a.tab[((u64)p0 * AC_D + p1) * AC_D + c];
   };
 
-  // uniform append of nb <= 32 bits (every lane passes the same values): used by the rare slow path
-  // and by the final flush
+  // uniform append of nb <= 32 bits (every lane of the helper wave passes the same values): used by the
+  // rare slow path and by the final flush
   auto emit_u = [&](u32 v, u32 nb) {
     for (int w = lane; w < 4; w += 64) buf[w] = (w == 0) ? carry : 0u;
     __builtin_amdgcn_wave_barrier();
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
     }
   };
 
-  // pack: rH = hi before the shift, rK = k | u << 8 per lane (0 for lanes without a symbol)
+  // pack one round: rH = hi before the shift, rK = k | u << 8 per lane (0 for lanes without a symbol)
   auto pack = [&](u32 rH, u32 rK) {
     const u32 k = rK & 0xFF, u = rK >> 8;
     const bool flag = k != 0;
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
     const u32 msb = flag ? (top >> (k - 1)) : 0u;
     const u32 rest = (k > 1) ? (top & ((1u << (k - 1)) - 1)) : 0u;
     const u32 pend_out = __shfl(U, 63, 64);
-    if (__any(flag && P > 32)) {
+    if (__any(flag && P > a.slow_threshold)) {
       // an underflow run longer than 32 bits (about once per 2^32 symbols): walk the round serially
       for (int j = 0; j < 64; j++) {
         const u32 kj = __builtin_amdgcn_readlane(k, j);
@@ -203,41 +217,64 @@ __global__ __launch_bounds__(64) void ac_encode_k(AcEncArgs a) {
     pend = pend_out;
   };
 
-  uint4 cur = gather(0);
-  for (u32 base = 0; base < n; base += 64) {
-    const uint4 ops = cur;
-    if (base + 64 < n) cur = gather(base + 64);  // in flight during the scalar chain below
-    const u32 cnt = (n - base) < 64 ? (n - base) : 64;
-    u32 rH = 0, rK = 0;
-    for (u32 j = (base == 0 ? 2u : 0u); j < cnt; j++) {
-      const u32 glo0 = __builtin_amdgcn_readlane(ops.x, j), glo1 = __builtin_amdgcn_readlane(ops.y, j);
-      const u32 ghi0 = __builtin_amdgcn_readlane(ops.z, j), ghi1 = __builtin_amdgcn_readlane(ops.w, j);
-      const u32 R = hi - lo;
-      const u32 qa = mulfrac(R, ghi0, ghi1);
-      const u32 qb = mulfrac(R, glo0, glo1);
-      const u32 nhi = ((ghi0 | ghi1) == 0) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
-      lo = lo + qb;
-      hi = nhi;
-      // renormalisation, arithmetic.cpp:133-152 in closed form
-      const u32 x = lo ^ hi;
-      const u32 k = x ? (u32)__clz(x) : 32u;  // leading bits on which lo and hi agree
-      const u32 hbefore = hi;
-      if (k == 32) { lo = 0; hi = 0xFFFFFFFFu; }
-      else { lo <<= k; hi = (hi << k) | ((1u << k) - 1); }
-      // "underflow ante portas": lo = 01.., hi = 10.. -> drop the second bit, remember it
-      const u32 y = (lo & ~hi) << 1;
-      const u32 u = (u32)__clz(~y);  // leading ones of y; y has bit 0 clear so u <= 31
-      lo = ((lo << u) & 0x7FFFFFFFu) | (u ? 0u : (lo & 0x80000000u));
-      hi = u ? ((hi << u) | ((1u << u) - 1) | 0x80000000u) : hi;
-      const bool mine = (u32)lane == j;  // drop the outcome into lane j (v_cmp + 2 v_cndmask)
-      rH = mine ? hbefore : rH;
-      rK = mine ? (k | (u << 8)) : rK;
-    }
-    pack(rH, rK);
+  if (!chain_wave) {
+    carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
+    ops[0][lane] = gather(0);
   }
-  // flush, arithmetic.cpp:160-169: bit 30 of lo, then pend+1 inverted copies, zero padding to a byte
-  {
-    const u32 b30 = (lo >> 30) & 1;
+  __syncthreads();
+  for (u32 r = 0; r < nrounds; r++) {
+    const u32 base = r << 6;
+    if (chain_wave) {
+      if (lane == 0) {
+        const u32 cnt = (n - base) < 64 ? (n - base) : 64;
+        const uint4 *op = ops[r & 1];
+        uint2 *rc = rec[r & 1];
+        u32 j = (r == 0) ? 2u : 0u;
+        uint4 g = op[j < 64 ? j : 63];
+        for (; j < cnt; j++) {
+          const uint4 gn = op[j + 1 < 64 ? j + 1 : 63];  // next symbol's operands: hides the LDS latency
+          const u32 R = hi - lo;
+          const u32 qa = mulfrac(R, g.z, g.w);
+          const u32 qb = mulfrac(R, g.x, g.y);
+          const u32 nhi = ((g.z | g.w) == 0) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
+          lo = lo + qb;
+          hi = nhi;
+          // renormalisation, arithmetic.cpp:133-152 in closed form
+          const u32 x = lo ^ hi;
+          const u32 k = x ? (u32)__clz(x) : 32u;  // leading bits on which lo and hi agree
+          const u32 hbefore = hi;
+          if (k == 32) { lo = 0; hi = 0xFFFFFFFFu; }
+          else { lo <<= k; hi = (hi << k) | ((1u << k) - 1); }
+          // "underflow ante portas": lo = 01.., hi = 10.. -> drop the second bit, remember it
+          const u32 y = (lo & ~hi) << 1;
+          const u32 u = (u32)__clz(~y);  // leading ones of y; y has bit 0 clear so u <= 31
+          lo = ((lo << u) & 0x7FFFFFFFu) | (u ? 0u : (lo & 0x80000000u));
+          hi = u ? ((hi << u) | ((1u << u) - 1) | 0x80000000u) : hi;
+          rc[j] = make_uint2(hbefore, k | (u << 8));
+          g = gn;
+        }
+        if (r + 1 == nrounds) final_lo = lo;
+      }
+    } else {
+      if (base + 64 < n) ops[(r + 1) & 1][lane] = gather(base + 64);
+      if (r > 0) {
+        const uint2 v = rec[(r - 1) & 1][lane];
+        const bool valid = !(r == 1 && lane < 2);  // round 0: the two raw symbols carry no outcome
+        pack(valid ? v.x : 0u, valid ? v.y : 0u);
+      }
+    }
+    __syncthreads();
+  }
+  if (!chain_wave) {
+    {  // outcomes of the last round
+      const u32 r = nrounds - 1;
+      const u32 cnt = n - (r << 6);
+      const uint2 v = rec[r & 1][lane];
+      const bool valid = (u32)lane < cnt && !(r == 0 && lane < 2);
+      pack(valid ? v.x : 0u, valid ? v.y : 0u);
+    }
+    // flush, arithmetic.cpp:160-169: bit 30 of lo, then pend+1 inverted copies, zero padding to a byte
+    const u32 b30 = (final_lo >> 30) & 1;
     emit_u(b30, 1);
     emit_run_u(b30 ^ 1, pend + 1);
     const u64 bits = (u64)gw * 32 + c0;

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -658,6 +659,8 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
     AcEncArgs a;
     a.sym = b->qs[m].as<u8>(); a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
     a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
+    a.slow_threshold = 32;
+    if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
     hipEvent_t ke0 = nullptr, ke1 = nullptr;
     if (b->ktiming) {
       if (b->kev_used == b->kev.size()) {
@@ -670,7 +673,7 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
       b->kev_used++;
       hipEventRecord(ke0, s);
     }
-    LAUNCH(ac_encode_k, nblk, 64, 0, s, a);
+    LAUNCH(ac_encode_k, nblk, 128, 0, s, a);
     if (ke1) hipEventRecord(ke1, s);
     b->k_in_bytes += nsym;
     exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
