@@ -210,29 +210,77 @@ __global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
 // freq4[(p0*80+p1)*80+s] += 1 for every symbol of the flat input-order stream that has two
 // predecessors (cross-read predecessors included: the reference's prev[] is static,
 // qualities.cpp:179).  prev0/prev1 = the two symbols before this shard (500 = none).
-constexpr int TRI_PER_THREAD = 256;
-__global__ __launch_bounds__(256) void trigram_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u64 *freq4) {
-  const u64 start = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * TRI_PER_THREAD;
-  if (start >= n) return;
-  const u64 stop = start + TRI_PER_THREAD < n ? start + TRI_PER_THREAD : n;
-  u32 a = start >= 2 ? q[start - 2] : (start == 1 ? prev1 : prev0);
-  u32 b = start >= 1 ? q[start - 1] : prev1;
-  u32 lastkey = 0xFFFFFFFFu, run = 0;
-  for (u64 t = start; t < stop; t++) {
-    const u32 s = q[t];
-    if (a < 80 && b < 80 && s < 80) {
-      const u32 key = (a * 80 + b) * 80 + s;
-      if (key == lastkey) run++;
-      else {
-        if (run) atomicAdd(&freq4[lastkey], (u64)run);
-        lastkey = key;
-        run = 1;
-      }
+//
+// The 80^3 x u64 table (4 MB) does not fit LDS and hot trigrams would serialise global atomics, so
+// the table is built in slices: one launch per group of TRI_W leading symbols p0, the slice
+// (TRI_W x 6400 x u32 = 128 KB) lives in LDS, every workgroup streams the whole q' array with
+// 16-byte loads and counts only the trigrams of its slice with LDS atomics, then adds its non-zero
+// counters to the global table.  Slices whose leading symbols never occur exit at once
+// (symbol histogram from sym_hist_k), so a 40-symbol alphabet costs 8 streaming passes.
+constexpr int TRI_W = 5;
+constexpr int TRI_THREADS = 1024;
+constexpr int TRI_SLICE = TRI_W * 80 * 80;
+
+__global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist /*[256]*/) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 stride = (u64)gridDim.x * blockDim.x * 16;
+  for (u64 t = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16; t < n; t += stride) {
+    if (t + 16 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(q + t);
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 16; k++) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 255u], 1u);
+    } else {
+      for (u64 i = t; i < n; i++) atomicAdd(&h[q[i]], 1u);
     }
-    a = b;
-    b = s;
   }
-  if (run) atomicAdd(&freq4[lastkey], (u64)run);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(TRI_THREADS) void trigram_slice_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 p0_lo,
+                                                              const u64 *sym_hist, u64 *freq4) {
+  __shared__ u32 tab[TRI_SLICE];  // 128 000 B of the CU's 160 KB
+  {  // nothing to count when none of this slice's leading symbols occurs (incl. the carried-in ones)
+    bool any = false;
+    for (u32 k = 0; k < TRI_W; k++) {
+      const u32 sidx = p0_lo + k;
+      any |= (sidx < 80) && (sym_hist[sidx] != 0 || prev0 == sidx || prev1 == sidx);
+    }
+    if (!any) return;
+  }
+  for (int i = threadIdx.x; i < TRI_SLICE; i += TRI_THREADS) tab[i] = 0;
+  __syncthreads();
+  const u64 stride = (u64)gridDim.x * TRI_THREADS * 16;
+  for (u64 t = ((u64)blockIdx.x * TRI_THREADS + threadIdx.x) * 16; t < n; t += stride) {
+    u32 a = t >= 2 ? q[t - 2] : (t == 1 ? prev1 : prev0);
+    u32 b = t >= 1 ? q[t - 1] : prev1;
+    u32 w[4];
+    int cnt = 16;
+    if (t + 16 <= n) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(q + t);
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+      cnt = (int)(n - t);
+      w[0] = w[1] = w[2] = w[3] = 0;
+      for (int k = 0; k < cnt; k++) w[k >> 2] |= (u32)q[t + k] << (8 * (k & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 c = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+      const u32 d = a - p0_lo;
+      if (k < cnt && d < (u32)TRI_W && b < 80 && c < 80) atomicAdd(&tab[(d * 80 + b) * 80 + c], 1u);
+      a = b;
+      b = c;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TRI_SLICE; i += TRI_THREADS) {
+    const u32 v = tab[i];
+    if (v && p0_lo * 6400 + i < 512000) atomicAdd(&freq4[(u64)p0_lo * 6400 + i], (u64)v);
+  }
 }
 
 }  // namespace scalce

@@ -212,11 +212,19 @@ struct JacobiArgs {
   u32 *choice;          // tie index -> chosen candidate ordinal
   u8 *chosen;
   u32 *changed;         // [0] any change, [1] lowest tie index that changed
+  const u8 *dirty_in;   // per bucket: did a read of this bucket change its choice in the previous sweep?
+  u8 *dirty_out;        // ... in this sweep (cleared by the host before the launch)
 };
 __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.ntie) return;
-  const u32 off = a.tie_off[t], k = a.tie_ncand[t], e0 = a.ev_off[a.tie_read[t]];
+  const u32 off = a.tie_off[t], k = a.tie_ncand[t];
+  {  // a decision can only move if the count of one of its candidate buckets moved
+    bool any = false;
+    for (u32 j = 0; j < k; j++) any |= a.dirty_in[a.cand_bucket[off + j]] != 0;
+    if (!any) return;
+  }
+  const u32 e0 = a.ev_off[a.tie_read[t]];
   u32 best = 0;
   u64 bestc = 0;
   for (u32 j = 0; j < k; j++) {
@@ -233,6 +241,8 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
     a.chosen[a.ev_place[e0 + old]] = 0;
     a.chosen[a.ev_place[e0 + best]] = 1;
     a.choice[t] = best;
+    a.dirty_out[a.cand_bucket[off + old]] = 1;
+    a.dirty_out[a.cand_bucket[off + best]] = 1;
     a.changed[0] = 1;
     atomicMin(&a.changed[1], t);
   }

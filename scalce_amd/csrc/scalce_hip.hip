@@ -160,7 +160,7 @@ struct scalce_batch {
   u8 *d_qlut[2] = {nullptr, nullptr};
   DBuf line_end[2], packed[2], q[2], namelen, freq4[2], table[2], qs[2];
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
-  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg;
+  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
   DBuf perm_a, perm_b, hist, scan_ws, S;
   DBuf out_reads[2], out_names, name_off, ac_tab, ac_cum, ac_blocks, ac_sizes, ac_off, out_qual[2];
@@ -200,7 +200,7 @@ static void free_all(scalce_batch *b) {
                  &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
                  &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
-                 &b->chosen, &b->G, &b->seg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
+                 &b->chosen, &b->G, &b->seg, &b->dirty, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
                  &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S,
                  &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab, &b->ac_cum,
                  &b->ac_blocks, &b->ac_sizes, &b->ac_off, &b->out_qual[0], &b->out_qual[1]};
@@ -243,7 +243,7 @@ extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64
   HIP_TRY(c, hipMalloc(&b->d_err, sizeof(DevErr)));
   HIP_TRY(c, hipMemset(b->d_err, 0, sizeof(DevErr)));
   HIP_TRY(c, hipMalloc(&b->d_small, 64 * sizeof(u32)));
-  HIP_TRY(c, hipMalloc(&b->d_small64, 64 * sizeof(u64)));
+  HIP_TRY(c, hipMalloc(&b->d_small64, 512 * sizeof(u64)));
   HIP_TRY(c, hipEventCreate(&b->ev0));
   HIP_TRY(c, hipEventCreate(&b->ev1));
   for (int m = 0; m < b->nm; m++) {
@@ -378,8 +378,13 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     HIP_TRY(c, hipMemsetAsync(b->freq4[m].p, 0, sizeof(u64) * 512000, s));
     if (b->p.no_ac) continue;  // statistics are skipped under -A (qualities.cpp:185)
     const u64 n = b->N * (u64)b->L[m];
-    if (n) LAUNCH(trigram_k, cdiv(n, (u64)256 * TRI_PER_THREAD), 256, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0],
-                  b->p.qprev[m][1], b->freq4[m].as<u64>());
+    if (!n) continue;
+    u64 *hist = b->d_small64 + 16;  // 256 symbol counters live behind the scalar scratch
+    HIP_TRY(c, hipMemsetAsync(hist, 0, sizeof(u64) * 256, s));
+    LAUNCH(sym_hist_k, 2048, 256, 0, s, b->q[m].as<u8>(), n, hist);
+    for (u32 p0 = 0; p0 < 80; p0 += TRI_W)
+      LAUNCH(trigram_slice_k, 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0],
+             b->p.qprev[m][1], p0, hist, b->freq4[m].as<u64>());
   }
   return SCALCE_OK;
 }
@@ -486,6 +491,9 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
   // Jacobi iterations to the fixed point
   u32 *G = b->G.as<u32>();
   b->jacobi_iters = 0;
+  ENSURE(b, b->dirty, 2 * (size_t)(nb1 + 64));
+  u8 *dirty_in = b->dirty.as<u8>(), *dirty_out = dirty_in + nb1 + 64;
+  HIP_TRY(c, hipMemsetAsync(dirty_in, 1, nb1, s));  // first sweep: every bucket counts as moved
   for (;;) {
     exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, ws32, G + nev, s);
     if (!ntie) break;
@@ -496,7 +504,10 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
     a.cand_bucket = b->cand_bucket.as<u32>(); a.ev_off = b->ev_off.as<u32>(); a.ev_place = b->ev_place.as<u32>(); a.G = G;
     a.seg = b->seg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
     a.changed = b->d_small + 4;
+    a.dirty_in = dirty_in; a.dirty_out = dirty_out;
+    HIP_TRY(c, hipMemsetAsync(dirty_out, 0, nb1, s));
     LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
+    { u8 *t = dirty_in; dirty_in = dirty_out; dirty_out = t; }
     u32 ch[2];
     int rc = read_u32(b, b->d_small + 4, ch, 2, s);
     if (rc) return rc;
