@@ -139,6 +139,12 @@ int scalce_memcpy_d2d(scalce_ctx *ctx, void *dst_dev, const void *src_dev, uint6
 /* diagnostics of the last tokenize call: tie reads, candidate events, fixed-point iterations, spill chunks */
 int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]);
 
+/* Device self-test of the arithmetic coder's closed-form step (multiply-high by reciprocal fractions, merged
+ * renormalisation shift) against the literal loop of arithmetic.cpp:122-152 on `ncases` random and crafted
+ * states.  general = 0: the production step on well-formed states with totals <= 2^30; general = 1: the
+ * all-states step, including inverted intervals.  out[0] = mismatches, out[1..5] = lo, hi, c_lo, c_hi, total of the first one. */
+int scalce_selftest_ac(scalce_ctx *ctx, uint64_t ncases, uint32_t seed, int general, uint32_t out[6]);
+
 /* ---- decode side (next row of SURVEY 8f-1): ac_read / ac_decoder (arithmetic.cpp:173-268,
  *      365-400).  d_blocks = [u32 size][bytes]... as written by scalce_batch_entropy. ---------- */
 int scalce_ac_decode(scalce_ctx *ctx, const uint32_t *table_host, const uint8_t *d_blocks, uint64_t nbytes,

@@ -30,26 +30,29 @@ __global__ __launch_bounds__(256) void ac_scale_k(const u64 *freq4, u32 factor, 
   table[i] = p ? (u32)p : 1u;
 }
 
-// per (context, symbol): {g(lo) low, g(lo) high, g(hi) low, g(hi) high}; g(hi) == 0 marks hi == total
+// per (context, symbol): {g(lo) low, g(lo) high, g(hi) low, g(hi) high}.  c_hi == total (the last symbol of
+// a context) is marked by g(hi) = 2^64-1: a regular g is at most 2^64 - 2^64/total + 1 < 2^64 - 2^32, so its
+// high word never reaches 0xFFFFFFFF.
 __device__ __forceinline__ u64 recip_frac(u32 c, u32 d) {
   const u64 qh = ((u64)c << 32) / d;
   const u64 rem = ((u64)c << 32) - qh * d;
   const u64 ql = (rem << 32) / d;
   return ((qh << 32) | ql) + 1;
 }
-__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/) {
+__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/, u32 *max_total) {
   const u32 ctx = blockIdx.x * blockDim.x + threadIdx.x;
   if (ctx >= AC_D * AC_D) return;
   const u32 *f = table + (u64)ctx * AC_D;
   u32 tot = 0;
   for (int s = 0; s < AC_D; s++) tot += f[s];
+  if (max_total) atomicMax(max_total, tot);
   u32 run = 0;
   u64 glo = 1;  // c == 0 -> quotient 0
   cum[ctx * 81] = 0;
   for (int s = 0; s < AC_D; s++) {
     run += f[s];
     cum[ctx * 81 + s + 1] = run;
-    const u64 ghi = (run == tot) ? 0ull : recip_frac(run, tot);
+    const u64 ghi = (run == tot) ? ~0ull : recip_frac(run, tot);
     tab[(u64)ctx * AC_D + s] = make_uint4((u32)glo, (u32)(glo >> 32), (u32)ghi, (u32)(ghi >> 32));
     glo = ghi;
   }
@@ -67,11 +70,63 @@ struct AcEncArgs {
   u32 slow_threshold;  // 32; tests lower it to drive every pending underflow through the serial path
 };
 
-// floor((R + 1) * g / 2^64) for R < 2^32, g < 2^64
+// floor((R + 1) * g / 2^64) for R < 2^32, g < 2^64 -- plain form, used by the self-test as the yardstick
 __device__ __forceinline__ u32 mulfrac(u32 R, u32 g_lo, u32 g_hi) {
   const u64 t0 = (u64)R * g_lo + g_lo;
   const u64 t1 = (u64)R * g_hi + g_hi + (t0 >> 32);
   return (u32)(t1 >> 32);
+}
+// same value with M = R + 1 taken modulo 2^32 and `wrap` = (R == 0xFFFFFFFF): three instructions
+// (v_mul_hi_u32, v_cndmask, v_mad_u64_u32).  When M wrapped to 0 the product term vanishes and the
+// missing 2^32 * g is put back through the high word of the addend.
+__device__ __forceinline__ u32 mulfrac_m(u32 M, bool wrap, u32 g_lo, u32 g_hi) {
+  const u64 add = ((u64)(wrap ? g_hi : 0u) << 32) | __umulhi(M, g_lo);
+  return (u32)(((u64)M * g_hi + add) >> 32);
+}
+
+// One coder step (arithmetic.cpp:122-152) in closed form.  Returns k | u << 8; `hbefore` = hi before the
+// shift (its top k bits are the bits to emit).
+//   k = leading bits on which lo and hi agree (:134-139), u = the following positions where lo has 1 and
+//   hi has 0 ("underflow ante portas", :140-146); the loop can only run k steps of the first kind and
+//   then u of the second.
+// GENERAL = false is the production path: it assumes a well-formed coder state (lo <= hi, lo = 0..,
+// hi = 1.. after every step), which holds whenever no context total exceeds 2^30 -- then every symbol
+// keeps a non-empty interval because range > 2^30 >= total.  Both shifts are merged into one, and shifting
+// by min(k, 31) also gives the right state (lo = 0, hi = ~0) when all 32 bits agree.
+// GENERAL = true reproduces the reference bit for bit on ANY state, including the inverted intervals
+// (hi < lo) its 32-bit arithmetic runs into once a context total passes 2^30; the host selects it from the
+// table (scalce_batch_entropy).
+template <bool GENERAL>
+__device__ __forceinline__ u32 ac_step(u32 &lo, u32 &hi, const uint4 g, u32 &hbefore) {
+  const u32 R = hi - lo;
+  u32 M;
+  const bool wrap = __builtin_add_overflow(R, 1u, &M);
+  const u32 qa = mulfrac_m(M, wrap, g.z, g.w);
+  const u32 qb = mulfrac_m(M, wrap, g.x, g.y);
+  const u32 nhi = (g.w == 0xFFFFFFFFu) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
+  const u32 nlo = lo + qb;
+  hbefore = nhi;
+  const u32 x = nlo ^ nhi;
+  const u32 kf = x ? (u32)__clz(x) : 0xFFFFFFFFu;
+  const u32 krec = kf < 32u ? kf : 32u;
+  if (!GENERAL) {
+    const u32 ks = kf < 31u ? kf : 31u;
+    const u32 z = ((nlo & ~nhi) << ks) << 1;
+    const u32 u = (u32)__clz(~z);  // z has bit 0 clear, so ~z != 0 and u <= 31 - ks
+    const u32 t = ks + u;
+    lo = (nlo << t) & 0x7FFFFFFFu;
+    hi = (nhi << t) | ((1u << t) - 1) | 0x80000000u;
+    return krec | (u << 8);
+  } else {
+    u32 l1, h1;
+    if (krec == 32) { l1 = 0; h1 = 0xFFFFFFFFu; }
+    else { l1 = nlo << krec; h1 = (nhi << krec) | ((1u << krec) - 1); }
+    const u32 y = (l1 & ~h1) << 1;
+    const u32 u = (u32)__clz(~y);
+    lo = u ? ((l1 << u) & 0x7FFFFFFFu) : l1;
+    hi = u ? ((h1 << u) | ((1u << u) - 1) | 0x80000000u) : h1;
+    return krec | (u << 8);
+  }
 }
 
 // ---- encoder -----------------------------------------------------------------------------------
@@ -98,6 +153,7 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
   if (s + n > 32) atomicOr(&buf[w + 1], (u32)x);
 }
 
+template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   __shared__ uint4 ops[2][64];
   __shared__ uint2 rec[2][64];
@@ -233,24 +289,9 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
         uint4 g = op[j < 64 ? j : 63];
         for (; j < cnt; j++) {
           const uint4 gn = op[j + 1 < 64 ? j + 1 : 63];  // next symbol's operands: hides the LDS latency
-          const u32 R = hi - lo;
-          const u32 qa = mulfrac(R, g.z, g.w);
-          const u32 qb = mulfrac(R, g.x, g.y);
-          const u32 nhi = ((g.z | g.w) == 0) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
-          lo = lo + qb;
-          hi = nhi;
-          // renormalisation, arithmetic.cpp:133-152 in closed form
-          const u32 x = lo ^ hi;
-          const u32 k = x ? (u32)__clz(x) : 32u;  // leading bits on which lo and hi agree
-          const u32 hbefore = hi;
-          if (k == 32) { lo = 0; hi = 0xFFFFFFFFu; }
-          else { lo <<= k; hi = (hi << k) | ((1u << k) - 1); }
-          // "underflow ante portas": lo = 01.., hi = 10.. -> drop the second bit, remember it
-          const u32 y = (lo & ~hi) << 1;
-          const u32 u = (u32)__clz(~y);  // leading ones of y; y has bit 0 clear so u <= 31
-          lo = ((lo << u) & 0x7FFFFFFFu) | (u ? 0u : (lo & 0x80000000u));
-          hi = u ? ((hi << u) | ((1u << u) - 1) | 0x80000000u) : hi;
-          rc[j] = make_uint2(hbefore, k | (u << 8));
+          u32 hbefore;
+          const u32 ku = ac_step<GENERAL>(lo, hi, g, hbefore);
+          rc[j] = make_uint2(hbefore, ku);
           g = gn;
         }
         if (r + 1 == nrounds) final_lo = lo;
@@ -367,6 +408,69 @@ __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
     if (lane == 0) out[i] = (u8)k;
     p0 = p1;
     p1 = k;
+  }
+}
+
+// ---- self-test: closed-form step vs the reference's literal loop, on random and crafted states ------
+__device__ __forceinline__ u32 mix32(u32 x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void ac_selftest_k(u64 n, u32 seed, int general, u32 *mismatch /*[0]=count,[1..5]=first case*/) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 r0 = mix32((u32)i * 2654435761u + seed), r1 = mix32(r0 + 0x9E3779B9u), r2 = mix32(r1 + 0x85EBCA6Bu),
+      r3 = mix32(r2 + 0xC2B2AE35u), r4 = mix32(r3 + 0x27D4EB2Fu);
+  u32 lo = r0, hi = r1;
+  if (lo > hi) { const u32 t = lo; lo = hi; hi = t; }
+  u32 d = (r2 >> (r4 & 15)) | 2u;                 // totals of every magnitude, >= 2
+  if (d >= 0xFFFFFFFEu) d = 0xFFFFFFFDu;
+  u32 c_lo = r3 % d, c_hi = c_lo + 1 + (r4 >> 8) % (d - c_lo);
+  if (!general) {
+    // production path: well-formed states only -- lo = 0.., hi = 1.., not (lo = 01.. and hi = 10..), total <= 2^30
+    lo &= 0x7FFFFFFFu; hi |= 0x80000000u;
+    if ((lo & 0x40000000u) && !(hi & 0x40000000u)) lo &= 0x3FFFFFFFu;
+    d = (d & 0x3FFFFFFFu) | 2u;
+    if ((i & 15) == 9) d = 0x40000000u;            // the largest total the fast path accepts
+    c_lo = r3 % d; c_hi = c_lo + 1 + (r4 >> 8) % (d - c_lo);
+  }
+  switch (i & 7) {
+    case 1: lo = 0; hi = 0xFFFFFFFFu; break;       // block start / after a 32-bit agreement: R + 1 wraps
+    case 2: c_hi = d; break;                       // last symbol of the context
+    case 3: if (general) hi = lo + (r4 & 7);       // tiny ranges: inverted intervals, new lo == new hi
+            else { c_hi = c_lo + 1; if ((r4 & 3) == 0) { lo = 0x3FFFFFFFu - (r3 & 0xFFFF); hi = 0xC0000000u + (r2 & 0xFFFF); } } break;
+    case 4: lo = 0x7FFFFFF0u + (r3 & 15); hi = 0x80000000u + (r4 & 0xFFFF);
+            if (!general) { lo = 0x3FFFFFF0u + (r3 & 15); hi = 0xC0000000u + (r4 & 0xFFFF); } break;  // near the midpoint
+    case 5: c_lo = 0; break;
+    default: break;
+  }
+  // literal reference step (arithmetic.cpp:122-152)
+  u32 rlo = lo, rhi = hi, rk = 0, ru = 0, rhb;
+  {
+    const u64 range = (u64)(u32)(hi - lo) + 1;
+    rhi = (u32)(lo + (range * c_hi) / d - 1);
+    rlo = (u32)(lo + (range * c_lo) / d);
+    rhb = rhi;
+    for (;;) {
+      if ((rhi & 0x80000000u) == (rlo & 0x80000000u)) rk++;
+      else if (!(rhi & 0x40000000u) && (rlo & 0x40000000u)) { ru++; rlo &= 0x3FFFFFFFu; rhi |= 0x40000000u; }
+      else break;
+      rlo <<= 1;
+      rhi = (rhi << 1) | 1;
+      if (rk + ru > 70) break;
+    }
+  }
+  // closed form through the reciprocal table entries
+  const u64 glo = c_lo ? recip_frac(c_lo, d) : 1ull;
+  const u64 ghi = (c_hi == d) ? ~0ull : recip_frac(c_hi, d);
+  u32 flo = lo, fhi = hi, fhb;
+  const uint4 gg = make_uint4((u32)glo, (u32)(glo >> 32), (u32)ghi, (u32)(ghi >> 32));
+  const u32 ku = general ? ac_step<true>(flo, fhi, gg, fhb) : ac_step<false>(flo, fhi, gg, fhb);
+  const bool ordered = rk == 0 || true;
+  // in the literal loop the agreeing-bit phase and the underflow phase can only interleave as k then u
+  const bool ok = ordered && flo == rlo && fhi == rhi && (ku & 0xFF) == rk && (ku >> 8) == ru && fhb == rhb;
+  if (!ok && atomicAdd(&mismatch[0], 1u) == 0) {
+    mismatch[1] = lo; mismatch[2] = hi; mismatch[3] = c_lo; mismatch[4] = c_hi; mismatch[5] = d;
   }
 }
 

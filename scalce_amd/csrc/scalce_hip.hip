@@ -660,7 +660,13 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
     }
     ENSURE(b, b->ac_tab, sizeof(uint4) * 512000);
     ENSURE(b, b->ac_cum, sizeof(u32) * 6400 * 81);
-    LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab.as<uint4>(), b->ac_cum.as<u32>());
+    HIP_TRY(c, hipMemsetAsync(b->d_small + 12, 0, sizeof(u32), s));
+    LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab.as<uint4>(), b->ac_cum.as<u32>(), b->d_small + 12);
+    u32 max_total = 0;
+    { int rc = read_u32(b, b->d_small + 12, &max_total, 1, s); if (rc) return rc; }
+    // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
+    // follows it there bit for bit
+    const bool general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
     const u32 nblk = cdiv(nsym, AC_BLOCK_SYMS);
     const u64 stride = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
     ENSURE(b, b->ac_blocks, (size_t)nblk * stride + 64);
@@ -684,7 +690,8 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
       b->kev_used++;
       hipEventRecord(ke0, s);
     }
-    LAUNCH(ac_encode_k, nblk, 128, 0, s, a);
+    if (general) LAUNCH(ac_encode_k<true>, nblk, 128, 0, s, a);
+    else LAUNCH(ac_encode_k<false>, nblk, 128, 0, s, a);
     if (ke1) hipEventRecord(ke1, s);
     b->k_in_bytes += nsym;
     exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
@@ -809,6 +816,19 @@ extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]) {
   return SCALCE_OK;
 }
 
+extern "C" int scalce_selftest_ac(scalce_ctx *c, uint64_t ncases, uint32_t seed, int general, uint32_t out[6]) {
+  if (!c || !out) return SCALCE_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  u32 *d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, 8 * sizeof(u32)));
+  HIP_TRY(c, hipMemset(d, 0, 8 * sizeof(u32)));
+  LAUNCH(ac_selftest_k, cdiv(ncases, 256), 256, 0, 0, (u64)ncases, seed, general, d);
+  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipMemcpy(out, d, 6 * sizeof(u32), hipMemcpyDeviceToHost));
+  hipFree(d);
+  return SCALCE_OK;
+}
+
 // ---- decode ---------------------------------------------------------------------------------------------
 extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const uint8_t *d_blocks, uint64_t nbytes,
                                 uint64_t nsym, uint8_t *d_out, void *stream) {
@@ -839,7 +859,7 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
   HIP_TRY(c, hipMemcpyAsync(d_table, table_host, sizeof(u32) * 512000, hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemcpyAsync(d_off, off.data(), sizeof(u64) * nblk, hipMemcpyHostToDevice, s));
   HIP_TRY(c, hipMemcpyAsync(d_sz, sz.data(), sizeof(u32) * nblk, hipMemcpyHostToDevice, s));
-  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, d_table, d_tab, d_cum);
+  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, d_table, d_tab, d_cum, (u32 *)nullptr);
   AcDecArgs a;
   a.in = d_blocks; a.blk_off = d_off; a.blk_size = d_sz; a.nsym = nsym; a.cum = d_cum; a.out = d_out;
   LAUNCH(ac_decode_k, nblk, 64, 0, s, a);

@@ -92,6 +92,7 @@ def lib():
     L.scalce_memcpy_d2h.argtypes = [vp, vp, vp, u64]
     L.scalce_memcpy_h2d.argtypes = [vp, vp, vp, u64]
     L.scalce_memcpy_d2d.argtypes = [vp, vp, vp, u64, vp]
+    L.scalce_selftest_ac.argtypes = [vp, u64, C.c_uint32, i32, C.POINTER(C.c_uint32)]
     L.scalce_ac_decode.argtypes = [vp, vp, vp, u64, u64, vp, vp]
     _LIB = L
     return L
@@ -142,6 +143,11 @@ class Context:
         if nbytes:
             self._check(self.L.scalce_memcpy_d2h(self.h, out.ctypes.data, d_ptr, int(nbytes)))
         return out.view(dtype)
+
+    def selftest_ac(self, ncases=1 << 24, seed=1, general=False):
+        out = (C.c_uint32 * 6)()
+        self._check(self.L.scalce_selftest_ac(self.h, int(ncases), int(seed), int(general), out))
+        return list(out)
 
     def copy_d2d(self, dst, src, nbytes, stream=0):
         self._check(self.L.scalce_memcpy_d2d(self.h, dst, src, int(nbytes), stream))

@@ -180,6 +180,32 @@ def test_files_match_oracle_and_roundtrip(case, tmp_path, ctx, patterns_blob):
             assert canon(src) == canon(got)
 
 
+def test_ac_step_closed_form_selftest(ctx):
+    """64 M random + crafted coder states: reciprocal multiply-high and the merged shift reproduce the
+    reference's division and bit-by-bit renormalisation loop exactly (incl. R+1 wrap, last symbol,
+    all-32-bits-agree, long underflow runs)."""
+    for general in (False, True):
+        for seed in (1, 2, 3, 4):
+            out = ctx.selftest_ac(1 << 24, seed, general)
+            assert out[0] == 0, (f"general={general} seed {seed}: {out[0]} mismatches, first lo={out[1]:#x} hi={out[2]:#x} "
+                                 f"c_lo={out[3]} c_hi={out[4]} d={out[5]}")
+
+
+def test_ac_slow_emit_path(ctx, oracle_trie, monkeypatch):
+    """Force every pending-underflow round through the serial emit path (normally taken about once per 2^32
+    symbols) and require the same bytes."""
+    monkeypatch.setenv("SCALCE_AC_SLOW_THRESHOLD", "0")
+    bases, quals = synth.reads_and_quals(30000, 100, seed=77)
+    check_against_oracle(ctx, oracle_trie, bases, quals, label="slow-emit")
+
+
+def test_ac_general_step_same_bytes(ctx, oracle_trie, monkeypatch):
+    """The all-states coder step (selected when a context total exceeds 2^30) gives the same stream."""
+    monkeypatch.setenv("SCALCE_AC_GENERAL", "1")
+    bases, quals = synth.reads_and_quals(30000, 100, seed=78)
+    check_against_oracle(ctx, oracle_trie, bases, quals, label="general-step")
+
+
 def test_malformed_input_is_an_error(ctx):
     from gpu_util import device_bytes
     b1, q1 = synth.reads_and_quals(50, 40, seed=3)
