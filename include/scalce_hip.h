@@ -142,7 +142,8 @@ int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]);
 /* Device self-test of the arithmetic coder's closed-form step (multiply-high by reciprocal fractions, merged
  * renormalisation shift) against the literal loop of arithmetic.cpp:122-152 on `ncases` random and crafted
  * states.  general = 0: the production step on well-formed states with totals <= 2^30; general = 1: the
- * all-states step, including inverted intervals.  out[0] = mismatches, out[1..5] = lo, hi, c_lo, c_hi, total of the first one. */
+ * all-states step, including inverted intervals; general = 2: the plain-round step on the (lo, range) state with
+ * its fall-back, as the encoder's inner loop runs it.  out[0] = mismatches, out[1..5] = lo, hi, c_lo, c_hi, total of the first one. */
 int scalce_selftest_ac(scalce_ctx *ctx, uint64_t ncases, uint32_t seed, int general, uint32_t out[6]);
 
 /* ---- decode side (next row of SURVEY 8f-1): ac_read / ac_decoder (arithmetic.cpp:173-268,

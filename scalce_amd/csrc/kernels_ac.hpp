@@ -129,6 +129,36 @@ __device__ __forceinline__ u32 ac_step(u32 &lo, u32 &hi, const uint4 g, u32 &hbe
   }
 }
 
+// The step of a "plain" round, on the state (lo, M) with M = hi - lo + 1 taken modulo 2^32.  Renormalising
+// by t bits multiplies the range by 2^t whichever mix of agreeing-bit and underflow steps t is made of, so
+// M' = (A - B) << t and hi never has to be rebuilt.  Preconditions, checked by the caller: no symbol of the
+// round is the last one of its context (helper wave), and M != 0, i.e. the interval is not the full 2^32.
+// Two outcomes need the general step and are reported through the return value being 0: all 32 bits agree
+// (x == 0), or the new interval is an aligned power-of-two block that renormalises to the full 2^32
+// (M' == 0).  In that case lo and M are left untouched and the caller redoes the symbol.
+__device__ __forceinline__ u32 ac_step_plain(u32 &lo, u32 &M, const uint4 g, u32 &hbefore, u32 &ku) {
+  const u32 A = (u32)(((u64)M * g.w + __umulhi(M, g.z)) >> 32);
+  const u32 B = (u32)(((u64)M * g.y + __umulhi(M, g.x)) >> 32);
+  const u32 W = A - B;           // new range before renormalisation (>= 1 on a well-formed table)
+  const u32 nlo = lo + B;
+  const u32 nhi = nlo + W - 1;
+  hbefore = nhi;
+  const u32 x = nlo ^ nhi;
+  const u32 k = (u32)__builtin_clz(x | 1u) & 31u;
+  const u32 z = ((nlo & ~nhi) << k) << 1;
+  const u32 u = (u32)__builtin_clz(~z);  // bit 0 of z is clear: ~z != 0
+  const u32 t = k + u;                   // <= 31
+  const u32 Mn = W << t;
+  const u32 e = x < Mn ? x : Mn;         // 0 iff x == 0 or the range wrapped to 2^32
+  ku = k | (u << 8);
+  const u32 es = __builtin_amdgcn_readfirstlane(e);  // only lane 0 is active: the caller's branch is scalar
+  if (es != 0) {
+    lo = (nlo << t) & 0x7FFFFFFFu;
+    M = Mn;
+  }
+  return es;
+}
+
 // ---- encoder -----------------------------------------------------------------------------------
 // One workgroup of two wavefronts per 10 MiB block, 64 symbols per round:
 //   wave 1, gather  (64 lanes)  operands of round r+1: context -> {g(lo), g(hi)} from the table -> LDS
@@ -155,10 +185,11 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
 
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
-  __shared__ uint4 ops[2][64];
+  __shared__ uint4 ops[2][66];  // +1: the chain prefetches one entry past the round
   __shared__ uint2 rec[2][64];
   __shared__ u32 buf[AC_BUF_WORDS];
   __shared__ u32 final_lo;
+  __shared__ u32 plain_round[2];  // helper -> chain: no last-of-context symbol in the round
   const u32 blk = blockIdx.x;
   const u64 boff = (u64)blk * AC_BLOCK_SYMS;
   const u8 *s = a.sym + boff;
@@ -275,7 +306,11 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
 
   if (!chain_wave) {
     carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
-    ops[0][lane] = gather(0);
+    const uint4 g0 = gather(0);
+    ops[0][lane] = g0;
+    const bool any_last = __any(g0.w == 0xFFFFFFFFu);
+    if (lane == 0) plain_round[0] = 0;  // round 0 starts from the full interval (R + 1 wraps): general step
+    (void)any_last;
   }
   __syncthreads();
   for (u32 r = 0; r < nrounds; r++) {
@@ -286,18 +321,44 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
         const uint4 *op = ops[r & 1];
         uint2 *rc = rec[r & 1];
         u32 j = (r == 0) ? 2u : 0u;
-        uint4 g = op[j < 64 ? j : 63];
-        for (; j < cnt; j++) {
-          const uint4 gn = op[j + 1 < 64 ? j + 1 : 63];  // next symbol's operands: hides the LDS latency
-          u32 hbefore;
-          const u32 ku = ac_step<GENERAL>(lo, hi, g, hbefore);
-          rc[j] = make_uint2(hbefore, ku);
-          g = gn;
+        u32 M = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
+        if (!GENERAL && plain_round[r & 1] && __builtin_amdgcn_readfirstlane(M) != 0) {
+          // two symbols per trip; operands are fetched from LDS one step ahead of their use (sched_barrier
+          // keeps the compiler from sinking the ds_read next to its consumer)
+          uint4 gA = op[j < 64 ? j : 63];
+          while (j + 1 < cnt) {
+            const uint4 gB = op[j + 1];
+            __builtin_amdgcn_sched_barrier(0);
+            u32 hb, ku;
+            if (ac_step_plain(lo, M, gA, hb, ku) == 0) break;  // rare: redo symbol j with the general step
+            rc[j] = make_uint2(hb, ku);
+            gA = op[j + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            if (ac_step_plain(lo, M, gB, hb, ku) == 0) { j += 1; break; }
+            rc[j + 1] = make_uint2(hb, ku);
+            j += 2;
+          }
+          hi = lo + M - 1;
+        }
+        if (j < cnt) {  // general steps: first round, rounds with a last-of-context symbol, after a 32-bit agreement
+          uint4 g = op[j];
+          for (; j < cnt; j++) {
+            const uint4 gn = op[j + 1];
+            u32 hbefore;
+            const u32 ku = ac_step<GENERAL>(lo, hi, g, hbefore);
+            rc[j] = make_uint2(hbefore, ku);
+            g = gn;
+          }
         }
         if (r + 1 == nrounds) final_lo = lo;
       }
     } else {
-      if (base + 64 < n) ops[(r + 1) & 1][lane] = gather(base + 64);
+      if (base + 64 < n) {
+        const uint4 gnext = gather(base + 64);
+        ops[(r + 1) & 1][lane] = gnext;
+        const bool any_last = __any(gnext.w == 0xFFFFFFFFu);
+        if (lane == 0) plain_round[(r + 1) & 1] = any_last ? 0u : 1u;
+      }
       if (r > 0) {
         const uint2 v = rec[(r - 1) & 1][lane];
         const bool valid = !(r == 1 && lane < 2);  // round 0: the two raw symbols carry no outcome
@@ -426,7 +487,7 @@ __global__ __launch_bounds__(256) void ac_selftest_k(u64 n, u32 seed, int genera
   u32 d = (r2 >> (r4 & 15)) | 2u;                 // totals of every magnitude, >= 2
   if (d >= 0xFFFFFFFEu) d = 0xFFFFFFFDu;
   u32 c_lo = r3 % d, c_hi = c_lo + 1 + (r4 >> 8) % (d - c_lo);
-  if (!general) {
+  if (general != 1) {
     // production path: well-formed states only -- lo = 0.., hi = 1.., not (lo = 01.. and hi = 10..), total <= 2^30
     lo &= 0x7FFFFFFFu; hi |= 0x80000000u;
     if ((lo & 0x40000000u) && !(hi & 0x40000000u)) lo &= 0x3FFFFFFFu;
@@ -437,11 +498,13 @@ __global__ __launch_bounds__(256) void ac_selftest_k(u64 n, u32 seed, int genera
   switch (i & 7) {
     case 1: lo = 0; hi = 0xFFFFFFFFu; break;       // block start / after a 32-bit agreement: R + 1 wraps
     case 2: c_hi = d; break;                       // last symbol of the context
-    case 3: if (general) hi = lo + (r4 & 7);       // tiny ranges: inverted intervals, new lo == new hi
+    case 3: if (general == 1) hi = lo + (r4 & 7);       // tiny ranges: inverted intervals, new lo == new hi
             else { c_hi = c_lo + 1; if ((r4 & 3) == 0) { lo = 0x3FFFFFFFu - (r3 & 0xFFFF); hi = 0xC0000000u + (r2 & 0xFFFF); } } break;
     case 4: lo = 0x7FFFFFF0u + (r3 & 15); hi = 0x80000000u + (r4 & 0xFFFF);
-            if (!general) { lo = 0x3FFFFFF0u + (r3 & 15); hi = 0xC0000000u + (r4 & 0xFFFF); } break;  // near the midpoint
+            if (general != 1) { lo = 0x3FFFFFF0u + (r3 & 15); hi = 0xC0000000u + (r4 & 0xFFFF); } break;  // near the midpoint
     case 5: c_lo = 0; break;
+    case 6:  // the new interval is an aligned power-of-two block: renormalises to the full 2^32 without x == 0
+      lo = 0x40000000u; hi = 0xBFFFFFFFu; d = 4u << (r3 & 7); c_lo = d / 4; c_hi = d / 2; break;
     default: break;
   }
   // literal reference step (arithmetic.cpp:122-152)
@@ -465,7 +528,25 @@ __global__ __launch_bounds__(256) void ac_selftest_k(u64 n, u32 seed, int genera
   const u64 ghi = (c_hi == d) ? ~0ull : recip_frac(c_hi, d);
   u32 flo = lo, fhi = hi, fhb;
   const uint4 gg = make_uint4((u32)glo, (u32)(glo >> 32), (u32)ghi, (u32)(ghi >> 32));
-  const u32 ku = general ? ac_step<true>(flo, fhi, gg, fhb) : ac_step<false>(flo, fhi, gg, fhb);
+  u32 ku;
+  if (general == 2) {
+    // the plain step exactly as the encoder uses it: (lo, M) state, fall back to the general step on a 0 return
+    u32 M = fhi - flo + 1, kup = 0;
+    bool done = false;
+    if (M != 0 && c_hi != d) {
+      // ac_step_plain's exit test reads lane 0 of the wave; give every lane its own verdict here
+      u32 plo = flo, pM = M, phb;
+      const u32 A = (u32)(((u64)M * gg.w + __umulhi(M, gg.z)) >> 32), B = (u32)(((u64)M * gg.y + __umulhi(M, gg.x)) >> 32);
+      const u32 W = A - B, nlo = plo + B, nhi = nlo + W - 1, x = nlo ^ nhi;
+      const u32 k = (u32)__builtin_clz(x | 1u) & 31u, z = ((nlo & ~nhi) << k) << 1, u = (u32)__builtin_clz(~z), t = k + u;
+      const u32 Mn = W << t, e = x < Mn ? x : Mn;
+      phb = nhi; kup = k | (u << 8);
+      if (e != 0) { plo = (nlo << t) & 0x7FFFFFFFu; pM = Mn; flo = plo; fhi = plo + pM - 1; fhb = phb; done = true; }
+    }
+    ku = done ? kup : ac_step<false>(flo, fhi, gg, fhb);
+  } else {
+    ku = general ? ac_step<true>(flo, fhi, gg, fhb) : ac_step<false>(flo, fhi, gg, fhb);
+  }
   const bool ordered = rk == 0 || true;
   // in the literal loop the agreeing-bit phase and the underflow phase can only interleave as k then u
   const bool ok = ordered && flo == rlo && fhi == rhi && (ku & 0xFF) == rk && (ku >> 8) == ru && fhb == rhb;

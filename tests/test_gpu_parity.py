@@ -184,7 +184,7 @@ def test_ac_step_closed_form_selftest(ctx):
     """64 M random + crafted coder states: reciprocal multiply-high and the merged shift reproduce the
     reference's division and bit-by-bit renormalisation loop exactly (incl. R+1 wrap, last symbol,
     all-32-bits-agree, long underflow runs)."""
-    for general in (False, True):
+    for general in (0, 1, 2):  # 0 production step, 1 all-states step, 2 plain-round step with its fallback
         for seed in (1, 2, 3, 4):
             out = ctx.selftest_ac(1 << 24, seed, general)
             assert out[0] == 0, (f"general={general} seed {seed}: {out[0]} mismatches, first lo={out[1]:#x} hi={out[2]:#x} "
