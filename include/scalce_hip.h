@@ -51,6 +51,11 @@ int scalce_patterns_buckets(const scalce_ctx *ctx); /* distinct cores = buckets,
 int scalce_pattern_length(const scalce_ctx *ctx, int pattern);
 const char *scalce_pattern_string(const scalce_ctx *ctx, int pattern);
 
+/* Host-only description of the table builder (runs without a device): bucket_pattern_out[k] = file-order
+ * index of the core whose bucket is emitted k-th (aho_output order, reads.cpp:466-499), root (0x3FFFFFFF) last. */
+int scalce_patterns_describe_host(const void *blob, size_t nbytes, int is_text, int32_t *bucket_pattern_out,
+                                  size_t cap, int32_t *n_states, int32_t *n_buckets);
+
 /* ---- quality model: quality_mapping_init (qualities.cpp:58-175), host only --------------- */
 typedef struct {
   int32_t offset;      /* 33 or 64 */

@@ -123,6 +123,19 @@ extern "C" const char *scalce_pattern_string(const scalce_ctx *c, int p) {
   return (c && p >= 0 && p < (int)c->A.patterns.size()) ? c->A.patterns[p].c_str() : nullptr;
 }
 
+extern "C" int scalce_patterns_describe_host(const void *blob, size_t n, int is_text, int32_t *bucket_pattern_out,
+                                            size_t cap, int32_t *n_states, int32_t *n_buckets) {
+  // host-only view of the table builder (no device needed): emission order of the buckets
+  Automaton A;
+  const bool ok = is_text ? A.load_text(static_cast<const char *>(blob), n) : A.load_bin(blob, n);
+  if (!ok) return SCALCE_ERR_FORMAT;
+  if (n_states) *n_states = A.n_states;
+  if (n_buckets) *n_buckets = A.n_buckets;
+  if (bucket_pattern_out)
+    for (size_t i = 0; i < cap && i < A.bucket_pattern.size(); i++) bucket_pattern_out[i] = A.bucket_pattern[i];
+  return SCALCE_OK;
+}
+
 extern "C" void scalce_params_default(scalce_params *p) {
   std::memset(p, 0, sizeof *p);
   p->use_names = 1;

@@ -1,0 +1,64 @@
+"""-m gpu: the `scalce` command line (C++ host over the C ABI) against the oracle's files, both directions."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import oraclelib as O
+from scalce_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "scalce_amd", "bin", "scalce")
+PBIN = os.path.join(ROOT, "tests", "golden", "patterns.bin")
+
+
+def run_cli(*args):
+    r = subprocess.run([CLI, *map(str, args)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r
+
+
+def maybe_gunzip(path):
+    raw = open(path, "rb").read()
+    return gzip.decompress(raw) if raw[:2] == b"\x1f\x8b" else raw
+
+
+@pytest.mark.parametrize("flags", [[], ["-r"], ["-p", "30"], ["-A"], ["-n", "lib"], ["-c", "gz"], ["-B", "1M"],
+                                   ["-r", "-c", "gz", "-p", "10"]])
+def test_cli_compress_matches_oracle_and_decompress_roundtrips(flags, tmp_path):
+    paired = "-r" in flags
+    n, L = 8000, 100
+    synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=31, n_frac=0.003, dup_frac=0.1,
+                      paired_suffix="/1" if paired else None)
+    if paired:
+        synth.write_fastq(str(tmp_path / "in_2.fq"), n, L, seed=32, paired_suffix="/2")
+    oflags = [("1048576" if f == "1M" else f) for f in flags]
+    cflags = list(flags) if "-c" in flags else list(flags) + ["-c", "no"]
+    run_cli(*cflags, "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc", *oflags)
+    for m in ((1, 2) if paired else (1,)):
+        for ext in "nrq":
+            a = maybe_gunzip(tmp_path / f"orc_{m}.scalce{ext}")
+            h = maybe_gunzip(tmp_path / f"hip_{m}.scalce{ext}")
+            assert a == h, f"{flags} .scalce{ext} mate {m}: {len(h)} vs {len(a)} bytes"
+    dflags = (["-r"] if paired else []) + (["-n", "lib"] if "-n" in flags else [])
+    run_cli("-d", *dflags, "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
+    O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback", *dflags)
+    for m in ((1, 2) if paired else (1,)):
+        assert open(tmp_path / f"back_{m}.fastq", "rb").read() == open(tmp_path / f"oback_{m}.fastq", "rb").read()
+
+
+def test_cli_errors_like_the_reference(tmp_path):
+    synth.write_fastq(str(tmp_path / "in_1.fq"), 100, 50, seed=1)
+    r = subprocess.run([CLI, str(tmp_path / "in_1.fq")], capture_output=True, text=True)
+    assert r.returncode == 1 and "(ERROR) No output file specified." in r.stderr
+    r = subprocess.run([CLI, "-o", "x", str(tmp_path / "nope_1.fq")], capture_output=True, text=True)
+    assert r.returncode == 1 and "does not exist" in r.stderr
+    lines = open(tmp_path / "in_1.fq", "rb").read().split(b"\n")
+    lines[9] = lines[9][:-3]
+    open(tmp_path / "bad_1.fq", "wb").write(b"\n".join(lines))
+    r = subprocess.run([CLI, "-o", str(tmp_path / "o"), str(tmp_path / "bad_1.fq"), "--patterns-bin", PBIN],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "(ERROR)" in r.stderr

@@ -1,0 +1,98 @@
+"""CPU (no GPU): the C-ABI library loads, exports what include/scalce_hip.h declares, refuses to run
+without a device, and its host-side pieces (table builder, quality model) agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oraclelib as O
+from scalce_amd import host, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "scalce_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(scalce_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 30
+    L = host.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_no_device_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(host.ScalceError, match="no CPU path"):
+        host.Context(0)
+
+
+def _describe(blob, is_text):
+    L = host.lib()
+    L.scalce_patterns_describe_host.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    ns, nb = C.c_int32(), C.c_int32()
+    assert L.scalce_patterns_describe_host(blob, len(blob), is_text, None, 0, C.byref(ns), C.byref(nb)) == 0
+    out = np.zeros(nb.value + 1, dtype=np.int32)
+    L.scalce_patterns_describe_host(blob, len(blob), is_text, out.ctypes.data, len(out), C.byref(ns), C.byref(nb))
+    return ns.value, nb.value, out
+
+
+def test_table_builder_matches_reference_bfs_order(patterns_blob):
+    """Bucket emission order of the product's DFA builder == BFS ids of prepare_aho_automata (pinned by the
+    reference objects through tests/golden/*.npz `ids`)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "se100.npz"))
+    ns, nb, order = _describe(patterns_blob, 0)
+    ids = g["ids"]  # BFS id per pattern (file order)
+    assert nb == 15600 and order[-1] == host.ROOT_CORE
+    assert (order[:-1] == np.argsort(ids, kind="stable")).all()
+    trie = O.Trie(blob=patterns_blob)
+    assert ns == trie.n_nodes + 1
+    # text list with nested and duplicated cores
+    g2 = np.load(os.path.join(ROOT, "tests", "golden", "se150_text.npz"))
+    txt = str(g2["ptxt"]).encode()
+    ns2, nb2, order2 = _describe(txt, 1)
+    ids2 = g2["ids"]
+    live = np.flatnonzero(ids2 >= 0)  # a duplicated core keeps only its last index (reads.cpp:264)
+    assert nb2 == len(live)
+    assert (order2[:-1] == live[np.argsort(ids2[live], kind="stable")]).all()
+
+
+def test_table_builder_rejects_garbage():
+    L = host.lib()
+    L.scalce_patterns_describe_host.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t,
+                                                C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    assert L.scalce_patterns_describe_host(b"\x08\x00\xff\xff\xff\x7f", 6, 0, None, 0, None, None) != 0
+    assert L.scalce_patterns_describe_host(b"\x40\x00\x01\x00\x00\x00" + b"\x00" * 16, 22, 0, None, 0, None, None) != 0
+
+
+@pytest.mark.parametrize("lossy", [0, 10, 30, 60, 100])
+def test_quality_model_matches_oracle(lossy):
+    rng = np.random.default_rng(5 + lossy)
+    for shape in ("normal", "bimodal", "phred64", "flat"):
+        if shape == "normal":
+            q = np.clip(np.rint(rng.normal(30, 8, 200000)), 2, 40).astype(int) + 33
+        elif shape == "bimodal":
+            q = np.concatenate([np.clip(np.rint(rng.normal(12, 3, 80000)), 2, 41),
+                                np.clip(np.rint(rng.normal(36, 2, 120000)), 2, 41)]).astype(int) + 33
+        elif shape == "phred64":
+            q = np.clip(np.rint(rng.normal(28, 9, 200000)), 2, 40).astype(int) + 64
+        else:
+            q = rng.integers(35, 75, 200000)
+        stat = np.bincount(q, minlength=128)[:128]
+        off_o, vals_o = O.qmap_init(stat, lossy)
+        off_h, vals_h = host.qmap_init(stat, lossy)
+        assert off_o == off_h and (vals_o == vals_h).all(), (shape, lossy)
+
+
+def test_sample_qmap_reads_like_the_reference():
+    from scalce_amd import format as fmt
+    b, q = synth.reads_and_quals(3000, 50, seed=9)
+    fq = synth.fastq_bytes_fast(b, q)
+    off, vals, L = fmt.sample_qmap(fq, sample=1000, lossy=30)
+    stat = np.bincount(q[:1000].reshape(-1), minlength=128)
+    off_o, vals_o = O.qmap_init(stat, 30)
+    assert L == 50 and off == off_o and (vals == vals_o).all()
