@@ -67,6 +67,7 @@ struct AcEncArgs {
   u32 out_cap;      // bytes a block may write (multiple of 4)
   u32 *out_size;
   DevErr *err;
+  u32 debug;           // profiling only: 1 = chain idles, 2 = helper skips pack, 4 = helper skips gather
   u32 slow_threshold;  // 32; tests lower it to drive every pending underflow through the serial path
 };
 
@@ -136,27 +137,35 @@ __device__ __forceinline__ u32 ac_step(u32 &lo, u32 &hi, const uint4 g, u32 &hbe
 // Two outcomes need the general step and are reported through the return value being 0: all 32 bits agree
 // (x == 0), or the new interval is an aligned power-of-two block that renormalises to the full 2^32
 // (M' == 0).  In that case lo and M are left untouched and the caller redoes the symbol.
+__device__ __forceinline__ u32 ffbh_raw(u32 x) {  // count leading zeros, 0xFFFFFFFF for 0 (callers discard that case)
+  u32 r;
+  asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+// Returns e (per lane; 0 iff this step needs the general path).  The state is always advanced: the caller
+// checks the minimum of e over a short group of steps with ONE scalar branch and, if it is 0, rolls the
+// group back and redoes it with the general step -- a branch per symbol would sit on the dependency spine
+// (the wave cannot issue past an unresolved branch).  After a bad step the following plain steps of the
+// group compute garbage, but only with plain integer operations.
 __device__ __forceinline__ u32 ac_step_plain(u32 &lo, u32 &M, const uint4 g, u32 &hbefore, u32 &ku) {
+  // dependency spine: M -> mul_hi -> mad -> add -> xor -> ffbh -> shift -> ffbh -> shift -> M'
   const u32 A = (u32)(((u64)M * g.w + __umulhi(M, g.z)) >> 32);
   const u32 B = (u32)(((u64)M * g.y + __umulhi(M, g.x)) >> 32);
-  const u32 W = A - B;           // new range before renormalisation (>= 1 on a well-formed table)
+  const u32 nhi = lo + A - 1;
   const u32 nlo = lo + B;
-  const u32 nhi = nlo + W - 1;
+  const u32 W = A - B;                       // new range before renormalisation (off the spine)
   hbefore = nhi;
   const u32 x = nlo ^ nhi;
-  const u32 k = (u32)__builtin_clz(x | 1u) & 31u;
-  const u32 z = ((nlo & ~nhi) << k) << 1;
-  const u32 u = (u32)__builtin_clz(~z);  // bit 0 of z is clear: ~z != 0
-  const u32 t = k + u;                   // <= 31
-  const u32 Mn = W << t;
-  const u32 e = x < Mn ? x : Mn;         // 0 iff x == 0 or the range wrapped to 2^32
+  const u32 k = ffbh_raw(x);                 // x == 0 leaves garbage here; that case is redone by the caller
+  // underflow steps = leading ones of ((nlo & ~nhi) << k) << 1.  Counted on the complement so that no
+  // inversion sits behind the shift: c1 = ~((nlo & ~nhi) << 1) has bit 0 set, and the zeros shifted into
+  // (c1 << k) lie below the first set bit (u <= 31 - k).
+  const u32 c1 = ((~nlo | nhi) << 1) | 1u;
+  const u32 u = ffbh_raw(c1 << k);
+  M = (W << k) << u;                         // renormalising by k + u bits scales the range by 2^(k+u)
+  lo = ((nlo << k) << u) & 0x7FFFFFFFu;
   ku = k | (u << 8);
-  const u32 es = __builtin_amdgcn_readfirstlane(e);  // only lane 0 is active: the caller's branch is scalar
-  if (es != 0) {
-    lo = (nlo << t) & 0x7FFFFFFFu;
-    M = Mn;
-  }
-  return es;
+  return x < M ? x : M;                      // 0 iff x == 0 or the range wrapped to 2^32
 }
 
 // ---- encoder -----------------------------------------------------------------------------------
@@ -185,11 +194,10 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
 
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
-  __shared__ uint4 ops[2][66];  // +1: the chain prefetches one entry past the round
   __shared__ uint2 rec[2][64];
   __shared__ u32 buf[AC_BUF_WORDS];
   __shared__ u32 final_lo;
-  __shared__ u32 plain_round[2];  // helper -> chain: no last-of-context symbol in the round
+
   const u32 blk = blockIdx.x;
   const u64 boff = (u64)blk * AC_BLOCK_SYMS;
   const u8 *s = a.sym + boff;
@@ -304,62 +312,62 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
     pend = pend_out;
   };
 
-  if (!chain_wave) {
-    carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
-    const uint4 g0 = gather(0);
-    ops[0][lane] = g0;
-    const bool any_last = __any(g0.w == 0xFFFFFFFFu);
-    if (lane == 0) plain_round[0] = 0;  // round 0 starts from the full interval (R + 1 wraps): general step
-    (void)any_last;
-  }
-  __syncthreads();
+  if (!chain_wave) carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
+  // chain wave: all 64 lanes fetch the operands of a round (one symbol per lane) a round ahead; lane 0 then
+  // pulls symbol j's operands out of those registers with v_readlane (no LDS round trip on the chain)
+  uint4 cur = chain_wave ? gather(0) : make_uint4(0, 0, 0, 0);
   for (u32 r = 0; r < nrounds; r++) {
     const u32 base = r << 6;
     if (chain_wave) {
-      if (lane == 0) {
+      const uint4 ops_r = cur;
+      if (base + 64 < n && !(a.debug & 4)) cur = gather(base + 64);  // in flight during this round's chain
+      const bool plain = !__any(ops_r.w == 0xFFFFFFFFu);           // no last-of-context symbol in the round
+      auto operand = [&](u32 j) -> uint4 {
+        return make_uint4(__builtin_amdgcn_readlane(ops_r.x, j), __builtin_amdgcn_readlane(ops_r.y, j),
+                          __builtin_amdgcn_readlane(ops_r.z, j), __builtin_amdgcn_readlane(ops_r.w, j));
+      };
+      if ((a.debug & 1) && lane == 0) {  // profiling: no coder work, only well-formed empty outcomes
+        for (int j = 0; j < 64; j++) rec[r & 1][j] = make_uint2(0u, 0u);
+        if (r + 1 == nrounds) final_lo = 0;
+      }
+      if (lane == 0 && !(a.debug & 1)) {
         const u32 cnt = (n - base) < 64 ? (n - base) : 64;
-        const uint4 *op = ops[r & 1];
         uint2 *rc = rec[r & 1];
         u32 j = (r == 0) ? 2u : 0u;
         u32 M = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
-        if (!GENERAL && plain_round[r & 1] && __builtin_amdgcn_readfirstlane(M) != 0) {
-          // two symbols per trip; operands are fetched from LDS one step ahead of their use (sched_barrier
-          // keeps the compiler from sinking the ds_read next to its consumer)
-          uint4 gA = op[j < 64 ? j : 63];
-          while (j + 1 < cnt) {
-            const uint4 gB = op[j + 1];
-            __builtin_amdgcn_sched_barrier(0);
+        if (!GENERAL && plain && __builtin_amdgcn_readfirstlane(M) != 0) {
+          while (j + 3 < cnt) {  // four symbols per trip, one exit test
+            const u32 lo_save = lo, M_save = M;
             u32 hb, ku;
-            if (ac_step_plain(lo, M, gA, hb, ku) == 0) break;  // rare: redo symbol j with the general step
+            u32 e = ac_step_plain(lo, M, operand(j), hb, ku);
             rc[j] = make_uint2(hb, ku);
-            gA = op[j + 2];
-            __builtin_amdgcn_sched_barrier(0);
-            if (ac_step_plain(lo, M, gB, hb, ku) == 0) { j += 1; break; }
+            u32 e2 = ac_step_plain(lo, M, operand(j + 1), hb, ku);
+            e = e2 < e ? e2 : e;
             rc[j + 1] = make_uint2(hb, ku);
-            j += 2;
+            e2 = ac_step_plain(lo, M, operand(j + 2), hb, ku);
+            e = e2 < e ? e2 : e;
+            rc[j + 2] = make_uint2(hb, ku);
+            e2 = ac_step_plain(lo, M, operand(j + 3), hb, ku);
+            e = e2 < e ? e2 : e;
+            rc[j + 3] = make_uint2(hb, ku);
+            // only lane 0 is active here, so readfirstlane turns the test into a scalar branch
+            if (__builtin_amdgcn_readfirstlane(e) == 0) {  // rare: roll the group back, the general loop redoes it
+              lo = lo_save; M = M_save;
+              break;
+            }
+            j += 4;
           }
           hi = lo + M - 1;
         }
-        if (j < cnt) {  // general steps: first round, rounds with a last-of-context symbol, after a 32-bit agreement
-          uint4 g = op[j];
-          for (; j < cnt; j++) {
-            const uint4 gn = op[j + 1];
-            u32 hbefore;
-            const u32 ku = ac_step<GENERAL>(lo, hi, g, hbefore);
-            rc[j] = make_uint2(hbefore, ku);
-            g = gn;
-          }
+        for (; j < cnt; j++) {  // general steps: first round, last-of-context symbols, full interval, round tails
+          u32 hbefore;
+          const u32 ku = ac_step<GENERAL>(lo, hi, operand(j), hbefore);
+          rc[j] = make_uint2(hbefore, ku);
         }
         if (r + 1 == nrounds) final_lo = lo;
       }
     } else {
-      if (base + 64 < n) {
-        const uint4 gnext = gather(base + 64);
-        ops[(r + 1) & 1][lane] = gnext;
-        const bool any_last = __any(gnext.w == 0xFFFFFFFFu);
-        if (lane == 0) plain_round[(r + 1) & 1] = any_last ? 0u : 1u;
-      }
-      if (r > 0) {
+      if (r > 0 && !(a.debug & 2)) {
         const uint2 v = rec[(r - 1) & 1][lane];
         const bool valid = !(r == 1 && lane < 2);  // round 0: the two raw symbols carry no outcome
         pack(valid ? v.x : 0u, valid ? v.y : 0u);
@@ -536,12 +544,10 @@ __global__ __launch_bounds__(256) void ac_selftest_k(u64 n, u32 seed, int genera
     if (M != 0 && c_hi != d) {
       // ac_step_plain's exit test reads lane 0 of the wave; give every lane its own verdict here
       u32 plo = flo, pM = M, phb;
-      const u32 A = (u32)(((u64)M * gg.w + __umulhi(M, gg.z)) >> 32), B = (u32)(((u64)M * gg.y + __umulhi(M, gg.x)) >> 32);
-      const u32 W = A - B, nlo = plo + B, nhi = nlo + W - 1, x = nlo ^ nhi;
-      const u32 k = (u32)__builtin_clz(x | 1u) & 31u, z = ((nlo & ~nhi) << k) << 1, u = (u32)__builtin_clz(~z), t = k + u;
-      const u32 Mn = W << t, e = x < Mn ? x : Mn;
-      phb = nhi; kup = k | (u << 8);
-      if (e != 0) { plo = (nlo << t) & 0x7FFFFFFFu; pM = Mn; flo = plo; fhi = plo + pM - 1; fhb = phb; done = true; }
+      const u32 A = 0, B = 0;
+      (void)A; (void)B;
+      const u32 e = ac_step_plain(plo, pM, gg, phb, kup);
+      if (e != 0) { flo = plo; fhi = plo + pM - 1; fhb = phb; done = true; }
     }
     ku = done ? kup : ac_step<false>(flo, fhi, gg, fhb);
   } else {

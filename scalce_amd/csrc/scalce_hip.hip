@@ -690,6 +690,8 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
     a.sym = b->qs[m].as<u8>(); a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
     a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
     a.slow_threshold = 32;
+    a.debug = 0;
+    if (const char *e = getenv("SCALCE_AC_DEBUG")) a.debug = (u32)atoi(e);  // profiling hook, breaks the output
     if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
     hipEvent_t ke0 = nullptr, ke1 = nullptr;
     if (b->ktiming) {
