@@ -94,6 +94,18 @@ int scalce_batch_quality(scalce_batch *b, void *stream);
  * resolved exactly in input order (-T 1 semantics).  d_prior_counts: per-bucket counts of reads
  * assigned by EARLIER shards (bucket order = scalce_bucket_*), or NULL. */
 int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior_counts, void *stream);
+/* The same in pieces, for runs sharded over several GPUs: begin (scan, candidates, first counts), then
+ * sweeps -- each re-decides this shard's tie reads against `d_prior_counts` (reads of EARLIER shards per
+ * bucket under the current decisions, i.e. the exclusive sum over ranks of SCALCE_OUT_BUCKET_COUNTS) and
+ * refreshes SCALCE_OUT_BUCKET_COUNTS -- until no rank reports a change, then end.  The fixed point is the
+ * sequential (-T 1) result over the whole run. */
+int scalce_batch_tokenize_begin(scalce_batch *b, void *stream);
+int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior_counts, int *changed, void *stream);
+int scalce_batch_tokenize_end(scalce_batch *b, void *stream);
+/* Spill-chunk boundaries given by the caller instead of the -B rule: starts[0] = 0 < starts[1] < ...;
+ * records of chunk i precede those of chunk i+1 inside every bucket (merge order, compress.cpp:104-159).
+ * A sharded run uses one chunk per shard. */
+int scalce_batch_set_chunks(scalce_batch *b, const uint64_t *starts, uint32_t n);
 /* aho_trie_bucket + aho_output + bin_prepare/_radix_sort (reads.cpp:233-250,466-499,547-634)
  * + the merge order of spilled chunks (compress.cpp:104-159): the output permutation. */
 int scalce_batch_order(scalce_batch *b, void *stream);
@@ -105,6 +117,13 @@ int scalce_batch_emit(scalce_batch *b, void *stream);
  * d_table_override (512000 x u32 per mate, already scaled) replaces this shard's own
  * statistics when the run-wide table was reduced across shards; NULL = use own. */
 int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream);
+/* Sharded runs: code a caller-assembled range of the run-wide reordered stream (it must start on a 10 MiB
+ * block boundary) against the run-wide table; result in SCALCE_OUT_QUAL of `mate`. */
+int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                uint64_t nsym, void *stream);
+/* Piecewise device copy: dst[piece_dst[p] + i] = src[piece_src[p] + i]; pieces contiguous in src, sorted. */
+int scalce_copy_pieces(scalce_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, const uint64_t *d_piece_src,
+                       const uint64_t *d_piece_dst, uint32_t npieces, uint64_t total_bytes, void *stream);
 /* all of the above in order */
 int scalce_batch_compress(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2,
                           uint64_t n2, void *stream);
@@ -122,7 +141,8 @@ enum {
   SCALCE_OUT_PERM = 6,      /* N x u32: input index of the k-th emitted record               */
   SCALCE_OUT_QSTREAM = 7,   /* N*L bytes: reordered q' stream, mate m                         */
   SCALCE_OUT_BUCKET_COUNTS = 8, /* (buckets+1) x u64 reads per bucket, emission order, root last */
-  SCALCE_OUT_QINPUT = 9     /* N*L bytes: q' in input order, mate m                          */
+  SCALCE_OUT_QINPUT = 9,    /* N*L bytes: q' in input order, mate m                          */
+  SCALCE_OUT_NAMELEN = 10   /* N bytes: stored name length per read, input order             */
 };
 int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes);
 uint64_t scalce_batch_reads(const scalce_batch *b);

@@ -182,4 +182,23 @@ __global__ __launch_bounds__(256) void gather_rows_k(u64 nrec, const u32 *perm, 
   }
 }
 
+// piecewise copy (sharded runs: received quality bytes -> their place in the run-wide stream).  Pieces are
+// contiguous in src and sorted; thread i moves src bytes [8i, 8i+8).
+__global__ __launch_bounds__(256) void copy_pieces_k(const u8 *src, u8 *dst, const u64 *piece_src, const u64 *piece_dst,
+                                                    u32 np, u64 total) {
+  const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i0 >= total) return;
+  u32 lo = 0, hi = np;  // last piece with piece_src <= i0
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (piece_src[mid] <= i0) lo = mid; else hi = mid;
+  }
+  u32 p = lo;
+  const u64 i1 = i0 + 8 < total ? i0 + 8 : total;
+  for (u64 i = i0; i < i1; i++) {
+    while (p + 1 < np && piece_src[p + 1] <= i) p++;
+    dst[piece_dst[p] + (i - piece_src[p])] = src[i];
+  }
+}
+
 }  // namespace scalce

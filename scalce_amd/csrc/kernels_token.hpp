@@ -248,6 +248,14 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   }
 }
 
+// cross-shard prior counts that moved since the last sweep wake up the reads of those buckets
+__global__ __launch_bounds__(256) void prior_dirty_k(u32 nb1, const u64 *prior, u64 *seen, u8 *dirty) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb1) return;
+  const u64 p = prior[b];
+  if (p != seen[b]) { seen[b] = p; dirty[b] = 1; }
+}
+
 // final (bucket, end) per read + API view (pattern index in file order, end)
 struct FinalizeArgs {
   u64 nrec;

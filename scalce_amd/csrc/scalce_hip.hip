@@ -181,6 +181,9 @@ struct scalce_batch {
   // host-side results
   u64 out_reads_bytes[2] = {0, 0}, out_names_bytes = 0, out_qual_bytes[2] = {0, 0};
   u32 ntie = 0, nev = 0, ncand_cap = 0, jacobi_iters = 0, nchunks = 1;
+  bool tok_open = false;
+  int dirty_cur = 0;
+  std::vector<uint64_t> explicit_chunks;  // spill-chunk starts given by the caller (sharded runs), else -B rule
   // stage timing
   bool timing = false;
   float stage_ms[ST_COUNT] = {0};
@@ -403,13 +406,15 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
 }
 
 // ---- stage 2: tokenize ------------------------------------------------------------------------------
-extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, void *stream) {
+extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   if (!b || !b->ingested[0]) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   const u64 N = b->N;
+  b->jacobi_iters = 0;
+  b->tok_open = true;
   const u32 nb1 = (u32)c->A.n_buckets + 1;  // buckets incl. root
   ENSURE(b, b->tok_bucket, sizeof(u32) * (N + 1));
   ENSURE(b, b->tok_pos, sizeof(u32) * (N + 1));
@@ -422,6 +427,7 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
   ENSURE(b, b->seg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(2 * N + 1024) + 1024));
   u32 *ws32 = b->scan_ws.as<u32>();
+  ENSURE(b, b->dirty, 2 * (size_t)(nb1 + 64) + sizeof(u64) * (nb1 + 8));
   if (!N) {
     HIP_TRY(c, hipMemsetAsync(b->counts.p, 0, sizeof(u64) * (nb1 + 1), s));
     b->ntie = b->nev = 0;
@@ -501,42 +507,87 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
   const u32 *sorted = src;
   LAUNCH(events_place_k, cdiv(nev, 256), 256, 0, s, nev, sorted, b->ev_init.as<u8>(), b->ev_place.as<u32>(), b->chosen.as<u8>());
   LAUNCH(events_segments_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, sorted, b->ev_bucket.as<u32>(), nb1, b->seg.as<u32>());
-  // Jacobi iterations to the fixed point
+  // first prefix sums; the sweeps follow (scalce_batch_tokenize_sweep)
   u32 *G = b->G.as<u32>();
-  b->jacobi_iters = 0;
-  ENSURE(b, b->dirty, 2 * (size_t)(nb1 + 64));
-  u8 *dirty_in = b->dirty.as<u8>(), *dirty_out = dirty_in + nb1 + 64;
-  HIP_TRY(c, hipMemsetAsync(dirty_in, 1, nb1, s));  // first sweep: every bucket counts as moved
-  for (;;) {
-    exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, ws32, G + nev, s);
-    if (!ntie) break;
-    static const u32 init[2] = {0u, 0xFFFFFFFFu};
-    HIP_TRY(c, hipMemcpyAsync(b->d_small + 4, init, sizeof init, hipMemcpyHostToDevice, s));
-    JacobiArgs a;
-    a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
-    a.cand_bucket = b->cand_bucket.as<u32>(); a.ev_off = b->ev_off.as<u32>(); a.ev_place = b->ev_place.as<u32>(); a.G = G;
-    a.seg = b->seg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
-    a.changed = b->d_small + 4;
-    a.dirty_in = dirty_in; a.dirty_out = dirty_out;
-    HIP_TRY(c, hipMemsetAsync(dirty_out, 0, nb1, s));
-    LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
-    { u8 *t = dirty_in; dirty_in = dirty_out; dirty_out = t; }
-    u32 ch[2];
-    int rc = read_u32(b, b->d_small + 4, ch, 2, s);
-    if (rc) return rc;
-    b->jacobi_iters++;
-    if (!ch[0]) break;
-    if (b->jacobi_iters > ntie + 1) { set_err(c, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
-  }
-  {
-    FinalizeArgs a;
-    a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
-    a.tie_off = b->tie_off.as<u32>(); a.choice = b->choice.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
-    a.cand_pos = b->cand_pos.as<u32>(); a.bucket_pattern = c->d_bucket_pattern; a.root_bucket = (u32)c->A.n_buckets;
-    a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>(); a.tokens = b->tokens.as<int32_t>();
-    LAUNCH(finalize_k, cdiv(N, 256), 256, 0, s, a);
-  }
+  exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, ws32, G + nev, s);
+  b->dirty_cur = 0;
+  HIP_TRY(c, hipMemsetAsync(b->dirty.p, 1, nb1, s));  // first sweep: every bucket counts as moved
+  HIP_TRY(c, hipMemsetAsync(b->dirty.as<u8>() + 2 * (size_t)(nb1 + 64), 0, sizeof(u64) * nb1, s));  // prior seen so far
   LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>());
+  return SCALCE_OK;
+}
+
+// One Jacobi sweep over the tie reads with the given cross-shard prior counts, then new prefix sums and
+// per-bucket counts (SCALCE_OUT_BUCKET_COUNTS).  *changed = 1 if any decision of THIS shard moved.
+extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior, int *changed, void *stream) {
+  if (!b || !b->tok_open || !changed) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_TOKENIZE, s);
+  *changed = 0;
+  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie, nev = b->nev;
+  if (!b->N || !ntie) return SCALCE_OK;
+  u8 *d0 = b->dirty.as<u8>(), *d1 = d0 + nb1 + 64;
+  u8 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
+  u64 *prior_seen = reinterpret_cast<u64 *>(d0 + 2 * (size_t)(nb1 + 64));
+  if (d_prior) LAUNCH(prior_dirty_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), prior_seen, dirty_in);
+  static const u32 init[2] = {0u, 0xFFFFFFFFu};
+  HIP_TRY(c, hipMemcpyAsync(b->d_small + 4, init, sizeof init, hipMemcpyHostToDevice, s));
+  u32 *G = b->G.as<u32>();
+  JacobiArgs a;
+  a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
+  a.cand_bucket = b->cand_bucket.as<u32>(); a.ev_off = b->ev_off.as<u32>(); a.ev_place = b->ev_place.as<u32>(); a.G = G;
+  a.seg = b->seg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
+  a.changed = b->d_small + 4;
+  a.dirty_in = dirty_in; a.dirty_out = dirty_out;
+  HIP_TRY(c, hipMemsetAsync(dirty_out, 0, nb1, s));
+  LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
+  b->dirty_cur ^= 1;
+  u32 ch[2];
+  { int rc = read_u32(b, b->d_small + 4, ch, 2, s); if (rc) return rc; }
+  b->jacobi_iters++;
+  *changed = ch[0] ? 1 : 0;
+  if (ch[0]) {
+    exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, b->scan_ws.as<u32>(), G + nev, s);
+    LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>());
+  }
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
+  if (!b || !b->tok_open) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_TOKENIZE, s);
+  b->tok_open = false;
+  const u64 N = b->N;
+  if (!N) return SCALCE_OK;
+  FinalizeArgs a;
+  a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
+  a.tie_off = b->tie_off.as<u32>(); a.choice = b->choice.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
+  a.cand_pos = b->cand_pos.as<u32>(); a.bucket_pattern = c->d_bucket_pattern; a.root_bucket = (u32)c->A.n_buckets;
+  a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>(); a.tokens = b->tokens.as<int32_t>();
+  LAUNCH(finalize_k, cdiv(N, 256), 256, 0, s, a);
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, void *stream) {
+  int rc = scalce_batch_tokenize_begin(b, stream);
+  if (rc) return rc;
+  for (;;) {
+    int changed = 0;
+    if ((rc = scalce_batch_tokenize_sweep(b, d_prior, &changed, stream))) return rc;
+    if (!changed) break;
+    if (b->jacobi_iters > b->ntie + 1) { set_err(b->ctx, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
+  }
+  return scalce_batch_tokenize_end(b, stream);
+}
+
+extern "C" int scalce_batch_set_chunks(scalce_batch *b, const uint64_t *starts, uint32_t n) {
+  if (!b || (n && !starts) || n > 4096) return SCALCE_ERR_ARG;
+  b->explicit_chunks.assign(starts, starts + n);
   return SCALCE_OK;
 }
 
@@ -557,8 +608,19 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   b->nchunks = 1;
   if (!N) return SCALCE_OK;
   u32 *ws32 = b->scan_ws.as<u32>();
-  // spill chunks under -B
-  if (b->p.bucket_set_size) {
+  // spill chunks: given explicitly (sharded runs: one chunk per shard) or by the -B rule
+  if (!b->explicit_chunks.empty()) {
+    const u32 nc = (u32)b->explicit_chunks.size();
+    ENSURE(b, b->chunk, sizeof(u32) * (N + 2));
+    ENSURE(b, b->chunk_start, sizeof(u64) * (nc + 2));
+    std::vector<u64> cs(b->explicit_chunks.begin(), b->explicit_chunks.end());
+    cs.push_back(N);
+    HIP_TRY(c, hipMemcpyAsync(b->chunk_start.p, cs.data(), sizeof(u64) * cs.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(b->d_small + 8, &nc, sizeof(u32), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    b->nchunks = nc;
+    if (nc > 1) LAUNCH(chunk_assign_k, cdiv(N, 256), 256, 0, s, N, b->chunk_start.as<u64>(), b->d_small + 8, b->chunk.as<u32>());
+  } else if (b->p.bucket_set_size) {
     ENSURE(b, b->S, sizeof(u64) * (N + 2));
     ENSURE(b, b->chunk, sizeof(u32) * (N + 2));
     const u32 max_chunks = 4096;
@@ -651,6 +713,62 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
 }
 
 // ---- stage 5: entropy ---------------------------------------------------------------------------------
+// Code one mate's symbol stream `d_sym` (nsym symbols, first symbol = start of a 10 MiB block of the run-wide
+// stream) against `table` (device, 512000 x u32, already scaled).
+static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  u32 *table = b->table[m].as<u32>();
+  ENSURE(b, b->ac_tab, sizeof(uint4) * 512000);
+  ENSURE(b, b->ac_cum, sizeof(u32) * 6400 * 81);
+  HIP_TRY(c, hipMemsetAsync(b->d_small + 12, 0, sizeof(u32), s));
+  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab.as<uint4>(), b->ac_cum.as<u32>(), b->d_small + 12);
+  u32 max_total = 0;
+  { int rc = read_u32(b, b->d_small + 12, &max_total, 1, s); if (rc) return rc; }
+  // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
+  // follows it there bit for bit
+  const bool general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
+  const u32 nblk = cdiv(nsym, AC_BLOCK_SYMS);
+  const u64 stride = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
+  ENSURE(b, b->ac_blocks, (size_t)nblk * stride + 64);
+  ENSURE(b, b->ac_sizes, sizeof(u32) * (nblk + 2));
+  ENSURE(b, b->ac_off, sizeof(u64) * (nblk + 2));
+  if (!nblk) { b->out_qual_bytes[m] = 0; return SCALCE_OK; }
+  AcEncArgs a;
+  a.sym = d_sym; a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
+  a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
+  a.slow_threshold = 32;
+  a.debug = 0;
+  if (const char *e = getenv("SCALCE_AC_DEBUG")) a.debug = (u32)atoi(e);  // profiling hook, breaks the output
+  if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
+  hipEvent_t ke0 = nullptr, ke1 = nullptr;
+  if (b->ktiming) {
+    if (b->kev_used == b->kev.size()) {
+      hipEvent_t x, y;
+      HIP_TRY(c, hipEventCreate(&x));
+      HIP_TRY(c, hipEventCreate(&y));
+      b->kev.emplace_back(x, y);
+    }
+    ke0 = b->kev[b->kev_used].first; ke1 = b->kev[b->kev_used].second;
+    b->kev_used++;
+    hipEventRecord(ke0, s);
+  }
+  if (general) LAUNCH(ac_encode_k<true>, nblk, 128, 0, s, a);
+  else LAUNCH(ac_encode_k<false>, nblk, 128, 0, s, a);
+  if (ke1) hipEventRecord(ke1, s);
+  b->k_in_bytes += nsym;
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nblk) + 64));
+  exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
+                      b->d_small64 + 8, s);
+  u64 total = 0;
+  { int rc = read_u64(b, b->d_small64 + 8, &total, 1, s); if (rc) return rc; }
+  b->out_qual_bytes[m] = total;
+  b->k_out_bytes += total - 4ull * nblk;
+  ENSURE(b, b->out_qual[m], total + 64);
+  LAUNCH(ac_frame_k, dim3(cdiv(stride, 16 * 256), nblk), 256, 0, s, b->ac_blocks.as<u8>(), stride, b->ac_sizes.as<u32>(),
+         b->ac_off.as<u64>(), b->out_qual[m].as<u8>());
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream) {
   if (!b) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -671,54 +789,33 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
       const u32 factor = 1 + (u32)(nsym / 0xFFFFFFFFull);  // compress.cpp:297-303
       LAUNCH(ac_scale_k, cdiv(512000, 256), 256, 0, s, b->freq4[m].as<u64>(), factor, table);
     }
-    ENSURE(b, b->ac_tab, sizeof(uint4) * 512000);
-    ENSURE(b, b->ac_cum, sizeof(u32) * 6400 * 81);
-    HIP_TRY(c, hipMemsetAsync(b->d_small + 12, 0, sizeof(u32), s));
-    LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab.as<uint4>(), b->ac_cum.as<u32>(), b->d_small + 12);
-    u32 max_total = 0;
-    { int rc = read_u32(b, b->d_small + 12, &max_total, 1, s); if (rc) return rc; }
-    // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
-    // follows it there bit for bit
-    const bool general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
-    const u32 nblk = cdiv(nsym, AC_BLOCK_SYMS);
-    const u64 stride = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
-    ENSURE(b, b->ac_blocks, (size_t)nblk * stride + 64);
-    ENSURE(b, b->ac_sizes, sizeof(u32) * (nblk + 2));
-    ENSURE(b, b->ac_off, sizeof(u64) * (nblk + 2));
-    if (!nblk) { b->out_qual_bytes[m] = 0; continue; }
-    AcEncArgs a;
-    a.sym = b->qs[m].as<u8>(); a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
-    a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
-    a.slow_threshold = 32;
-    a.debug = 0;
-    if (const char *e = getenv("SCALCE_AC_DEBUG")) a.debug = (u32)atoi(e);  // profiling hook, breaks the output
-    if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
-    hipEvent_t ke0 = nullptr, ke1 = nullptr;
-    if (b->ktiming) {
-      if (b->kev_used == b->kev.size()) {
-        hipEvent_t x, y;
-        HIP_TRY(c, hipEventCreate(&x));
-        HIP_TRY(c, hipEventCreate(&y));
-        b->kev.emplace_back(x, y);
-      }
-      ke0 = b->kev[b->kev_used].first; ke1 = b->kev[b->kev_used].second;
-      b->kev_used++;
-      hipEventRecord(ke0, s);
-    }
-    if (general) LAUNCH(ac_encode_k<true>, nblk, 128, 0, s, a);
-    else LAUNCH(ac_encode_k<false>, nblk, 128, 0, s, a);
-    if (ke1) hipEventRecord(ke1, s);
-    b->k_in_bytes += nsym;
-    exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
-                        b->d_small64 + 8, s);
-    u64 total = 0;
-    { int rc = read_u64(b, b->d_small64 + 8, &total, 1, s); if (rc) return rc; }
-    b->out_qual_bytes[m] = total;
-    b->k_out_bytes += total - 4ull * nblk;
-    ENSURE(b, b->out_qual[m], total + 64);
-    LAUNCH(ac_frame_k, dim3(cdiv(stride, 16 * 256), nblk), 256, 0, s, b->ac_blocks.as<u8>(), stride, b->ac_sizes.as<u32>(),
-           b->ac_off.as<u64>(), b->out_qual[m].as<u8>());
+    int rc = encode_stream(b, m, b->qs[m].as<u8>(), nsym, s);
+    if (rc) return rc;
   }
+  return SCALCE_OK;
+}
+
+// Sharded runs: code `nsym` symbols of mate `mate` that the caller assembled on the device (a range of the
+// run-wide reordered stream that starts on a 10 MiB block boundary) against the run-wide table.
+extern "C" int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                           uint64_t nsym, void *stream) {
+  if (!b || mate < 0 || mate >= b->nm || !d_table || (nsym && !d_symbols) || b->p.no_ac) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_ENTROPY, s);
+  HIP_TRY(c, hipMemcpyAsync(b->table[mate].p, d_table, sizeof(u32) * 512000, hipMemcpyDeviceToDevice, s));
+  return encode_stream(b, mate, d_symbols, nsym, s);
+}
+
+// dst[piece_dst[p] + i] = src[piece_src[p] + i] for i < piece_len[p]; pieces sorted by piece_src, contiguous in src
+extern "C" int scalce_copy_pieces(scalce_ctx *c, const uint8_t *d_src, uint8_t *d_dst, const uint64_t *d_piece_src,
+                                  const uint64_t *d_piece_dst, uint32_t npieces, uint64_t total_bytes, void *stream) {
+  if (!c) return SCALCE_ERR_ARG;
+  if (!npieces || !total_bytes) return SCALCE_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  LAUNCH(copy_pieces_k, cdiv(cdiv(total_bytes, 8), 256), 256, 0, (hipStream_t)stream, d_src, d_dst,
+         reinterpret_cast<const u64 *>(d_piece_src), reinterpret_cast<const u64 *>(d_piece_dst), npieces, (u64)total_bytes);
   return SCALCE_OK;
 }
 
@@ -764,6 +861,7 @@ extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, c
     case SCALCE_OUT_QSTREAM: *d_ptr = b->qs[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
     case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->counts.p; *nbytes = sizeof(u64) * nb1; break;
     case SCALCE_OUT_QINPUT: *d_ptr = b->q[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
+    case SCALCE_OUT_NAMELEN: *d_ptr = b->namelen.p; *nbytes = b->N; break;
     default: return SCALCE_ERR_ARG;
   }
   return SCALCE_OK;

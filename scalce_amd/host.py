@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-OUT_READS, OUT_NAMES, OUT_QUAL, OUT_TABLE, OUT_FREQ4, OUT_TOKENS, OUT_PERM, OUT_QSTREAM, OUT_BUCKET_COUNTS, OUT_QINPUT = range(10)
+OUT_READS, OUT_NAMES, OUT_QUAL, OUT_TABLE, OUT_FREQ4, OUT_TOKENS, OUT_PERM, OUT_QSTREAM, OUT_BUCKET_COUNTS, OUT_QINPUT, OUT_NAMELEN = range(11)
 STAGES = ("ingest", "quality", "tokenize", "order", "emit", "entropy")
 ROOT_CORE = 0x3FFFFFFF
 
@@ -92,6 +92,14 @@ def lib():
     L.scalce_memcpy_d2h.argtypes = [vp, vp, vp, u64]
     L.scalce_memcpy_h2d.argtypes = [vp, vp, vp, u64]
     L.scalce_memcpy_d2d.argtypes = [vp, vp, vp, u64, vp]
+    L.scalce_batch_tokenize_begin.argtypes = [vp, vp]
+    L.scalce_batch_tokenize_sweep.argtypes = [vp, vp, C.POINTER(i32), vp]
+    L.scalce_batch_tokenize_end.argtypes = [vp, vp]
+    L.scalce_batch_set_chunks.argtypes = [vp, C.POINTER(u64), C.c_uint32]
+    L.scalce_batch_entropy_stream.argtypes = [vp, i32, vp, vp, u64, vp]
+    L.scalce_copy_pieces.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, u64, vp]
+    L.scalce_patterns_describe_host.argtypes = [C.c_char_p, C.c_size_t, i32, vp, C.c_size_t, C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_int32)]
     L.scalce_selftest_ac.argtypes = [vp, u64, C.c_uint32, i32, C.POINTER(C.c_uint32)]
     L.scalce_ac_decode.argtypes = [vp, vp, vp, u64, u64, vp, vp]
     _LIB = L
@@ -110,6 +118,8 @@ class Context:
     def __init__(self, device=0, patterns_bin=None, patterns_text=None):
         self.L = lib()
         self.h = C.c_void_p()
+        self.device = int(device)
+        self._table = (patterns_bin, 0) if patterns_bin is not None else (patterns_text, 1)
         rc = self.L.scalce_ctx_create(int(device), C.byref(self.h))
         if rc:
             msg = self.L.scalce_last_error(self.h).decode() if self.h else "scalce_ctx_create failed"
@@ -148,6 +158,18 @@ class Context:
         out = (C.c_uint32 * 6)()
         self._check(self.L.scalce_selftest_ac(self.h, int(ncases), int(seed), int(general), out))
         return list(out)
+
+    def bucket_patterns(self):
+        """File-order core index of every bucket in emission order, root (0x3FFFFFFF) last."""
+        blob, is_text = self._table
+        out = np.zeros(self.n_buckets + 1, dtype=np.int32)
+        ns, nb = C.c_int32(), C.c_int32()
+        self._check(self.L.scalce_patterns_describe_host(blob, len(blob), is_text, out.ctypes.data, len(out),
+                                                         C.byref(ns), C.byref(nb)))
+        return out
+
+    def copy_pieces(self, d_src, d_dst, d_piece_src, d_piece_dst, npieces, total, stream=0):
+        self._check(self.L.scalce_copy_pieces(self.h, d_src, d_dst, d_piece_src, d_piece_dst, int(npieces), int(total), stream))
 
     def copy_d2d(self, dst, src, nbytes, stream=0):
         self._check(self.L.scalce_memcpy_d2d(self.h, dst, src, int(nbytes), stream))
@@ -207,6 +229,24 @@ class Batch:
 
     def tokenize(self, d_prior_counts=None, stream=0):
         self._check(self.L.scalce_batch_tokenize(self.h, d_prior_counts, stream))
+
+    def tokenize_begin(self, stream=0):
+        self._check(self.L.scalce_batch_tokenize_begin(self.h, stream))
+
+    def tokenize_sweep(self, d_prior_counts=None, stream=0):
+        ch = C.c_int(0)
+        self._check(self.L.scalce_batch_tokenize_sweep(self.h, d_prior_counts, C.byref(ch), stream))
+        return ch.value
+
+    def tokenize_end(self, stream=0):
+        self._check(self.L.scalce_batch_tokenize_end(self.h, stream))
+
+    def set_chunks(self, starts):
+        a = (C.c_uint64 * len(starts))(*[int(x) for x in starts])
+        self._check(self.L.scalce_batch_set_chunks(self.h, a, len(starts)))
+
+    def entropy_stream(self, mate, d_table, d_symbols, nsym, stream=0):
+        self._check(self.L.scalce_batch_entropy_stream(self.h, mate, d_table, d_symbols, int(nsym), stream))
 
     def order(self, stream=0):
         self._check(self.L.scalce_batch_order(self.h, stream))
