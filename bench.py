@@ -4,7 +4,8 @@
 A step = one pass of the whole hot path (ingest -> quality statistics -> tokenize with exact tie-break
 -> bucket/reorder -> emit -> arithmetic coder) over one synthetic shard that is already resident in HBM.
 N = 1 runs BASELINE.json configs[1]: 50 M x 100 bp single-end, arithmetic-coded qualities.  N > 1 is weak
-scaling: every rank holds a shard of the same size (one process per GPU, torch.distributed / RCCL).
+scaling: every rank holds a shard of the same size (one process per GPU, torch.distributed / RCCL) and the
+ranks produce ONE archive (scalce_amd/dist.py: run-wide tie-break, quality model and block cutting).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (ac_encode_k): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
@@ -39,6 +40,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from scalce_amd import dist as sdist
     from scalce_amd import host, synth_gpu
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,8 +48,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL over xGMI on a real node; SCALCE_DIST_BACKEND=gloo rehearses the same code on fewer GPUs
+        dist.init_process_group(os.environ.get("SCALCE_DIST_BACKEND", "nccl"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -65,6 +69,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     state = {}
+    comm = sdist.TorchComm() if world > 1 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -76,7 +81,7 @@ def main():
         if world == 1:
             batch.compress(text.data_ptr(), nbytes, None, 0, stream)
         else:
-            sharded_step(batch, ctx, text, nbytes, stream, dist, dev, n * L * world, state)
+            state["res"] = sdist.compress_shard(comm, ctx, batch, text.data_ptr(), nbytes, stream=stream)
         batch.finish(stream)
 
     for _ in range(args.warmup):
@@ -129,7 +134,7 @@ def main():
             "config": {"workload": f"{n} x {L} bp single-end synthetic FASTQ per GPU, arithmetic-coded qualities "
                                    "(BASELINE.json configs[1])", "reads_per_gpu": n, "read_length": L,
                        "input_bytes_per_gpu": nbytes, "output_bytes_per_gpu": int(out_bytes),
-                       "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}",
+                       "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if world == 1 else ": read ranges per rank, run-wide tie-break / quality model / 10 MiB blocks (RCCL all-gather, all-reduce, all-to-all)"),
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"]},
             "roofline": {"bound": "hbm", "kernel": "ac_encode_k", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
@@ -140,52 +145,6 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
-
-
-def sharded_step(batch, ctx, text, nbytes, stream, dist, dev, total_symbols, state):
-    """One step of the N > 1 path (DESIGN.md "Multi-GPU"): read ranges are sharded over ranks; the quality
-    model is run-wide -- the 80^3 trigram counters are summed with an RCCL all-reduce (plus the two
-    cross-shard trigrams per shard boundary), as are the per-core bucket counts; tokenisation, order and
-    coding then run per shard against the shared table."""
-    import torch
-    from scalce_amd import host
-    batch.ingest(0, text.data_ptr(), nbytes, stream)
-    batch.quality(stream)
-    if "f4" not in state:
-        state["f4"] = torch.empty(512000, dtype=torch.int64, device=dev)
-        state["edge"] = torch.empty(4, dtype=torch.int64, device=dev)
-    f4 = state["f4"]
-    p, nb = batch.output_ptr(host.OUT_FREQ4, 0)
-    ctx.copy_d2d(f4.data_ptr(), p, nb, stream)
-    dist.all_reduce(f4, op=dist.ReduceOp.SUM)
-    # shard-boundary trigrams: (a, b | c) and (b | c, d) with a,b the last symbols of the previous shard
-    qp, qn = batch.output_ptr(host.OUT_QINPUT, 0)
-    q = state["edge"]
-    qb = torch.empty(4, dtype=torch.uint8, device=dev)
-    ctx.copy_d2d(qb.data_ptr(), qp, 2, stream)
-    ctx.copy_d2d(qb.data_ptr() + 2, qp + qn - 2, 2, stream)
-    torch.cuda.synchronize()
-    world = dist.get_world_size()
-    edges = [torch.empty(4, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(edges, qb)
-    e = torch.stack(edges).cpu().numpy().astype("int64")
-    for r in range(1, world):
-        a, b = e[r - 1][2], e[r - 1][3]
-        c, d = e[r][0], e[r][1]
-        f4[(a * 80 + b) * 80 + c] += 1
-        f4[(b * 80 + c) * 80 + d] += 1
-    factor = 1 + total_symbols // 0xFFFFFFFF
-    table = torch.clamp_min((f4 + 1) // factor, 1).to(torch.int32)  # same bits as u32
-    state["table"] = table
-    batch.tokenize(None, stream)
-    cp, cn = batch.output_ptr(host.OUT_BUCKET_COUNTS, 0)
-    if "counts" not in state:
-        state["counts"] = torch.empty(cn // 8, dtype=torch.int64, device=dev)
-    ctx.copy_d2d(state["counts"].data_ptr(), cp, cn, stream)
-    dist.all_reduce(state["counts"], op=dist.ReduceOp.SUM)  # run-wide reads per core bucket
-    batch.order(stream)
-    batch.emit(stream)
-    batch.entropy(table.data_ptr(), stream)
 
 
 def cpu_baseline(text, n, L, sample):
