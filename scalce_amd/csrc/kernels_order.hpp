@@ -123,24 +123,34 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     for (int i = 0; i < 8; i++) dst[4 + i] = (u8)(cnt >> (8 * i));
   }
   dst += 12 + (k - first) * (u64)recsz;
-  // output_read(line, dest, n = e - lv, l = lv): bases [e, L) then [0, e - lv)
-  const u8 *row = a.packed + (u64)r * a.stride;
+  // output_read(line, dest, n = e - lv, l = lv): bases [e, L) then [0, e - lv).  Done on 32-bit big-endian
+  // words of the packed row: output word j = up to two bit-field fetches (funnel shifts) instead of 16
+  // single-base extractions.
+  const u32 *roww = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
+  const int nwords = a.stride >> 2;
+  auto S = [&](int i) -> u32 { return i < nwords ? __builtin_bswap32(roww[i]) : 0u; };
+  auto bits32 = [&](int pos) -> u32 {  // 32 source bits starting at bit `pos` (MSB first)
+    const int w = pos >> 5, sh = pos & 31;
+    const u32 w0 = S(w);
+    if (!sh) return w0;
+    return (w0 << sh) | (S(w + 1) >> (32 - sh));
+  };
   const int n = e ? e - lv : 0;
-  const int tail = a.L - e;       // bases after the core
-  const int total = tail + n;     // == L - lv when a core exists, L otherwise
+  const int A = 2 * (a.L - e);        // bits of the part after the core
+  const int T = A + 2 * n;            // bits of the record (2 * (L - lv) with a core, 2 * L without)
+  const int nbytes = (T + 7) >> 3;
   int j = 0;
-  for (int o = 0; o < total; o += 4) {
-    u32 byte = 0;
-    for (int t = 0; t < 4; t++) {
-      const int q = o + t;
-      u32 c = 0;
-      if (q < total) {
-        const int src = q < tail ? e + q : q - tail;
-        c = base_at(row, src);
-      }
-      byte = (byte << 2) | c;
-    }
-    dst[j++] = (u8)byte;
+  for (int p0 = 0; p0 < T; p0 += 32) {
+    int n1 = A - p0;
+    n1 = n1 < 0 ? 0 : (n1 > 32 ? 32 : n1);
+    u32 word = 0;
+    if (n1) word = bits32(2 * e + p0) & (0xFFFFFFFFu << (32 - n1));
+    if (n1 < 32) word |= bits32(p0 + n1 - A) >> n1;
+    const int left = T - p0;          // record bits from this word on
+    if (left < 32) word &= 0xFFFFFFFFu << (32 - left);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+      if (j < nbytes) dst[j++] = (u8)(word >> (24 - 8 * t));
   }
   dst[j] = (u8)e;  // end marker, reads.cpp:130
   if (a.sz_meta == 2) dst[j + 1] = (u8)(e >> 8);

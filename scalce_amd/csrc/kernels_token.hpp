@@ -202,35 +202,45 @@ __global__ __launch_bounds__(256) void events_segments_k(u32 nev, const u32 *sor
   }
 }
 
+// position of every candidate in the sorted event array, in CSR order (read once per sweep, coalesced)
+__global__ __launch_bounds__(256) void tie_place_k(u32 ntie, const u32 *tie_read, const u32 *tie_off, const u32 *tie_ncand,
+                                                  const u32 *ev_off, const u32 *ev_place, u32 *cand_place) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntie) return;
+  const u32 off = tie_off[t], k = tie_ncand[t], e0 = ev_off[tie_read[t]];
+  for (u32 j = 0; j < k; j++) cand_place[off + j] = ev_place[e0 + j];
+}
+
 struct JacobiArgs {
   u32 ntie;
   const u32 *tie_read, *tie_off, *tie_ncand, *cand_bucket;
-  const u32 *ev_off, *ev_place;
+  const u32 *cand_place;  // sorted-event position of every candidate (CSR order)
   const u32 *G;         // exclusive prefix of `chosen` over the sorted events (G[nev] = total)
-  const u32 *seg;
+  const u32 *Gseg;      // G at the start of every bucket's segment (small, cache resident)
   const u64 *prior;     // reads already in each bucket before this shard, or null
   u32 *choice;          // tie index -> chosen candidate ordinal
   u8 *chosen;
-  u32 *changed;         // [0] any change, [1] lowest tie index that changed
-  const u8 *dirty_in;   // per bucket: did a read of this bucket change its choice in the previous sweep?
-  u8 *dirty_out;        // ... in this sweep (cleared by the host before the launch)
+  u32 *changed;         // [0] any change
+  // per bucket: the first read that a choice change of the previous sweep can affect (= changed read + 1;
+  // 0 = all, 0xFFFFFFFF = none).  A decision only depends on counts BEFORE its read, so later changes cannot move it.
+  const u32 *dirty_in;
+  u32 *dirty_out;       // ... in this sweep (reset by the host before the launch)
 };
 __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.ntie) return;
   const u32 off = a.tie_off[t], k = a.tie_ncand[t];
-  {  // a decision can only move if the count of one of its candidate buckets moved
+  const u32 r = a.tie_read[t];
+  {  // a decision can only move if the count of one of its candidate buckets moved before this read
     bool any = false;
-    for (u32 j = 0; j < k; j++) any |= a.dirty_in[a.cand_bucket[off + j]] != 0;
+    for (u32 j = 0; j < k; j++) any |= a.dirty_in[a.cand_bucket[off + j]] <= r;
     if (!any) return;
   }
-  const u32 e0 = a.ev_off[a.tie_read[t]];
   u32 best = 0;
   u64 bestc = 0;
   for (u32 j = 0; j < k; j++) {
     const u32 b = a.cand_bucket[off + j];
-    const u32 i = a.ev_place[e0 + j];
-    const u64 c = (a.prior ? a.prior[b] : 0ull) + (u64)(a.G[i] - a.G[a.seg[b]]);
+    const u64 c = (a.prior ? a.prior[b] : 0ull) + (u64)(a.G[a.cand_place[off + j]] - a.Gseg[b]);
     if (j == 0 || c > bestc) {  // strict: an earlier candidate keeps the bucket on equal counts
       best = j;
       bestc = c;
@@ -238,22 +248,21 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   }
   const u32 old = a.choice[t];
   if (best != old) {
-    a.chosen[a.ev_place[e0 + old]] = 0;
-    a.chosen[a.ev_place[e0 + best]] = 1;
+    a.chosen[a.cand_place[off + old]] = 0;
+    a.chosen[a.cand_place[off + best]] = 1;
     a.choice[t] = best;
-    a.dirty_out[a.cand_bucket[off + old]] = 1;
-    a.dirty_out[a.cand_bucket[off + best]] = 1;
-    a.changed[0] = 1;
-    atomicMin(&a.changed[1], t);
+    atomicMin(&a.dirty_out[a.cand_bucket[off + old]], r + 1);
+    atomicMin(&a.dirty_out[a.cand_bucket[off + best]], r + 1);
+    a.changed[0] = 1;  // plain store: every writer stores the same value
   }
 }
 
 // cross-shard prior counts that moved since the last sweep wake up the reads of those buckets
-__global__ __launch_bounds__(256) void prior_dirty_k(u32 nb1, const u64 *prior, u64 *seen, u8 *dirty) {
+__global__ __launch_bounds__(256) void prior_dirty_k(u32 nb1, const u64 *prior, u64 *seen, u32 *dirty) {
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb1) return;
   const u64 p = prior[b];
-  if (p != seen[b]) { seen[b] = p; dirty[b] = 1; }
+  if (p != seen[b]) { seen[b] = p; dirty[b] = 0; }  // moved before every read of this shard
 }
 
 // final (bucket, end) per read + API view (pattern index in file order, end)
@@ -283,10 +292,12 @@ __global__ __launch_bounds__(256) void finalize_k(FinalizeArgs a) {
 }
 
 // reads per bucket from the converged prefix sums
-__global__ __launch_bounds__(256) void bucket_counts_k(u32 nb1, const u32 *G, const u32 *seg, u64 *counts) {
+__global__ __launch_bounds__(256) void bucket_counts_k(u32 nb1, const u32 *G, const u32 *seg, u64 *counts, u32 *Gseg) {
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb1) return;
-  counts[b] = (u64)(G[seg[b + 1]] - G[seg[b]]);
+  const u32 g0 = G[seg[b]];
+  counts[b] = (u64)(G[seg[b + 1]] - g0);
+  Gseg[b] = g0;
 }
 
 }  // namespace scalce

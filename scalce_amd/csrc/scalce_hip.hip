@@ -173,7 +173,7 @@ struct scalce_batch {
   u8 *d_qlut[2] = {nullptr, nullptr};
   DBuf line_end[2], packed[2], q[2], namelen, freq4[2], table[2], qs[2];
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
-  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty;
+  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
   DBuf perm_a, perm_b, hist, scan_ws, S;
   DBuf out_reads[2], out_names, name_off, ac_tab, ac_cum, ac_blocks, ac_sizes, ac_off, out_qual[2];
@@ -216,7 +216,7 @@ static void free_all(scalce_batch *b) {
                  &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
                  &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
-                 &b->chosen, &b->G, &b->seg, &b->dirty, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
+                 &b->chosen, &b->G, &b->seg, &b->dirty, &b->cand_place, &b->Gseg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
                  &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S,
                  &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab, &b->ac_cum,
                  &b->ac_blocks, &b->ac_sizes, &b->ac_off, &b->out_qual[0], &b->out_qual[1]};
@@ -425,9 +425,10 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   ENSURE(b, b->tokens, sizeof(int32_t) * 2 * (N + 1));
   ENSURE(b, b->counts, sizeof(u64) * (nb1 + 1));
   ENSURE(b, b->seg, sizeof(u32) * (nb1 + 2));
+  ENSURE(b, b->Gseg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(2 * N + 1024) + 1024));
   u32 *ws32 = b->scan_ws.as<u32>();
-  ENSURE(b, b->dirty, 2 * (size_t)(nb1 + 64) + sizeof(u64) * (nb1 + 8));
+  ENSURE(b, b->dirty, 2 * sizeof(u32) * (size_t)(nb1 + 64) + sizeof(u64) * (nb1 + 8));
   if (!N) {
     HIP_TRY(c, hipMemsetAsync(b->counts.p, 0, sizeof(u64) * (nb1 + 1), s));
     b->ntie = b->nev = 0;
@@ -463,6 +464,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   b->ncand_cap = ncap;
   ENSURE(b, b->cand_bucket, sizeof(u32) * (ncap + 2));
   ENSURE(b, b->cand_pos, sizeof(u32) * (ncap + 2));
+  ENSURE(b, b->cand_place, sizeof(u32) * (ncap + 2));
   if (ntie) {
     TieArgs a;
     a.next = c->d_next; a.outinfo = c->d_outinfo; a.packed = b->packed[0].as<u8>(); a.L = b->L[0]; a.stride = b->stride[0];
@@ -507,13 +509,16 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   const u32 *sorted = src;
   LAUNCH(events_place_k, cdiv(nev, 256), 256, 0, s, nev, sorted, b->ev_init.as<u8>(), b->ev_place.as<u32>(), b->chosen.as<u8>());
   LAUNCH(events_segments_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, sorted, b->ev_bucket.as<u32>(), nb1, b->seg.as<u32>());
+  if (ntie)
+    LAUNCH(tie_place_k, cdiv(ntie, 256), 256, 0, s, ntie, b->tie_read.as<u32>(), b->tie_off.as<u32>(), b->tie_ncand.as<u32>(),
+           b->ev_off.as<u32>(), b->ev_place.as<u32>(), b->cand_place.as<u32>());
   // first prefix sums; the sweeps follow (scalce_batch_tokenize_sweep)
   u32 *G = b->G.as<u32>();
   exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, ws32, G + nev, s);
   b->dirty_cur = 0;
-  HIP_TRY(c, hipMemsetAsync(b->dirty.p, 1, nb1, s));  // first sweep: every bucket counts as moved
-  HIP_TRY(c, hipMemsetAsync(b->dirty.as<u8>() + 2 * (size_t)(nb1 + 64), 0, sizeof(u64) * nb1, s));  // prior seen so far
-  LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>());
+  HIP_TRY(c, hipMemsetAsync(b->dirty.p, 0, sizeof(u32) * nb1, s));  // first sweep: every bucket moved "before read 0"
+  HIP_TRY(c, hipMemsetAsync(b->dirty.as<u32>() + 2 * (size_t)(nb1 + 64), 0, sizeof(u64) * nb1, s));  // prior seen so far
+  LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>(), b->Gseg.as<u32>());
   return SCALCE_OK;
 }
 
@@ -528,8 +533,8 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   *changed = 0;
   const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie, nev = b->nev;
   if (!b->N || !ntie) return SCALCE_OK;
-  u8 *d0 = b->dirty.as<u8>(), *d1 = d0 + nb1 + 64;
-  u8 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
+  u32 *d0 = b->dirty.as<u32>(), *d1 = d0 + nb1 + 64;
+  u32 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
   u64 *prior_seen = reinterpret_cast<u64 *>(d0 + 2 * (size_t)(nb1 + 64));
   if (d_prior) LAUNCH(prior_dirty_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), prior_seen, dirty_in);
   static const u32 init[2] = {0u, 0xFFFFFFFFu};
@@ -537,11 +542,11 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   u32 *G = b->G.as<u32>();
   JacobiArgs a;
   a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
-  a.cand_bucket = b->cand_bucket.as<u32>(); a.ev_off = b->ev_off.as<u32>(); a.ev_place = b->ev_place.as<u32>(); a.G = G;
-  a.seg = b->seg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
+  a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_place = b->cand_place.as<u32>(); a.G = G;
+  a.Gseg = b->Gseg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
   a.changed = b->d_small + 4;
   a.dirty_in = dirty_in; a.dirty_out = dirty_out;
-  HIP_TRY(c, hipMemsetAsync(dirty_out, 0, nb1, s));
+  HIP_TRY(c, hipMemsetAsync(dirty_out, 0xFF, sizeof(u32) * nb1, s));
   LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
   b->dirty_cur ^= 1;
   u32 ch[2];
@@ -550,7 +555,7 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   *changed = ch[0] ? 1 : 0;
   if (ch[0]) {
     exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, b->scan_ws.as<u32>(), G + nev, s);
-    LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>());
+    LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>(), b->Gseg.as<u32>());
   }
   return SCALCE_OK;
 }
