@@ -133,12 +133,11 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8 *t, u64 at, u64 n) {
   return (lo >> sh) | (hi << (32 - sh));
 }
 
-__global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
-  __shared__ u8 lut[128];
-  if (threadIdx.x < 128) lut[threadIdx.x] = a.qlut[threadIdx.x];
-  __syncthreads();
-  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= a.nrec) return;
+// One record: bases -> 2-bit row (global), qualities -> q' (through `qrow`, LDS or global), name length.
+// `word(at)` returns the aligned little-endian 32-bit word that contains text byte `at & ~3`.
+template <typename WordAt, typename ByteAt>
+__device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const u8 *lut, WordAt word, ByteAt byte_at, u8 *qrow,
+                                              bool qrow_aligned) {
   const u64 p0 = a.line_end[4 * r], p1 = a.line_end[4 * r + 1], p2 = a.line_end[4 * r + 2], p3 = a.line_end[4 * r + 3];
   if (p1 - p0 - 1 != (u64)a.L || p3 - p2 - 1 != (u64)a.L) {
     dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
@@ -146,14 +145,19 @@ __global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
   }
   const int L = a.L;
   u8 *prow = a.packed + r * (u64)a.stride;
-  u8 *qrow = a.q + r * (u64)L;
   const u64 sb = p0 + 1, sq = p2 + 1;
+  auto fetch = [&](u64 at) -> u32 {  // unaligned little-endian 32-bit fetch
+    const u32 sh = (u32)(at & 3) * 8;
+    const u32 lo = word(at);
+    if (!sh) return lo;
+    return (lo >> sh) | (word(at + 4) << (32 - sh));
+  };
   u32 acc = 0;
   int nacc = 0, wout = 0;
   bool bad = false;
   for (int i = 0; i < L; i += 4) {
-    u32 vb = load_u32_unaligned(a.text, sb + i, a.nbytes);
-    u32 vq = load_u32_unaligned(a.text, sq + i, a.nbytes);
+    u32 vb = fetch(sb + i);
+    u32 vq = fetch(sq + i);
     const int rem = L - i;
     if (rem < 4) {  // last partial group: bytes beyond the line are not part of the read
       const u32 keep = (1u << (8 * rem)) - 1;
@@ -173,17 +177,16 @@ __global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
              ((u32)lut[(vq >> 24) & 127] << 24);
     qq &= ~isN;
     if (rem >= 4) {
-      if (((u64)qrow & 3) == 0)
+      if (qrow_aligned)
         *reinterpret_cast<u32 *>(qrow + i) = qq;
       else {
         qrow[i] = (u8)qq; qrow[i + 1] = (u8)(qq >> 8); qrow[i + 2] = (u8)(qq >> 16); qrow[i + 3] = (u8)(qq >> 24);
       }
-      if (!a.no_ac && ((((qq & 0x7F7F7F7Fu) + 0x30303030u) | qq) & 0x80808080u)) bad = true;  // a byte >= 80
     } else {
       for (int k = 0; k < rem; k++) qrow[i + k] = (u8)(qq >> (8 * k));
       qq &= (1u << (8 * rem)) - 1;
-      if (!a.no_ac && ((((qq & 0x7F7F7F7Fu) + 0x30303030u) | qq) & 0x80808080u)) bad = true;  // a byte >= 80
     }
+    if (!a.no_ac && ((((qq & 0x7F7F7F7Fu) + 0x30303030u) | qq) & 0x80808080u)) bad = true;  // a byte >= 80
   }
   // flush the partial word and zero the rest of the row
   for (int w = wout; w < a.stride / 4; w++) {
@@ -197,12 +200,81 @@ __global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
     u32 len = 0;
     if (a.use_names) {
       u64 i = ns + 1;
-      while (i < p0 && a.text[i] != ' ') i++;
+      while (i < p0 && byte_at(i) != ' ') i++;
       const u64 l = i - (ns + 1);
       if (l > 255 || p0 <= ns) dev_fail(a.err, E_NAMELEN, r);
       len = (u32)(l & 255);
     }
     a.namelen[r] = (u8)len;
+  }
+}
+
+// direct form: every thread reads its record straight from global memory (fallback for long reads / huge names)
+__global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
+  __shared__ u8 lut[128];
+  if (threadIdx.x < 128) lut[threadIdx.x] = a.qlut[threadIdx.x];
+  __syncthreads();
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.nrec) return;
+  u8 *qrow = a.q + r * (u64)a.L;
+  unpack_record(a, r, lut, [&](u64 at) { return load_word(a.text, at & ~3ull, a.nbytes); },
+                [&](u64 at) { return a.text[at]; }, qrow, ((u64)qrow & 3) == 0);
+}
+
+// tiled form: a workgroup copies the contiguous text of UNP_RPB records into LDS with 16-byte loads, the
+// threads then work out of LDS, and the q' rows leave through LDS as one contiguous, coalesced block.
+constexpr int UNP_RPB = 128;
+constexpr int UNP_TEXT_CAP = 44 * 1024;
+constexpr int UNP_Q_CAP = 20 * 1024;  // UNP_RPB * L must fit: L <= 160
+__global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
+  __shared__ __attribute__((aligned(16))) u8 tile[UNP_TEXT_CAP + 32];
+  __shared__ __attribute__((aligned(16))) u8 qt[UNP_Q_CAP];
+  __shared__ u8 lut[128];
+  const int tid = threadIdx.x;
+  lut[tid] = a.qlut[tid];
+  const u64 r0 = (u64)blockIdx.x * UNP_RPB;
+  const u64 r1 = r0 + UNP_RPB < a.nrec ? r0 + UNP_RPB : a.nrec;
+  const u64 span0 = r0 ? a.line_end[4 * r0 - 1] + 1 : 0;
+  const u64 span1 = a.line_end[4 * (r1 - 1) + 3] + 1;
+  const u64 a0 = span0 & ~15ull;
+  const u64 tbytes = span1 - a0;
+  const bool in_lds = tbytes <= (u64)UNP_TEXT_CAP;  // uniform for the workgroup
+  if (in_lds) {
+    for (u64 i = (u64)tid * 16; i < tbytes + 8; i += (u64)UNP_RPB * 16) {  // +8: the funnel fetch may touch the next word
+      uint4 v;
+      if (a0 + i + 16 <= a.nbytes) v = *reinterpret_cast<const uint4 *>(a.text + a0 + i);
+      else {
+        u32 w[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 16; k++)
+          if (a0 + i + k < a.nbytes) w[k >> 2] |= (u32)a.text[a0 + i + k] << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      *reinterpret_cast<uint4 *>(tile + i) = v;
+    }
+  }
+  __syncthreads();
+  const u64 r = r0 + tid;
+  if (r < r1) {
+    u8 *qrow = qt + (size_t)tid * a.L;
+    const bool al = ((a.L & 3) == 0);
+    if (in_lds)
+      unpack_record(a, r, lut, [&](u64 at) { return *reinterpret_cast<const u32 *>(tile + ((at & ~3ull) - a0)); },
+                    [&](u64 at) { return tile[at - a0]; }, qrow, al);
+    else
+      unpack_record(a, r, lut, [&](u64 at) { return load_word(a.text, at & ~3ull, a.nbytes); },
+                    [&](u64 at) { return a.text[at]; }, qrow, al);
+  }
+  __syncthreads();
+  // q' rows of this workgroup are one contiguous range of the output
+  const u64 qbytes = (r1 - r0) * (u64)a.L;
+  u8 *qdst = a.q + r0 * (u64)a.L;
+  if ((((u64)qdst) & 15) == 0) {
+    for (u64 i = (u64)tid * 16; i < qbytes; i += (u64)UNP_RPB * 16) {
+      if (i + 16 <= qbytes) *reinterpret_cast<uint4 *>(qdst + i) = *reinterpret_cast<const uint4 *>(qt + i);
+      else for (u64 k = i; k < qbytes; k++) qdst[k] = qt[k];
+    }
+  } else {
+    for (u64 i = tid; i < qbytes; i += UNP_RPB) qdst[i] = qt[i];
   }
 }
 
