@@ -217,12 +217,15 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   // ---- chain-wave state ----
   u32 lo = 0, hi = 0xFFFFFFFFu;
 
-  auto gather = [&](u32 base) -> uint4 {
-    const u32 i = base + lane;
-    if (i < 2 || i >= n) return make_uint4(0, 0, 0, 0);
+  // operands of the 32 symbols [base, base + 32): lane l serves symbol base + (l & 31); lanes 0..31 fetch the
+  // reciprocal fraction of the symbol's upper bound g(hi), lanes 32..63 that of its lower bound g(lo)
+  auto gather = [&](u32 base) -> uint2 {
+    const u32 i = base + (lane & 31);
+    if (i < 2 || i >= n) return make_uint2(0, 0);
     const u32 p0 = s[i - 2], p1 = s[i - 1], c = s[i];
-    if (p0 >= AC_D || p1 >= AC_D || c >= AC_D) return make_uint4(0, 0, 0, 0);  // E_SYMBOL was raised at ingest
-    return a.tab[((u64)p0 * AC_D + p1) * AC_D + c];
+    if (p0 >= AC_D || p1 >= AC_D || c >= AC_D) return make_uint2(0, 0);  // E_SYMBOL was raised at ingest
+    const uint2 *e = reinterpret_cast<const uint2 *>(a.tab + ((u64)p0 * AC_D + p1) * AC_D + c);
+    return e[lane < 32 ? 1 : 0];
   };
 
   // uniform append of nb <= 32 bits (every lane of the helper wave passes the same values): used by the
@@ -313,58 +316,82 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   };
 
   if (!chain_wave) carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
-  // chain wave: all 64 lanes fetch the operands of a round (one symbol per lane) a round ahead; lane 0 then
-  // pulls symbol j's operands out of those registers with v_readlane (no LDS round trip on the chain)
-  uint4 cur = chain_wave ? gather(0) : make_uint4(0, 0, 0, 0);
+  // chain wave: the operands of a round (two halves of 32 symbols) are fetched a round ahead
+  uint2 curA = chain_wave ? gather(0) : make_uint2(0, 0), curB = chain_wave ? gather(32) : make_uint2(0, 0);
   for (u32 r = 0; r < nrounds; r++) {
     const u32 base = r << 6;
     if (chain_wave) {
-      const uint4 ops_r = cur;
-      if (base + 64 < n && !(a.debug & 4)) cur = gather(base + 64);  // in flight during this round's chain
-      const bool plain = !__any(ops_r.w == 0xFFFFFFFFu);           // no last-of-context symbol in the round
-      auto operand = [&](u32 j) -> uint4 {
-        return make_uint4(__builtin_amdgcn_readlane(ops_r.x, j), __builtin_amdgcn_readlane(ops_r.y, j),
-                          __builtin_amdgcn_readlane(ops_r.z, j), __builtin_amdgcn_readlane(ops_r.w, j));
-      };
+      const uint2 opsA = curA, opsB = curB;
+      if (base + 64 < n && !(a.debug & 4)) {  // in flight during this round's chain
+        curA = gather(base + 64);
+        curB = gather(base + 96);
+      }
       if ((a.debug & 1) && lane == 0) {  // profiling: no coder work, only well-formed empty outcomes
         for (int j = 0; j < 64; j++) rec[r & 1][j] = make_uint2(0u, 0u);
         if (r + 1 == nrounds) final_lo = 0;
       }
-      if (lane == 0 && !(a.debug & 1)) {
-        const u32 cnt = (n - base) < 64 ? (n - base) : 64;
-        uint2 *rc = rec[r & 1];
-        u32 j = (r == 0) ? 2u : 0u;
-        u32 M = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
-        if (!GENERAL && plain && __builtin_amdgcn_readfirstlane(M) != 0) {
-          while (j + 3 < cnt) {  // four symbols per trip, one exit test
-            const u32 lo_save = lo, M_save = M;
-            u32 hb, ku;
-            u32 e = ac_step_plain(lo, M, operand(j), hb, ku);
-            rc[j] = make_uint2(hb, ku);
-            u32 e2 = ac_step_plain(lo, M, operand(j + 1), hb, ku);
-            e = e2 < e ? e2 : e;
-            rc[j + 1] = make_uint2(hb, ku);
-            e2 = ac_step_plain(lo, M, operand(j + 2), hb, ku);
-            e = e2 < e ? e2 : e;
-            rc[j + 2] = make_uint2(hb, ku);
-            e2 = ac_step_plain(lo, M, operand(j + 3), hb, ku);
-            e = e2 < e ? e2 : e;
-            rc[j + 3] = make_uint2(hb, ku);
-            // only lane 0 is active here, so readfirstlane turns the test into a scalar branch
-            if (__builtin_amdgcn_readfirstlane(e) == 0) {  // rare: roll the group back, the general loop redoes it
-              lo = lo_save; M = M_save;
-              break;
+      if (!(a.debug & 1)) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint2 ops = h ? opsB : opsA;
+          const u32 hbase = base + 32 * h;
+          if (hbase >= n) break;
+          const u32 cnt = (n - hbase) < 32 ? (n - hbase) : 32;
+          uint2 *rc = rec[r & 1] + 32 * h;
+          u32 j = (r == 0 && h == 0) ? 2u : 0u;
+          const u32 M0 = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
+          bool done = false;
+          if (!GENERAL && cnt == 32 && j == 0 && M0 != 0 && !__any(lane < 32 && ops.y == 0xFFFFFFFFu)) {
+            // Systolic plain steps.  Step s is the work of lane pair (s, s + 32): the lower lane multiplies
+            // the range by g(hi), the upper one by g(lo) -- ONE v_mul_hi_u32 + ONE v_mad_u64_u32 serve both
+            // quotients -- v_permlane32_swap hands each lane the other's quotient, and both lanes then advance
+            // the same state.  The state moves one lane per step (DPP wave_shr:1), so the operands never move.
+            // Every lane executes every step; only the step that matches its lane is meaningful, its outcome is
+            // latched.  All 64 lanes start from the round's state, which also feeds lane 32 in step 0.
+            u32 st_lo = lo, st_M = M0, recH = 0, recK = 0, eL = 0xFFFFFFFFu;
+            for (u32 st = 0; st < 32; st++) {
+              const u32 in_lo = __builtin_amdgcn_update_dpp(lo, st_lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
+              const u32 in_M = __builtin_amdgcn_update_dpp(M0, st_M, 0x138, 0xF, 0xF, false);
+              const u32 Q = (u32)(((u64)in_M * ops.y + __umulhi(in_M, ops.x)) >> 32);
+              const auto sw = __builtin_amdgcn_permlane32_swap(Q, Q, false, false);
+              const u32 A = sw[0], B = sw[1];  // quotient of the upper / lower bound, in both lanes of the pair
+              const u32 W = A - B;             // new range before renormalisation
+              const u32 nlo = in_lo + B, nhi = in_lo + A - 1;
+              const u32 x = nlo ^ nhi;
+              const u32 k = ffbh_raw(x);                  // x == 0: garbage, flagged through e
+              const u32 c1 = ((~nlo | nhi) << 1) | 1u;    // see ac_step_plain
+              const u32 u = ffbh_raw(c1 << k);
+              st_lo = ((nlo << k) << u) & 0x7FFFFFFFu;
+              st_M = (W << k) << u;                       // renormalising by k + u bits scales the range by 2^(k+u)
+              const u32 e = x < st_M ? x : st_M;          // 0 iff x == 0 or the range wrapped to 2^32
+              const bool mine = (u32)(lane & 31) == st;
+              recH = mine ? nhi : recH;
+              recK = mine ? (k | (u << 8)) : recK;
+              eL = mine ? e : eL;
             }
-            j += 4;
+            if (!__any(eL == 0)) {  // else (rare): a step needs the general path; redo the half below
+              lo = __builtin_amdgcn_readlane(st_lo, 31);
+              hi = lo + __builtin_amdgcn_readlane(st_M, 31) - 1;
+              if (lane < 32) rc[lane] = make_uint2(recH, recK);
+              done = true;
+            }
           }
-          hi = lo + M - 1;
+          if (!done) {  // general steps on lane 0: first round, last-of-context symbols, full interval, tails
+            u32 glo = lo, ghi = hi;
+            if (lane == 0) {
+              for (; j < cnt; j++) {
+                const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops.x, j + 32), __builtin_amdgcn_readlane(ops.y, j + 32),
+                                           __builtin_amdgcn_readlane(ops.x, j), __builtin_amdgcn_readlane(ops.y, j));
+                u32 hbefore;
+                const u32 ku = ac_step<GENERAL>(glo, ghi, g, hbefore);
+                rc[j] = make_uint2(hbefore, ku);
+              }
+            }
+            lo = __builtin_amdgcn_readfirstlane(glo);
+            hi = __builtin_amdgcn_readfirstlane(ghi);
+          }
         }
-        for (; j < cnt; j++) {  // general steps: first round, last-of-context symbols, full interval, round tails
-          u32 hbefore;
-          const u32 ku = ac_step<GENERAL>(lo, hi, operand(j), hbefore);
-          rc[j] = make_uint2(hbefore, ku);
-        }
-        if (r + 1 == nrounds) final_lo = lo;
+        if (r + 1 == nrounds && lane == 0) final_lo = lo;
       }
     } else {
       if (r > 0 && !(a.debug & 2)) {
