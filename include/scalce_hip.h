@@ -161,8 +161,9 @@ int scalce_batch_kernel_ms(scalce_batch *b, double *total_ms, int *launches, uin
 int scalce_memcpy_d2h(scalce_ctx *ctx, void *dst_host, const void *src_dev, uint64_t nbytes);
 int scalce_memcpy_h2d(scalce_ctx *ctx, void *dst_dev, const void *src_host, uint64_t nbytes);
 int scalce_memcpy_d2d(scalce_ctx *ctx, void *dst_dev, const void *src_dev, uint64_t nbytes, void *stream); /* async */
-/* diagnostics of the last tokenize call: tie reads, candidate events, fixed-point iterations, spill chunks */
-int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]);
+/* diagnostics of the last run: tie reads, candidate events, fixed-point sweeps, spill chunks, records that
+ * needed the second sort phase */
+int scalce_batch_stats(const scalce_batch *b, uint32_t out[5]);
 
 /* Device self-test of the arithmetic coder's closed-form step (multiply-high by reciprocal fractions, merged
  * renormalisation shift) against the literal loop of arithmetic.cpp:122-152 on `ncases` random and crafted

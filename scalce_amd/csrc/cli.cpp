@@ -216,7 +216,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   const double t2 = now();
   const uint64_t N = scalce_batch_reads(b);
   LOG("\tDone with file %s, %llu reads found\n", files[0].c_str(), (unsigned long long)N);
-  uint32_t st4[4] = {0, 0, 0, 0};
+  uint32_t st4[5] = {0, 0, 0, 0, 0};
   scalce_batch_stats(b, st4);
 
   // final writer: headers of combine_and_compress_with_split (compress.cpp:263-343)

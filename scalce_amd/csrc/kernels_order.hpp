@@ -32,6 +32,60 @@ struct KeyDigit {
   }
 };
 
+// ---- two-phase order -----------------------------------------------------------------------------
+// Phase 1 sorts by (bucket, chunk, first PREFIX_DIGITS key digits); records that still tie with a neighbour
+// form "runs" and only those go through the remaining key digits (phase 2).  On reads without exact
+// duplicates almost nothing is left for phase 2, so the random digit gathers drop from ceil(L/4) passes to
+// PREFIX_DIGITS.
+constexpr int PREFIX_DIGITS = 4;
+
+struct RunArgs {
+  u32 n;
+  const u32 *perm;      // order after phase 1
+  const u32 *bucket;
+  const u32 *chunk;     // or null
+  const u8 *packed;
+  const u16 *end;
+  int L, stride, ndig1; // digits sorted in phase 1
+};
+__device__ __forceinline__ bool same_phase1_key(const RunArgs &a, u32 x, u32 y) {
+  if (a.bucket[x] != a.bucket[y]) return false;
+  if (a.chunk && a.chunk[x] != a.chunk[y]) return false;
+  for (int d = 0; d < a.ndig1; d++) {
+    KeyDigit kd{a.packed, a.end, a.L, a.stride, d};
+    if (kd(x) != kd(y)) return false;
+  }
+  return true;
+}
+// head[i] = 1 when position i starts a new phase-1 key
+__global__ __launch_bounds__(256) void run_heads_k(RunArgs a, u8 *head) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  head[i] = (i == 0) ? 1 : (same_phase1_key(a, a.perm[i - 1], a.perm[i]) ? 0 : 1);
+}
+struct RunMember {  // position i belongs to a run of length > 1
+  const u8 *head;
+  u32 n;
+  __device__ u32 operator()(u64 i) const { return (!head[i] || (i + 1 < n && !head[i + 1])) ? 1u : 0u; }
+};
+// compaction of the run members: items (read indices), their positions, and the run id of every member
+__global__ __launch_bounds__(256) void run_compact_k(u32 n, const u8 *head, const u32 *member_rank, const u32 *head_count,
+                                                    const u32 *perm, u32 *items, u32 *pos_list, u32 *runid_of_read) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool member = !head[i] || (i + 1 < n && !head[i + 1]);
+  if (!member) return;
+  const u32 m = member_rank[i];
+  const u32 r = perm[i];
+  items[m] = r;
+  pos_list[m] = i;
+  runid_of_read[r] = head_count[i] + head[i];  // heads at positions <= i: constant inside a run, increasing across runs
+}
+__global__ __launch_bounds__(256) void run_scatter_k(u32 m, const u32 *sorted, const u32 *pos_list, u32 *perm) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) perm[pos_list[i]] = sorted[i];
+}
+
 // spill chunks (compress.cpp:702-715): running size of the records since the last dump; when it
 // reaches -B the current read closes the chunk.  rec_size is scanned inclusively into S; the
 // boundaries are found by one thread with binary searches (there are few chunks).

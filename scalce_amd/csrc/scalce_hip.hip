@@ -175,7 +175,8 @@ struct scalce_batch {
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
-  DBuf perm_a, perm_b, hist, scan_ws, S;
+  DBuf perm_a, perm_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
+  u32 order_run_members = 0;
   DBuf out_reads[2], out_names, name_off, ac_tab, ac_cum, ac_blocks, ac_sizes, ac_off, out_qual[2];
   u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
   // host-side results
@@ -217,7 +218,8 @@ static void free_all(scalce_batch *b) {
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
                  &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
                  &b->chosen, &b->G, &b->seg, &b->dirty, &b->cand_place, &b->Gseg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
-                 &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S,
+                 &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S, &b->run_head, &b->run_hcount, &b->run_rank, &b->runid,
+                 &b->run_items_a, &b->run_items_b, &b->run_pos,
                  &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab, &b->ac_cum,
                  &b->ac_blocks, &b->ac_sizes, &b->ac_off, &b->out_qual[0], &b->out_qual[1]};
   for (DBuf *d : all)
@@ -644,11 +646,15 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   u32 *dst = b->perm_a.as<u32>(), *alt = b->perm_b.as<u32>();
   auto flip = [&]() { src = dst; u32 *t = dst; dst = alt; alt = t; };
   const int ndig = (b->L[0] + 3) / 4;
-  for (int d = ndig - 1; d >= 0; d--) {
+  const bool two_phase = getenv("SCALCE_ORDER_SINGLE_PHASE") == nullptr;  // test hook: all digits in one go
+  const int ndig1 = two_phase ? (ndig < PREFIX_DIGITS ? ndig : PREFIX_DIGITS) : ndig;
+  // phase 1: first ndig1 key digits (least significant first), then chunk, then bucket
+  for (int d = ndig1 - 1; d >= 0; d--) {
     radix_pass(src, dst, (u32)N, KeyDigit{b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], d}, b->hist.as<u32>(),
                ws32, s);
     flip();
   }
+  const u32 *chunk_or_null = b->nchunks > 1 ? b->chunk.as<u32>() : nullptr;
   if (b->nchunks > 1)
     for (int sh = 0; (1u << sh) < b->nchunks; sh += 8) {
       radix_pass(src, dst, (u32)N, DigitOfArray{b->chunk.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
@@ -660,7 +666,45 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
     radix_pass(src, dst, (u32)N, DigitOfArray{b->bucket.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
     flip();
   }
-  b->perm = const_cast<u32 *>(src);
+  u32 *perm1 = const_cast<u32 *>(src);
+  b->order_run_members = 0;
+  if (ndig1 < ndig) {
+    // phase 2: records that still tie on (bucket, chunk, prefix) are sorted on the remaining digits, run by run
+    ENSURE(b, b->run_head, N + 64);
+    ENSURE(b, b->run_hcount, sizeof(u32) * (N + 2));
+    ENSURE(b, b->run_rank, sizeof(u32) * (N + 2));
+    ENSURE(b, b->runid, sizeof(u32) * (N + 2));
+    RunArgs ra{(u32)N, perm1, b->bucket.as<u32>(), chunk_or_null, b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], ndig1};
+    u8 *head = b->run_head.as<u8>();
+    LAUNCH(run_heads_k, cdiv(N, 256), 256, 0, s, ra, head);
+    exclusive_scan<u32>(LoadAs<u8, u32>{head}, N, StoreTo<u32>{b->run_hcount.as<u32>()}, ws32, (u32 *)nullptr, s);
+    exclusive_scan<u32>(RunMember{head, (u32)N}, N, StoreTo<u32>{b->run_rank.as<u32>()}, ws32, b->d_small + 9, s);
+    u32 M = 0;
+    { int rc = read_u32(b, b->d_small + 9, &M, 1, s); if (rc) return rc; }
+    b->order_run_members = M;
+    if (M) {
+      ENSURE(b, b->run_items_a, sizeof(u32) * (M + 2));
+      ENSURE(b, b->run_items_b, sizeof(u32) * (M + 2));
+      ENSURE(b, b->run_pos, sizeof(u32) * (M + 2));
+      LAUNCH(run_compact_k, cdiv(N, 256), 256, 0, s, (u32)N, head, b->run_rank.as<u32>(), b->run_hcount.as<u32>(), perm1,
+             b->run_items_a.as<u32>(), b->run_pos.as<u32>(), b->runid.as<u32>());
+      const u32 *rs = b->run_items_a.as<u32>();
+      u32 *rd = b->run_items_b.as<u32>(), *ralt = b->run_items_a.as<u32>();
+      auto rflip = [&]() { rs = rd; u32 *t = rd; rd = ralt; ralt = t; };
+      for (int d = ndig - 1; d >= ndig1; d--) {
+        radix_pass(rs, rd, M, KeyDigit{b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], d}, b->hist.as<u32>(), ws32, s);
+        rflip();
+      }
+      int rbits = 1;
+      while ((1ull << rbits) <= N && rbits < 32) rbits++;  // run ids are at most N
+      for (int sh = 0; sh < rbits; sh += 8) {
+        radix_pass(rs, rd, M, DigitOfArray{b->runid.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+        rflip();
+      }
+      LAUNCH(run_scatter_k, cdiv(M, 256), 256, 0, s, M, rs, b->run_pos.as<u32>(), perm1);
+    }
+  }
+  b->perm = perm1;
   return SCALCE_OK;
 }
 
@@ -929,9 +973,10 @@ extern "C" int scalce_memcpy_d2d(scalce_ctx *c, void *dst, const void *src, uint
   HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SCALCE_OK;
 }
-extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[4]) {
+extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[5]) {
   if (!b || !out) return SCALCE_ERR_ARG;
   out[0] = b->ntie; out[1] = b->nev; out[2] = b->jacobi_iters; out[3] = b->nchunks;
+  out[4] = b->order_run_members;
   return SCALCE_OK;
 }
 

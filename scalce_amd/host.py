@@ -277,9 +277,9 @@ class Batch:
         return self.ctx.to_host(p, n, dtype)
 
     def stats(self):
-        a = (C.c_uint32 * 4)()
+        a = (C.c_uint32 * 5)()
         self._check(self.L.scalce_batch_stats(self.h, a))
-        return dict(tie_reads=a[0], events=a[1], jacobi_iters=a[2], chunks=a[3])
+        return dict(tie_reads=a[0], events=a[1], jacobi_iters=a[2], chunks=a[3], order_run_members=a[4])
 
     def stage_reset(self, enable=True):
         self.L.scalce_batch_stage_reset(self.h, int(enable))

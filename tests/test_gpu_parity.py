@@ -206,6 +206,24 @@ def test_ac_general_step_same_bytes(ctx, oracle_trie, monkeypatch):
     check_against_oracle(ctx, oracle_trie, bases, quals, label="general-step")
 
 
+def test_heavy_duplicates_two_phase_order(ctx, oracle_trie, monkeypatch):
+    """Few distinct reads, many copies, and long shared prefixes: nearly every record goes through the second
+    sort phase (runs that tie on bucket + 16-base prefix); same permutation as the all-digits sort."""
+    rng = np.random.default_rng(5)
+    base_reads, _ = synth.reads_and_quals(60, 100, seed=41)
+    idx = rng.integers(0, 60, 20000)
+    bases = base_reads[idx].copy()
+    mut = rng.random(20000) < 0.5          # half of them differ only near the end of the read
+    pos = rng.integers(70, 100, 20000)
+    bases[mut, pos[mut]] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, mut.sum())]
+    _, quals = synth.reads_and_quals(20000, 100, seed=42)
+    b, ref, st = check_against_oracle(ctx, oracle_trie, bases, quals, label="dups")
+    assert st["order_run_members"] > 15000
+    monkeypatch.setenv("SCALCE_ORDER_SINGLE_PHASE", "1")
+    b2, _, st2 = check_against_oracle(ctx, oracle_trie, bases, quals, label="dups-single-phase")
+    assert st2["order_run_members"] == 0
+
+
 def test_malformed_input_is_an_error(ctx):
     from gpu_util import device_bytes
     b1, q1 = synth.reads_and_quals(50, 40, seed=3)
