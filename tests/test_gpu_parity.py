@@ -224,6 +224,63 @@ def test_heavy_duplicates_two_phase_order(ctx, oracle_trie, monkeypatch):
     assert st2["order_run_members"] == 0
 
 
+def test_paired_150bp_mid_size(ctx, patterns_blob, tmp_path):
+    """BASELINE configs[2] shape (150 bp paired-end, -r) at 400 k pairs: files equal the oracle's, both mates."""
+    from gpu_util import hip_compress
+    n, L = 400000, 150
+    b1, q1 = synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=61, n_frac=0.001, paired_suffix="/1")
+    synth.write_fastq(str(tmp_path / "in_2.fq"), n, L, seed=62, n_frac=0.001, paired_suffix="/2")
+    fq1 = open(tmp_path / "in_1.fq", "rb").read()
+    fq2 = open(tmp_path / "in_2.fq", "rb").read()
+    off, vals, _ = fmt.sample_qmap(fq1)
+    off2, vals2, _ = fmt.sample_qmap(fq2)
+    O.orc_cli("compress", os.path.join(GOLD, "patterns.bin"), tmp_path / "in_1.fq", tmp_path / "orc", "-r")
+    b = hip_compress(ctx, fq1, L, fastq2=fq2, L2=L, qmap=[(off, vals), (off2, vals2)])
+    fmt.write_archive(str(tmp_path / "hip"), b, off)
+    for m in (1, 2):
+        for ext in "nrq":
+            assert open(tmp_path / f"orc_{m}.scalce{ext}", "rb").read() == open(tmp_path / f"hip_{m}.scalce{ext}", "rb").read(), (m, ext)
+
+
+def test_large_shard_properties(ctx):
+    """3 M reads (beyond what the oracle is asked to redo here): size-independent properties -- the order is a
+    permutation sorted by (bucket, key), bucket counts add up, the GPU decoder inverts every coded block, and the
+    .scalcer payload has exactly the advertised size."""
+    import torch
+    from scalce_amd import synth_gpu
+    n, L = 3_000_000, 100
+    text = synth_gpu.fastq_on_device(n, L, torch.device("cuda", 0), seed=123)
+    b = host.Batch(ctx, L, n + 8, text.numel() + 64)
+    b.compress(text.data_ptr(), text.numel())
+    b.finish()
+    assert b.n_reads == n
+    perm = b.output(host.OUT_PERM, 0, np.uint32)
+    assert (np.sort(perm) == np.arange(n, dtype=np.uint32)).all()
+    tok = b.output(host.OUT_TOKENS, 0, np.int32).reshape(-1, 2)
+    counts = b.output(host.OUT_BUCKET_COUNTS, 0, np.uint64)
+    assert counts.sum() == n
+    order = ctx.bucket_patterns()
+    rank_of_pattern = {int(p): i for i, p in enumerate(order[:-1])}
+    bucket = np.array([rank_of_pattern[p] if p >= 0 else len(order) - 1 for p in tok[perm, 0]])
+    assert (np.diff(bucket) >= 0).all(), "buckets not in emission order"
+    assert (np.bincount(bucket, minlength=len(order)) == counts.astype(np.int64)).all()
+    # coreless reads have end 0, others end >= core length
+    lens = np.array([len(ctx.pattern(int(p))) for p in order[:-1]] + [0])
+    assert ((tok[:, 1] == 0) == (tok[:, 0] < 0)).all() and (tok[perm, 1] >= lens[bucket]).all()
+    # decoder round trip on the device
+    nsym = n * L
+    out = torch.zeros(nsym, dtype=torch.uint8, device="cuda:0")
+    p, nbytes = b.output_ptr(host.OUT_QUAL, 0)
+    ctx.ac_decode(b.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nsym, out.data_ptr())
+    qs_ptr, qs_n = b.output_ptr(host.OUT_QSTREAM, 0)
+    want = torch.empty(nsym, dtype=torch.uint8, device="cuda:0")
+    ctx.copy_d2d(want.data_ptr(), qs_ptr, qs_n)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    recsz = (L - lens + 3) // 4 + 1
+    assert len(b.output(host.OUT_READS, 0)) == int((counts.astype(np.int64) * recsz).sum() + 12 * (counts > 0).sum())
+
+
 def test_malformed_input_is_an_error(ctx):
     from gpu_util import device_bytes
     b1, q1 = synth.reads_and_quals(50, 40, seed=3)
