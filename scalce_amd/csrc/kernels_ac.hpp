@@ -442,14 +442,20 @@ __global__ __launch_bounds__(256) void ac_frame_k(const u8 *blocks, u64 stride, 
   for (u64 i = i0; i < i0 + 16 && i < sz; i++) dst[4 + i] = src[i];
 }
 
-// ---- decoder (next row): one wavefront per block; the symbol search of
-// read_single (arithmetic.cpp:205-209) is one ballot over the 80 cumulative bounds -----------
+// ---- decoder (next row): ac_decoder::read_single, arithmetic.cpp:196-244 -------------------
+// One wavefront per block.  The reference divides by the current range to get `count` and then searches the
+// symbol linearly (:199-209).  Here the 64 lanes evaluate the encoder's own interval bounds of all 80 symbols
+// of the context at once -- floor(range * cum[s+1] / total) through the same reciprocal fractions -- and one
+// ballot finds the symbol whose interval holds the code value: for v = code - lo,
+//   count >= cum[s]  <=>  v >= floor(range * cum[s] / total),   count < cum[s+1]  <=>  v < floor(range * cum[s+1] / total),
+// so the search is equivalent and no division is left.  The table row of the context is the one dependent
+// memory access per symbol (the context is only known once the previous symbol is out).
 struct AcDecArgs {
   const u8 *in;          // framed stream
   const u64 *blk_off;    // byte offset of each block's payload (after its size word)
   const u32 *blk_size;
   u64 nsym;
-  const u32 *cum;        // [6400][81]
+  const uint4 *tab;      // [6400][80] {g(lo), g(hi)} as built by ac_table_k
   u8 *out;
 };
 __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
@@ -464,47 +470,80 @@ __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
   if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
   if (p0 >= AC_D) p0 = AC_D - 1;  // corrupt stream: stay inside the tables
   if (p1 >= AC_D) p1 = AC_D - 1;
-  u64 bitpos = 16;
-  auto getbits = [&](u32 cnt) -> u32 {  // cnt <= 32, MSB first, zeros past the end
-    u64 v = 0;
-    const u64 byte = bitpos >> 3;
-    for (int k = 0; k < 6; k++) v = (v << 8) | (byte + k < insz ? in[byte + k] : 0u);
-    const u32 sh = 48 - (u32)(bitpos & 7) - cnt;
-    bitpos += cnt;
-    return cnt ? (u32)((v >> sh) & (cnt == 32 ? 0xFFFFFFFFull : ((1ull << cnt) - 1))) : 0u;
+  // bit reader: `win` holds the next `wb` bits of the stream, left aligned; refilled 32 bits at a time
+  u32 bytepos = 2;
+  auto word_at = [&](u32 pos) -> u32 {  // big-endian, zeros past the end of the block
+    u32 w = 0;
+    for (int k = 0; k < 4; k++) w = (w << 8) | (pos + k < insz ? (u32)in[pos + k] : 0u);
+    return w;
+  };
+  u64 win = ((u64)word_at(2) << 32) | word_at(6);
+  u32 wb = 64;
+  bytepos = 10;
+  u32 nextw = word_at(10);
+  auto getbits = [&](u32 cnt) -> u32 {  // cnt in 1..32
+    const u32 r = (u32)(win >> (64 - cnt));
+    win <<= cnt;
+    wb -= cnt;
+    if (wb <= 32) {
+      win |= (u64)nextw << (32 - wb);
+      wb += 32;
+      bytepos += 4;
+      nextw = word_at(bytepos);
+    }
+    return r;
   };
   u32 lo = 0, hi = 0xFFFFFFFFu, code = getbits(32);
+  // lane j keeps symbol (i & 63) == j until 64 are gathered; the two raw symbols sit in lanes 0 and 1
+  u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
   for (u32 i = 2; i < n; i++) {
-    const u32 *c = a.cum + (u64)(p0 * AC_D + p1) * 81;
-    const u32 tot = c[80];
-    const u64 range = (u64)(hi - lo) + 1;
-    const u32 count = (u32)((((u64)(code - lo) + 1) * tot - 1) / range);
-    // first symbol whose upper bound exceeds count: lanes test bounds lane+1 and lane+65
-    const u64 m0 = __ballot(count < c[lane + 1]);
-    const u64 m1 = __ballot(lane + 65 <= 80 && count < c[lane + 65 <= 80 ? lane + 65 : 80]);
-    const u32 k = m0 ? (u32)(__ffsll((long long)m0) - 1) : (m1 ? 64u + (u32)(__ffsll((long long)m1) - 1) : 79u);
-    const u32 chi = c[k + 1], clo = c[k];
-    hi = (u32)(lo + (range * chi) / tot - 1);
-    lo = (u32)(lo + (range * clo) / tot);
-    const u32 x = lo ^ hi;
-    const u32 kk = x ? (u32)__clz(x) : 32u;
-    if (kk) {
-      if (kk == 32) { lo = 0; hi = 0xFFFFFFFFu; code = getbits(32); }
-      else { lo <<= kk; hi = (hi << kk) | ((1u << kk) - 1); code = (code << kk) | getbits(kk); }
+    const uint4 *row = a.tab + (u64)(p0 * AC_D + p1) * AC_D;
+    const uint4 e0 = row[lane];
+    const uint4 e1 = lane < 16 ? row[64 + lane] : make_uint4(0, 0, 0, 0);
+    const u32 R = hi - lo, v = code - lo;
+    // upper bound of symbol `lane` (and 64 + lane) relative to lo; the last symbol of a context reaches the range itself
+    const bool last0 = e0.w == 0xFFFFFFFFu, last1 = e1.w == 0xFFFFFFFFu;
+    const u32 U0 = mulfrac(R, e0.z, e0.w), U1 = mulfrac(R, e1.z, e1.w);
+    const u64 m0 = __ballot(last0 || v < U0);
+    const u64 m1 = __ballot(lane < 16 && (last1 || v < U1));
+    u32 sidx, A, B;
+    bool is_last;
+    if (m0) {
+      sidx = (u32)__ffsll((long long)m0) - 1;
+      A = __builtin_amdgcn_readlane(U0, sidx);
+      is_last = __builtin_amdgcn_readlane((u32)last0, sidx) != 0;
+      B = sidx ? __builtin_amdgcn_readlane(U0, sidx - 1) : 0u;
+    } else {
+      const u32 t = m1 ? (u32)__ffsll((long long)m1) - 1 : 15u;  // corrupt stream: last symbol
+      sidx = 64 + t;
+      A = __builtin_amdgcn_readlane(U1, t);
+      is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
+      B = t ? __builtin_amdgcn_readlane(U1, t - 1) : __builtin_amdgcn_readlane(U0, 63);
     }
-    const u32 y = (lo & ~hi) << 1;
+    const u32 nhi = is_last ? hi : lo + A - 1;
+    const u32 nlo = lo + B;
+    // renormalisation exactly as the encoder's general closed form; the code register follows (:225-239)
+    const u32 x = nlo ^ nhi;
+    const u32 k = x ? (u32)__clz(x) : 32u;
+    u32 l1, h1;
+    if (k == 32) { l1 = 0; h1 = 0xFFFFFFFFu; code = getbits(32); }
+    else if (k) { l1 = nlo << k; h1 = (nhi << k) | ((1u << k) - 1); code = (code << k) | getbits(k); }
+    else { l1 = nlo; h1 = nhi; }
+    const u32 y = (l1 & ~h1) << 1;
     const u32 u = (u32)__clz(~y);
-    if (u) {  // each underflow step: code ^= 0x40000000 then shift in one bit (arithmetic.cpp:228-238)
-      lo = (lo << u) & 0x7FFFFFFFu;
-      hi = (hi << u) | ((1u << u) - 1) | 0x80000000u;
-      // u steps of code = ((code ^ 0x40000000) << 1) | bit: every step drops the top bit and promotes the
-      // inverted second bit, so after u steps the top bit is ~c[31-u] and the rest is code << u
-      code = ((code << u) ^ 0x80000000u) | getbits(u);
-    }
-    if (lane == 0) out[i] = (u8)k;
+    if (u) {
+      lo = (l1 << u) & 0x7FFFFFFFu;
+      hi = (h1 << u) | ((1u << u) - 1) | 0x80000000u;
+      code = ((code << u) ^ 0x80000000u) | getbits(u);  // u steps of code = ((code ^ 0x40000000) << 1) | bit
+    } else { lo = l1; hi = h1; }
+    outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
+    if ((i & 63) == 63) out[(i & ~63u) + lane] = (u8)outacc;  // 64 symbols per store
     p0 = p1;
-    p1 = k;
+    p1 = sidx;
   }
+  // tail of the last partial group
+  const u32 done = n & ~63u;
+  if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
 }
 
 // ---- self-test: closed-form step vs the reference's literal loop, on random and crafted states ------

@@ -1025,7 +1025,7 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
   HIP_TRY(c, hipMemcpyAsync(d_sz, sz.data(), sizeof(u32) * nblk, hipMemcpyHostToDevice, s));
   LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, d_table, d_tab, d_cum, (u32 *)nullptr);
   AcDecArgs a;
-  a.in = d_blocks; a.blk_off = d_off; a.blk_size = d_sz; a.nsym = nsym; a.cum = d_cum; a.out = d_out;
+  a.in = d_blocks; a.blk_off = d_off; a.blk_size = d_sz; a.nsym = nsym; a.tab = d_tab; a.out = d_out;
   LAUNCH(ac_decode_k, nblk, 64, 0, s, a);
   HIP_TRY(c, hipStreamSynchronize(s));
   hipFree(d_table); hipFree(d_cum); hipFree(d_tab); hipFree(d_off); hipFree(d_sz);
