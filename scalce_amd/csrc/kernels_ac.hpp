@@ -195,6 +195,7 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   __shared__ uint2 rec[2][64];
+  __shared__ uint4 stage[32][64];  // chain wave only: what every lane computed in every step of a half round
   __shared__ u32 buf[AC_BUF_WORDS];
   __shared__ u32 final_lo;
 
@@ -348,10 +349,10 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
             // the same state.  The state moves one lane per step (DPP wave_shr:1), so the operands never move.
             // Every lane executes every step; only the step that matches its lane is meaningful, its outcome is
             // latched.  All 64 lanes start from the round's state, which also feeds lane 32 in step 0.
-            u32 st_lo = lo, st_M = M0, recH = 0, recK = 0, eL = 0xFFFFFFFFu;
-            for (u32 st = 0; st < 32; st++) {
-              const u32 in_lo = __builtin_amdgcn_update_dpp(lo, st_lo, 0x138, 0xF, 0xF, false);  // wave_shr:1
-              const u32 in_M = __builtin_amdgcn_update_dpp(M0, st_M, 0x138, 0xF, 0xF, false);
+            // No latching in the loop: every lane drops what it computed in every step into LDS (one ds_write_b128);
+            // afterwards lane l picks entry [l][l], the only step in which it held the true state.
+            u32 st_lo = lo, st_M = M0;
+            auto step = [&](u32 in_lo, u32 in_M, u32 stp) {
               const u32 Q = (u32)(((u64)in_M * ops.y + __umulhi(in_M, ops.x)) >> 32);
               const auto sw = __builtin_amdgcn_permlane32_swap(Q, Q, false, false);
               const u32 A = sw[0], B = sw[1];  // quotient of the upper / lower bound, in both lanes of the pair
@@ -364,15 +365,21 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
               st_lo = ((nlo << k) << u) & 0x7FFFFFFFu;
               st_M = (W << k) << u;                       // renormalising by k + u bits scales the range by 2^(k+u)
               const u32 e = x < st_M ? x : st_M;          // 0 iff x == 0 or the range wrapped to 2^32
-              const bool mine = (u32)(lane & 31) == st;
-              recH = mine ? nhi : recH;
-              recK = mine ? (k | (u << 8)) : recK;
-              eL = mine ? e : eL;
+              stage[stp][lane] = make_uint4(nhi, k, u, e);
+            };
+            step(lo, M0, 0);  // step 0: every lane (lanes 0 and 32 matter) starts from the round's state
+#pragma unroll
+            for (u32 stp = 1; stp < 32; stp++) {
+              // wave_shr:1, bound_ctrl: lane l takes the state lane l-1 produced in the previous step
+              const u32 in_lo = __builtin_amdgcn_mov_dpp(st_lo, 0x138, 0xF, 0xF, true);
+              const u32 in_M = __builtin_amdgcn_mov_dpp(st_M, 0x138, 0xF, 0xF, true);
+              step(in_lo, in_M, stp);
             }
-            if (!__any(eL == 0)) {  // else (rare): a step needs the general path; redo the half below
+            const uint4 d = stage[lane & 31][lane & 31];
+            if (!__any(lane < 32 && d.w == 0)) {  // else (rare): a step needs the general path; redo the half below
               lo = __builtin_amdgcn_readlane(st_lo, 31);
               hi = lo + __builtin_amdgcn_readlane(st_M, 31) - 1;
-              if (lane < 32) rc[lane] = make_uint2(recH, recK);
+              if (lane < 32) rc[lane] = make_uint2(d.x, d.y | (d.z << 8));
               done = true;
             }
           }
