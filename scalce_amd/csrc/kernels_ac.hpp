@@ -168,6 +168,77 @@ __device__ __forceinline__ u32 ac_step_plain(u32 &lo, u32 &M, const uint4 g, u32
   return x < M ? x : M;                      // 0 iff x == 0 or the range wrapped to 2^32
 }
 
+// ---- systolic plain round ----------------------------------------------------------------------
+// 64 plain steps (see ac_step_plain) of one round.  Lane s holds the operands of symbol s; the state (lo, M)
+// walks one lane per step with DPP wave_shr:1, so operands never move and nothing is broadcast.  Every lane
+// executes every step, only step s is meaningful for lane s.  A lone wave issues one instruction per 4 cycles
+// whether it depends on the previous one or not (tools/ubench_issue2.hip), so the cost of a symbol is the
+// number of instructions in a step and nothing else.  Hence:
+//   * no outcome leaves the loop.  Each lane only keeps the state it received in ITS step; after the loop all
+//     64 lanes redo their own symbol at once (k, u, hi-before-shift, exit test).
+//   * keeping costs nothing: the DPP moves that bring the state in are restricted to the quad of lane s by
+//     their row_mask / bank_mask (write enables per 16 and per 4 lanes), and consecutive steps write four
+//     rotating register sets, so what lane s received in step s is never overwritten.
+//   * lo travels without its bit 31 cleared ((nlo << t) & 0x7FFFFFFF in ac_step_plain): a stray bit 31 flips
+//     bit 31 of nlo and nhi alike, which changes neither x = nlo ^ nhi nor the underflow count (its mask is
+//     shifted left by one), and is shifted out or carried as is.  The caller removes it afterwards.
+// Per step: dpp mov, 2 x (mul_hi, mad), sub, dpp add, add3, xor, ffbh, bitop, lshl_or, lshl, ffbh, add, 2 x lshl.
+struct SysState {
+  u32 kM[4], nl[4];  // per lane: range received / lo + B computed in the lane's own step (set = lane & 3)
+};
+template <int S>
+__device__ __forceinline__ void sys_step(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
+  constexpr int Q = S & 3;
+  constexpr int RM = 1 << (S >> 4), BM = 1 << ((S & 15) >> 2);
+  // lane l takes the state lane l-1 produced in the previous step; only the quad of lane S is written
+  st.kM[Q] = __builtin_amdgcn_update_dpp(st.kM[Q], tM, 0x138, RM, BM, false);
+  const u32 M = st.kM[Q];
+  const u32 A = (u32)(((u64)M * ops.w + __umulhi(M, ops.z)) >> 32);
+  const u32 B = (u32)(((u64)M * ops.y + __umulhi(M, ops.x)) >> 32);
+  const u32 W = A - B;  // new range before renormalisation
+  // nl = lo(from lane l-1) + B in one instruction; tlo was written many instructions ago (DPP read hazard)
+  asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:%3 bank_mask:%4"
+      : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(RM), "n"(BM));
+  const u32 nlo = st.nl[Q];
+  const u32 nhi = nlo + W - 1;
+  const u32 k = ffbh_raw(nlo ^ nhi);           // x == 0: garbage, found by the caller's exit test
+  const u32 c1 = ((~nlo | nhi) << 1) | 1u;     // see ac_step_plain
+  const u32 t = k + ffbh_raw(c1 << k);
+  tM = W << t;                                 // renormalising by t bits scales the range by 2^t
+  tlo = nlo << t;
+}
+template <int S, int E>
+struct SysLoop {
+  static __device__ __forceinline__ void run(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
+    sys_step<S>(st, tlo, tM, ops);
+    SysLoop<S + 1, E>::run(st, tlo, tM, ops);
+  }
+};
+template <int E>
+struct SysLoop<E, E> {
+  static __device__ __forceinline__ void run(SysState &, u32 &, u32 &, const uint4 &) {}
+};
+__device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const uint4 &ops) {
+  // step 0: every lane starts from the round's state (lane 0 is the one that matters)
+  u32 tlo, tM;
+  {
+    st.kM[0] = M0;
+    st.kM[1] = st.kM[2] = st.kM[3] = 0;
+    const u32 A = (u32)(((u64)M0 * ops.w + __umulhi(M0, ops.z)) >> 32);
+    const u32 B = (u32)(((u64)M0 * ops.y + __umulhi(M0, ops.x)) >> 32);
+    const u32 W = A - B;
+    st.nl[0] = lo + B;
+    st.nl[1] = st.nl[2] = st.nl[3] = 0;
+    const u32 nlo = st.nl[0], nhi = nlo + W - 1;
+    const u32 k = ffbh_raw(nlo ^ nhi);
+    const u32 c1 = ((~nlo | nhi) << 1) | 1u;
+    const u32 t = k + ffbh_raw(c1 << k);
+    tM = W << t;
+    tlo = nlo << t;
+  }
+  SysLoop<1, 64>::run(st, tlo, tM, ops);
+}
+
 // ---- encoder -----------------------------------------------------------------------------------
 // One workgroup of two wavefronts per 10 MiB block, 64 symbols per round:
 //   wave 1, gather  (64 lanes)  operands of round r+1: context -> {g(lo), g(hi)} from the table -> LDS
@@ -195,7 +266,6 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   __shared__ uint2 rec[2][64];
-  __shared__ uint4 stage[32][64];  // chain wave only: what every lane computed in every step of a half round
   __shared__ u32 buf[AC_BUF_WORDS];
   __shared__ u32 final_lo;
 
@@ -218,15 +288,14 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   // ---- chain-wave state ----
   u32 lo = 0, hi = 0xFFFFFFFFu;
 
-  // operands of the 32 symbols [base, base + 32): lane l serves symbol base + (l & 31); lanes 0..31 fetch the
-  // reciprocal fraction of the symbol's upper bound g(hi), lanes 32..63 that of its lower bound g(lo)
-  auto gather = [&](u32 base) -> uint2 {
-    const u32 i = base + (lane & 31);
-    if (i < 2 || i >= n) return make_uint2(0, 0);
+  // operands of the 64 symbols [base, base + 64): lane l serves symbol base + l with both reciprocal fractions
+  // {g(lo), g(hi)} of its interval bounds
+  auto gather = [&](u32 base) -> uint4 {
+    const u32 i = base + lane;
+    if (i < 2 || i >= n) return make_uint4(0, 0, 0, 0);
     const u32 p0 = s[i - 2], p1 = s[i - 1], c = s[i];
-    if (p0 >= AC_D || p1 >= AC_D || c >= AC_D) return make_uint2(0, 0);  // E_SYMBOL was raised at ingest
-    const uint2 *e = reinterpret_cast<const uint2 *>(a.tab + ((u64)p0 * AC_D + p1) * AC_D + c);
-    return e[lane < 32 ? 1 : 0];
+    if (p0 >= AC_D || p1 >= AC_D || c >= AC_D) return make_uint4(0, 0, 0, 0);  // E_SYMBOL was raised at ingest
+    return a.tab[((u64)p0 * AC_D + p1) * AC_D + c];
   };
 
   // uniform append of nb <= 32 bits (every lane of the helper wave passes the same values): used by the
@@ -317,86 +386,64 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   };
 
   if (!chain_wave) carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
-  // chain wave: the operands of a round (two halves of 32 symbols) are fetched a round ahead
-  uint2 curA = chain_wave ? gather(0) : make_uint2(0, 0), curB = chain_wave ? gather(32) : make_uint2(0, 0);
+  // chain wave: the operands of a round (64 symbols, one per lane) are fetched a round ahead
+  uint4 cur = chain_wave ? gather(0) : make_uint4(0, 0, 0, 0);
   for (u32 r = 0; r < nrounds; r++) {
     const u32 base = r << 6;
     if (chain_wave) {
-      const uint2 opsA = curA, opsB = curB;
-      if (base + 64 < n && !(a.debug & 4)) {  // in flight during this round's chain
-        curA = gather(base + 64);
-        curB = gather(base + 96);
-      }
+      const uint4 ops = cur;
+      if (base + 64 < n && !(a.debug & 4)) cur = gather(base + 64);  // in flight during this round's chain
       if ((a.debug & 1) && lane == 0) {  // profiling: no coder work, only well-formed empty outcomes
         for (int j = 0; j < 64; j++) rec[r & 1][j] = make_uint2(0u, 0u);
         if (r + 1 == nrounds) final_lo = 0;
       }
       if (!(a.debug & 1)) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const uint2 ops = h ? opsB : opsA;
-          const u32 hbase = base + 32 * h;
-          if (hbase >= n) break;
-          const u32 cnt = (n - hbase) < 32 ? (n - hbase) : 32;
-          uint2 *rc = rec[r & 1] + 32 * h;
-          u32 j = (r == 0 && h == 0) ? 2u : 0u;
-          const u32 M0 = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
-          bool done = false;
-          if (!GENERAL && cnt == 32 && j == 0 && M0 != 0 && !__any(lane < 32 && ops.y == 0xFFFFFFFFu)) {
-            // Systolic plain steps.  Step s is the work of lane pair (s, s + 32): the lower lane multiplies
-            // the range by g(hi), the upper one by g(lo) -- ONE v_mul_hi_u32 + ONE v_mad_u64_u32 serve both
-            // quotients -- v_permlane32_swap hands each lane the other's quotient, and both lanes then advance
-            // the same state.  The state moves one lane per step (DPP wave_shr:1), so the operands never move.
-            // Every lane executes every step; only the step that matches its lane is meaningful, its outcome is
-            // latched.  All 64 lanes start from the round's state, which also feeds lane 32 in step 0.
-            // No latching in the loop: every lane drops what it computed in every step into LDS (one ds_write_b128);
-            // afterwards lane l picks entry [l][l], the only step in which it held the true state.
-            u32 st_lo = lo, st_M = M0;
-            auto step = [&](u32 in_lo, u32 in_M, u32 stp) {
-              const u32 Q = (u32)(((u64)in_M * ops.y + __umulhi(in_M, ops.x)) >> 32);
-              const auto sw = __builtin_amdgcn_permlane32_swap(Q, Q, false, false);
-              const u32 A = sw[0], B = sw[1];  // quotient of the upper / lower bound, in both lanes of the pair
-              const u32 W = A - B;             // new range before renormalisation
-              const u32 nlo = in_lo + B, nhi = in_lo + A - 1;
-              const u32 x = nlo ^ nhi;
-              const u32 k = ffbh_raw(x);                  // x == 0: garbage, flagged through e
-              const u32 c1 = ((~nlo | nhi) << 1) | 1u;    // see ac_step_plain
-              const u32 u = ffbh_raw(c1 << k);
-              st_lo = ((nlo << k) << u) & 0x7FFFFFFFu;
-              st_M = (W << k) << u;                       // renormalising by k + u bits scales the range by 2^(k+u)
-              const u32 e = x < st_M ? x : st_M;          // 0 iff x == 0 or the range wrapped to 2^32
-              stage[stp][lane] = make_uint4(nhi, k, u, e);
-            };
-            step(lo, M0, 0);  // step 0: every lane (lanes 0 and 32 matter) starts from the round's state
-#pragma unroll
-            for (u32 stp = 1; stp < 32; stp++) {
-              // wave_shr:1, bound_ctrl: lane l takes the state lane l-1 produced in the previous step
-              const u32 in_lo = __builtin_amdgcn_mov_dpp(st_lo, 0x138, 0xF, 0xF, true);
-              const u32 in_M = __builtin_amdgcn_mov_dpp(st_M, 0x138, 0xF, 0xF, true);
-              step(in_lo, in_M, stp);
-            }
-            const uint4 d = stage[lane & 31][lane & 31];
-            if (!__any(lane < 32 && d.w == 0)) {  // else (rare): a step needs the general path; redo the half below
-              lo = __builtin_amdgcn_readlane(st_lo, 31);
-              hi = lo + __builtin_amdgcn_readlane(st_M, 31) - 1;
-              if (lane < 32) rc[lane] = make_uint2(d.x, d.y | (d.z << 8));
-              done = true;
+        const u32 cnt = (n - base) < 64 ? (n - base) : 64;
+        uint2 *rc = rec[r & 1];
+        u32 j = (r == 0) ? 2u : 0u;
+        const u32 M0 = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
+        bool done = false;
+        if (!GENERAL && cnt == 64 && j == 0 && M0 != 0 && !__any(ops.w == 0xFFFFFFFFu)) {
+          SysState st;
+          sys_round(st, lo, M0, ops);
+          // every lane now redoes its own symbol from the state it latched: outcome for the helper wave, exit test
+          const int q = lane & 3;
+          const u32 inM = q == 0 ? st.kM[0] : q == 1 ? st.kM[1] : q == 2 ? st.kM[2] : st.kM[3];
+          const u32 nlo = q == 0 ? st.nl[0] : q == 1 ? st.nl[1] : q == 2 ? st.nl[2] : st.nl[3];
+          const u32 A = (u32)(((u64)inM * ops.w + __umulhi(inM, ops.z)) >> 32);
+          const u32 B = (u32)(((u64)inM * ops.y + __umulhi(inM, ops.x)) >> 32);
+          const u32 W = A - B;
+          const u32 nhi = nlo + W - 1;
+          const u32 x = nlo ^ nhi;
+          const u32 k = ffbh_raw(x);
+          const u32 c1 = ((~nlo | nhi) << 1) | 1u;
+          const u32 u = ffbh_raw(c1 << k);
+          const u32 olo = nlo << (k + u), oM = W << (k + u);
+          // bit 31 of the travelling lo is not cleared in the loop (see sys_step): the lane's nlo / nhi carry the
+          // stray bit of the state it received, which is bit 31 of what its left neighbour sent
+          u32 prev = __builtin_amdgcn_update_dpp(0u, olo, 0x138, 0xF, 0xF, false);
+          const u32 stray = prev & 0x80000000u;
+          const bool bad = x == 0 || oM == 0;   // 32 agreeing bits, or the range renormalised to the full 2^32
+          if (!__any(bad)) {  // else (rare): a step needs the general path; redo the round below
+            lo = __builtin_amdgcn_readlane(olo, 63) & 0x7FFFFFFFu;
+            hi = lo + __builtin_amdgcn_readlane(oM, 63) - 1;
+            rc[lane] = make_uint2(nhi ^ stray, k | (u << 8));
+            done = true;
+          }
+        }
+        if (!done) {  // general steps on lane 0: first round, last-of-context symbols, full interval, tails
+          u32 glo = lo, ghi = hi;
+          if (lane == 0) {
+            for (; j < cnt; j++) {
+              const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops.x, j), __builtin_amdgcn_readlane(ops.y, j),
+                                         __builtin_amdgcn_readlane(ops.z, j), __builtin_amdgcn_readlane(ops.w, j));
+              u32 hbefore;
+              const u32 ku = ac_step<GENERAL>(glo, ghi, g, hbefore);
+              rc[j] = make_uint2(hbefore, ku);
             }
           }
-          if (!done) {  // general steps on lane 0: first round, last-of-context symbols, full interval, tails
-            u32 glo = lo, ghi = hi;
-            if (lane == 0) {
-              for (; j < cnt; j++) {
-                const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops.x, j + 32), __builtin_amdgcn_readlane(ops.y, j + 32),
-                                           __builtin_amdgcn_readlane(ops.x, j), __builtin_amdgcn_readlane(ops.y, j));
-                u32 hbefore;
-                const u32 ku = ac_step<GENERAL>(glo, ghi, g, hbefore);
-                rc[j] = make_uint2(hbefore, ku);
-              }
-            }
-            lo = __builtin_amdgcn_readfirstlane(glo);
-            hi = __builtin_amdgcn_readfirstlane(ghi);
-          }
+          lo = __builtin_amdgcn_readfirstlane(glo);
+          hi = __builtin_amdgcn_readfirstlane(ghi);
         }
         if (r + 1 == nrounds && lane == 0) final_lo = lo;
       }
