@@ -201,9 +201,9 @@ __device__ __forceinline__ void sys_step(SysState &st, u32 &tlo, u32 &tM, const 
       : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(RM), "n"(BM));
   const u32 nlo = st.nl[Q];
   const u32 nhi = nlo + W - 1;
-  const u32 k = ffbh_raw(nlo ^ nhi);           // x == 0: garbage, found by the caller's exit test
+  const u32 k = (u32)__builtin_clz(nlo ^ nhi);           // x == 0: garbage, found by the caller's exit test
   const u32 c1 = ((~nlo | nhi) << 1) | 1u;     // see ac_step_plain
-  const u32 t = k + ffbh_raw(c1 << k);
+  const u32 t = k + (u32)__builtin_clz(c1 << k);
   tM = W << t;                                 // renormalising by t bits scales the range by 2^t
   tlo = nlo << t;
 }
@@ -230,9 +230,9 @@ __device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const ui
     st.nl[0] = lo + B;
     st.nl[1] = st.nl[2] = st.nl[3] = 0;
     const u32 nlo = st.nl[0], nhi = nlo + W - 1;
-    const u32 k = ffbh_raw(nlo ^ nhi);
+    const u32 k = (u32)__builtin_clz(nlo ^ nhi);
     const u32 c1 = ((~nlo | nhi) << 1) | 1u;
-    const u32 t = k + ffbh_raw(c1 << k);
+    const u32 t = k + (u32)__builtin_clz(c1 << k);
     tM = W << t;
     tlo = nlo << t;
   }
@@ -386,13 +386,32 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   };
 
   if (!chain_wave) carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
-  // chain wave: the operands of a round (64 symbols, one per lane) are fetched a round ahead
+  // chain wave: operands are fetched a round ahead and the symbols they are looked up with two rounds ahead, so
+  // no load of a round waits for another load of the same round (the table address needs the symbol bytes)
+  auto sym_at = [&](u32 i) -> u32 { return i < n ? (u32)s[i] : 0u; };
   uint4 cur = chain_wave ? gather(0) : make_uint4(0, 0, 0, 0);
+  u32 sy_cur = chain_wave ? sym_at(lane) : 0u;        // symbols of this round (contexts of the next one's first lanes)
+  u32 sy_nxt = chain_wave ? sym_at(64 + lane) : 0u;   // symbols of the next round
+  // every load of the prologue has landed before the loop starts: otherwise the compiler cannot tell inside the
+  // loop whether `cur` is still in flight and waits for ALL loads (including the ones just issued for the next
+  // round) in front of every round's chain
+  asm volatile("; prologue operands landed" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w), "+v"(sy_cur), "+v"(sy_nxt));
   for (u32 r = 0; r < nrounds; r++) {
     const u32 base = r << 6;
     if (chain_wave) {
       const uint4 ops = cur;
-      if (base + 64 < n && !(a.debug & 4)) cur = gather(base + 64);  // in flight during this round's chain
+      uint4 nxt = make_uint4(0, 0, 0, 0);
+      u32 sy_nn = 0;
+      if (base + 64 < n && !(a.debug & 4)) {  // in flight during this round's chain
+        // contexts: p1 = symbol of lane - 1, p0 = symbol of lane - 2; lanes 0 and 1 reach into this round's symbols
+        const u32 e63 = __builtin_amdgcn_readlane(sy_cur, 63), e62 = __builtin_amdgcn_readlane(sy_cur, 62);
+        const u32 p1 = __builtin_amdgcn_update_dpp(e63, sy_nxt, 0x138, 0xF, 0xF, false);
+        const u32 p0 = __builtin_amdgcn_update_dpp(e62, p1, 0x138, 0xF, 0xF, false);
+        const u32 D1 = AC_D - 1;  // symbols >= AC_D raised E_SYMBOL at ingest; stay inside the table regardless
+        const u32 c = sy_nxt < D1 ? sy_nxt : D1, q1 = p1 < D1 ? p1 : D1, q0 = p0 < D1 ? p0 : D1;
+        if (base + 64 + lane < n) nxt = a.tab[(q0 * AC_D + q1) * AC_D + c];
+        sy_nn = sym_at(base + 128 + lane);
+      }
       if ((a.debug & 1) && lane == 0) {  // profiling: no coder work, only well-formed empty outcomes
         for (int j = 0; j < 64; j++) rec[r & 1][j] = make_uint2(0u, 0u);
         if (r + 1 == nrounds) final_lo = 0;
@@ -447,6 +466,9 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
         }
         if (r + 1 == nrounds && lane == 0) final_lo = lo;
       }
+      cur = nxt;
+      sy_cur = sy_nxt;
+      sy_nxt = sy_nn;
     } else {
       if (r > 0 && !(a.debug & 2)) {
         const uint2 v = rec[(r - 1) & 1][lane];
