@@ -117,10 +117,20 @@ int scalce_batch_emit(scalce_batch *b, void *stream);
  * d_table_override (512000 x u32 per mate, already scaled) replaces this shard's own
  * statistics when the run-wide table was reduced across shards; NULL = use own. */
 int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream);
+/* The same stage in two halves, for callers that keep several shards in flight: _begin only enqueues (table,
+ * coder, framing -- one short wait for the table's largest context total, none for the coder), so the caller
+ * can run the front stages of the next shard on another stream while the coder -- a long kernel that leaves
+ * most of the chip idle, one wavefront per 10 MiB block -- works in the background; _end (or
+ * scalce_batch_finish) waits for it and fills in the size of SCALCE_OUT_QUAL.  This is the device-side
+ * counterpart of the reference coding `-T` blocks per batch on its thread pool (arithmetic.cpp:349-357). */
+int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_table_override, void *stream);
+int scalce_batch_entropy_end(scalce_batch *b, void *stream);
 /* Sharded runs: code a caller-assembled range of the run-wide reordered stream (it must start on a 10 MiB
  * block boundary) against the run-wide table; result in SCALCE_OUT_QUAL of `mate`. */
 int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
                                 uint64_t nsym, void *stream);
+int scalce_batch_entropy_stream_begin(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                      uint64_t nsym, void *stream);
 /* Piecewise device copy: dst[piece_dst[p] + i] = src[piece_src[p] + i]; pieces contiguous in src, sorted. */
 int scalce_copy_pieces(scalce_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, const uint64_t *d_piece_src,
                        const uint64_t *d_piece_dst, uint32_t npieces, uint64_t total_bytes, void *stream);

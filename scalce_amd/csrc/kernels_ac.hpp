@@ -203,9 +203,12 @@ __device__ __forceinline__ void sys_step(SysState &st, u32 &tlo, u32 &tM, const 
   const u32 nhi = nlo + W - 1;
   const u32 k = (u32)__builtin_clz(nlo ^ nhi);           // x == 0: garbage, found by the caller's exit test
   const u32 c1 = ((~nlo | nhi) << 1) | 1u;     // see ac_step_plain
-  const u32 t = k + (u32)__builtin_clz(c1 << k);
-  tM = W << t;                                 // renormalising by t bits scales the range by 2^t
-  tlo = nlo << t;
+  const u32 Wk = W << k;
+  const u32 u = (u32)__builtin_clz(c1 << k);
+  // renormalising by k + u bits scales the range by 2^(k+u).  tM is finished two instructions before the next
+  // step's DPP move reads it (a DPP read needs two wait states after the write; this way they are not s_nops)
+  tM = Wk << u;
+  tlo = nlo << (k + u);
 }
 template <int S, int E>
 struct SysLoop {
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   const bool chain_wave = wave_id() == 0;
   const u32 nrounds = (n + 63) >> 6;
 
+  if (chain_wave) __builtin_amdgcn_s_setprio(3);  // the chain owns its SIMD's issue slots; whatever else lands there gets the gaps
   // ---- helper-wave state (bit sink) ----
   u32 *dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
   const u32 wcap = a.out_cap / 4;

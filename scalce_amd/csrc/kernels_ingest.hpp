@@ -290,8 +290,7 @@ __global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
 // counters to the global table.  Slices whose leading symbols never occur exit at once
 // (symbol histogram from sym_hist_k), so a 40-symbol alphabet costs 8 streaming passes.
 constexpr int TRI_W = 5;
-constexpr int TRI_THREADS = 1024;
-constexpr int TRI_SLICE = TRI_W * 80 * 80;
+constexpr int TRI_THREADS = 512;
 
 __global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist /*[256]*/) {
   __shared__ u32 h[256];
@@ -312,8 +311,10 @@ __global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist 
   if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)h[threadIdx.x]);
 }
 
+template <int TRI_THREADS, int TRI_W>
 __global__ __launch_bounds__(TRI_THREADS) void trigram_slice_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 p0_lo,
                                                               const u64 *sym_hist, u64 *freq4) {
+  constexpr int TRI_SLICE = TRI_W * 80 * 80;
   __shared__ u32 tab[TRI_SLICE];  // 128 000 B of the CU's 160 KB
   {  // nothing to count when none of this slice's leading symbols occurs (incl. the carried-in ones)
     bool any = false;

@@ -195,6 +195,8 @@ struct scalce_batch {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
   size_t kev_used = 0;
   u64 k_in_bytes = 0, k_out_bytes = 0;
+  // entropy launched but its result size not read back yet (scalce_batch_entropy_begin / _end): blocks per mate
+  u32 ent_pending[2] = {0, 0};
 };
 
 static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
@@ -401,8 +403,11 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     u64 *hist = b->d_small64 + 16;  // 256 symbol counters live behind the scalar scratch
     HIP_TRY(c, hipMemsetAsync(hist, 0, sizeof(u64) * 256, s));
     LAUNCH(sym_hist_k, 2048, 256, 0, s, b->q[m].as<u8>(), n, hist);
+    // 512-thread workgroups: with 1024 threads a workgroup needs four free wave slots on every SIMD of a CU at once
+    // and does not get placed while another shard's arithmetic coder is resident (measured: the stage then takes as
+    // long as the coder has left to run); 512 threads cost 11 ms more when the stage runs alone
     for (u32 p0 = 0; p0 < 80; p0 += TRI_W)
-      LAUNCH(trigram_slice_k, 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0],
+      LAUNCH((trigram_slice_k<TRI_THREADS, TRI_W>), 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0],
              b->p.qprev[m][1], p0, hist, b->freq4[m].as<u64>());
   }
   return SCALCE_OK;
@@ -808,23 +813,35 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
   b->k_in_bytes += nsym;
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nblk) + 64));
   exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
-                      b->d_small64 + 8, s);
-  u64 total = 0;
-  { int rc = read_u64(b, b->d_small64 + 8, &total, 1, s); if (rc) return rc; }
-  b->out_qual_bytes[m] = total;
-  b->k_out_bytes += total - 4ull * nblk;
-  ENSURE(b, b->out_qual[m], total + 64);
+                      b->d_small64 + 8 + m, s);
+  // no host round trip here: the framed stream is sized for the worst case (every block at its cap) and the
+  // frame kernel takes the block sizes from the device, so the whole stage is enqueued behind the coder and the
+  // caller may go on with another shard (scalce_batch_entropy_begin); the total is read back by entropy_collect
+  ENSURE(b, b->out_qual[m], (size_t)nblk * (stride + 4) + 64);
   LAUNCH(ac_frame_k, dim3(cdiv(stride, 16 * 256), nblk), 256, 0, s, b->ac_blocks.as<u8>(), stride, b->ac_sizes.as<u32>(),
          b->ac_off.as<u64>(), b->out_qual[m].as<u8>());
+  b->ent_pending[m] = nblk;
   return SCALCE_OK;
 }
 
-extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream) {
+// second half of the entropy stage: wait for the coder and read the size of the framed stream(s)
+static int entropy_collect(scalce_batch *b, hipStream_t s) {
+  for (int m = 0; m < b->nm; m++) {
+    if (!b->ent_pending[m]) continue;
+    u64 total = 0;
+    { int rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s); if (rc) return rc; }
+    b->out_qual_bytes[m] = total;
+    b->k_out_bytes += total - 4ull * b->ent_pending[m];
+    b->ent_pending[m] = 0;
+  }
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_table_override, void *stream) {
   if (!b) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
-  StageTimer tm(b, ST_ENTROPY, s);
   const u64 N = b->N;
   for (int m = 0; m < b->nm; m++) {
     const u64 nsym = N * (u64)b->L[m];
@@ -845,17 +862,38 @@ extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_ove
   return SCALCE_OK;
 }
 
+extern "C" int scalce_batch_entropy_end(scalce_batch *b, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  return entropy_collect(b, (hipStream_t)stream);
+}
+
+extern "C" int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  StageTimer tm(b, ST_ENTROPY, (hipStream_t)stream);
+  int rc = scalce_batch_entropy_begin(b, d_table_override, stream);
+  if (rc) return rc;
+  return entropy_collect(b, (hipStream_t)stream);
+}
+
 // Sharded runs: code `nsym` symbols of mate `mate` that the caller assembled on the device (a range of the
 // run-wide reordered stream that starts on a 10 MiB block boundary) against the run-wide table.
-extern "C" int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
-                                           uint64_t nsym, void *stream) {
+extern "C" int scalce_batch_entropy_stream_begin(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                                 uint64_t nsym, void *stream) {
   if (!b || mate < 0 || mate >= b->nm || !d_table || (nsym && !d_symbols) || b->p.no_ac) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
-  StageTimer tm(b, ST_ENTROPY, s);
   HIP_TRY(c, hipMemcpyAsync(b->table[mate].p, d_table, sizeof(u32) * 512000, hipMemcpyDeviceToDevice, s));
   return encode_stream(b, mate, d_symbols, nsym, s);
+}
+extern "C" int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                           uint64_t nsym, void *stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  StageTimer tm(b, ST_ENTROPY, (hipStream_t)stream);
+  int rc = scalce_batch_entropy_stream_begin(b, mate, d_table, d_symbols, nsym, stream);
+  if (rc) return rc;
+  return entropy_collect(b, (hipStream_t)stream);
 }
 
 // dst[piece_dst[p] + i] = src[piece_src[p] + i] for i < piece_len[p]; pieces sorted by piece_src, contiguous in src
@@ -889,6 +927,7 @@ extern "C" int scalce_batch_finish(scalce_batch *b, void *stream) {
   HIP_TRY(b->ctx, hipStreamSynchronize(s));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { set_err(b->ctx, "kernel launch failed: %s", hipGetErrorString(e)); return SCALCE_ERR_HIP; }
+  { int rc = entropy_collect(b, s); if (rc) return rc; }
   return check_device_error(b, s);
 }
 

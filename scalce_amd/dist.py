@@ -211,10 +211,16 @@ class ShardResult:
     pass
 
 
-def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, stream=0):
+def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, stream=0, ent_stream=None):
     """SPMD: every rank calls this with its own shard.  Leaves the rank's pieces of the archive in `batch`
     (reads/names payload of the shard, AC blocks of the rank's block range) and returns the metadata needed to
-    assemble or to report."""
+    assemble or to report.
+
+    `stream` (raw handle) must be torch's current stream.  With `ent_stream` (a torch.cuda.Stream) the arithmetic
+    coder is only enqueued there, behind everything issued so far, and the call returns while it runs: the
+    caller owes a `batch.finish(ent_stream.cuda_stream)` before it reads the result or reuses `batch`, and can
+    start the next shard's front stages (and their collectives, still issued in program order on every rank)
+    in the meantime."""
     import torch
     dev = torch.device("cuda", ctx_device(ctx))
     p = batch.params
@@ -243,7 +249,7 @@ def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, st
             if qn >= 2:
                 ctx.copy_d2d(e.data_ptr(), qp, 2, stream)
                 ctx.copy_d2d(e.data_ptr() + 2, qp + qn - 2, 2, stream)
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
             edges = comm.all_gather(e).cpu().numpy()
             keys = boundary_trigrams(edges, [int(x) * L[m] for x in n_all])
             if keys:
@@ -259,7 +265,7 @@ def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, st
         cp, cn = batch.output_ptr(host.OUT_BUCKET_COUNTS, 0)
         counts = torch.empty(cn // 8, dtype=torch.int64, device=dev)
         ctx.copy_d2d(counts.data_ptr(), cp, cn, stream)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         allc = comm.all_gather(counts)                       # [world, nb1]
         prior = allc[:comm.rank].sum(dim=0) if comm.rank else torch.zeros_like(counts)
         changed = batch.tokenize_sweep(prior.data_ptr(), stream)
@@ -274,28 +280,35 @@ def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, st
     cp, cn = batch.output_ptr(host.OUT_BUCKET_COUNTS, 0)
     counts = torch.empty(cn // 8, dtype=torch.int64, device=dev)
     ctx.copy_d2d(counts.data_ptr(), cp, cn, stream)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()
     C = comm.all_gather(counts).cpu().numpy()
     res.C = C
     # ---- run-wide block ranges of the reordered quality stream, all-to-all, code
     res.plans = []
+    keep = []
     if not p.no_ac:
         for m in range(nm):
             plan = stream_plan(C, L[m], comm.rank)
             qsp, qsn = batch.output_ptr(host.OUT_QSTREAM, m)
             local = torch.empty(qsn, dtype=torch.uint8, device=dev)
             ctx.copy_d2d(local.data_ptr(), qsp, qsn, stream)
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
             got = comm.all_to_all(local, plan["send"], plan["recv"])
             mine = torch.empty(plan["hi"] - plan["lo"] + 16, dtype=torch.uint8, device=dev)
             if got.numel():
                 ps = torch.from_numpy(plan["piece_src"].astype(np.int64)).to(dev)
                 pd = torch.from_numpy(plan["piece_dst"].astype(np.int64)).to(dev)
                 ctx.copy_pieces(got.data_ptr(), mine.data_ptr(), ps.data_ptr(), pd.data_ptr(), ps.numel(), got.numel(), stream)
-            batch.entropy_stream(m, tables[m].data_ptr(), mine.data_ptr(), plan["hi"] - plan["lo"], stream)
-            batch.finish(stream)
-            batch._keep_alive = (local, got, mine)
+            if ent_stream is None:
+                batch.entropy_stream(m, tables[m].data_ptr(), mine.data_ptr(), plan["hi"] - plan["lo"], stream)
+                batch.finish(stream)
+            else:
+                ent_stream.wait_stream(torch.cuda.current_stream())
+                batch.entropy_stream_begin(m, tables[m].data_ptr(), mine.data_ptr(), plan["hi"] - plan["lo"],
+                                           ent_stream.cuda_stream)
+            keep.append((local, got, mine, tables[m]))
             res.plans.append(plan)
+    batch._keep_alive = keep  # read by the coder after this call returns
     return res
 
 

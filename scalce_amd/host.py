@@ -77,6 +77,9 @@ def lib():
     L.scalce_batch_order.argtypes = [vp, vp]
     L.scalce_batch_emit.argtypes = [vp, vp]
     L.scalce_batch_entropy.argtypes = [vp, vp, vp]
+    L.scalce_batch_entropy_begin.argtypes = [vp, vp, vp]
+    L.scalce_batch_entropy_end.argtypes = [vp, vp]
+    L.scalce_batch_entropy_stream_begin.argtypes = [vp, i32, vp, vp, u64, vp]
     L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
     L.scalce_batch_finish.argtypes = [vp, vp]
     L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
@@ -256,6 +259,26 @@ class Batch:
 
     def entropy(self, d_table_override=None, stream=0):
         self._check(self.L.scalce_batch_entropy(self.h, d_table_override, stream))
+
+    def entropy_begin(self, d_table_override=None, stream=0):
+        """Enqueue the entropy stage and return; entropy_end / finish waits for it (several shards in flight)."""
+        self._check(self.L.scalce_batch_entropy_begin(self.h, d_table_override, stream))
+
+    def entropy_end(self, stream=0):
+        self._check(self.L.scalce_batch_entropy_end(self.h, stream))
+
+    def entropy_stream_begin(self, mate, d_table, d_symbols, nsym, stream=0):
+        self._check(self.L.scalce_batch_entropy_stream_begin(self.h, mate, d_table, d_symbols, int(nsym), stream))
+
+    def front(self, d_text1, n1, d_text2=None, n2=0, stream=0):
+        """Every stage before the entropy coder (ingest .. emit) on `stream`."""
+        self.ingest(0, d_text1, n1, stream)
+        if self.params.paired:
+            self.ingest(1, d_text2, n2, stream)
+        self.quality(stream)
+        self.tokenize(None, stream)
+        self.order(stream)
+        self.emit(stream)
 
     def compress(self, d_text1, n1, d_text2=None, n2=0, stream=0):
         self._check(self.L.scalce_batch_compress(self.h, d_text1, int(n1), d_text2, int(n2), stream))
