@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--inflight", type=int, default=2,
                     help="shards in flight per GPU: the coder of shard j runs on its own stream while the front "
@@ -92,6 +92,13 @@ def main():
             batches[slot].finish(ent[slot].cuda_stream)  # waits for the coder, checks the device error word
             busy[slot] = False
 
+    def chain_coders(slot):
+        # one coder at a time: a second ac_encode_k beside the first does not add throughput -- wherever the
+        # dispatcher puts two chain waves on one SIMD the younger one starves (measured: 733 ms instead of 412) --
+        # so the coders queue behind each other and only the front stages of the next shard run beside them
+        if D > 1:
+            ent[slot].wait_stream(ent[(slot - 1) % D])
+
     def submit(j):
         slot = j % D
         b = batches[slot]
@@ -100,8 +107,10 @@ def main():
             if world == 1:
                 b.front(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
                 ent[slot].wait_stream(front)
+                chain_coders(slot)
                 b.entropy_begin(None, ent[slot].cuda_stream)
             else:
+                chain_coders(slot)
                 state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
                                                    ent_stream=ent[slot])
         busy[slot] = True

@@ -69,7 +69,16 @@ struct AcEncArgs {
   DevErr *err;
   u32 debug;           // profiling only: 1 = chain idles, 2 = helper skips pack, 4 = helper skips gather
   u32 slow_threshold;  // 32; tests lower it to drive every pending underflow through the serial path
+  u32 *simd_load;      // [AC_SIMD_KEYS] coder waves per SIMD of the device, shared by every launch (may be null)
 };
+// index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
+constexpr u32 AC_SIMD_KEYS = 16u << 10;
+__device__ __forceinline__ u32 simd_key() {
+  u32 hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  return ((xcc & 15u) << 10) | (((hw >> 8) & 0xFFu) << 2) | ((hw >> 4) & 3u);
+}
 
 // floor((R + 1) * g / 2^64) for R < 2^32, g < 2^64 -- plain form, used by the self-test as the yardstick
 __device__ __forceinline__ u32 mulfrac(u32 R, u32 g_lo, u32 g_hi) {
@@ -185,7 +194,21 @@ __device__ __forceinline__ u32 ac_step_plain(u32 &lo, u32 &M, const uint4 g, u32
 // Per step: dpp mov, 2 x (mul_hi, mad), sub, dpp add, add3, xor, ffbh, bitop, lshl_or, lshl, ffbh, add, 2 x lshl.
 struct SysState {
   u32 kM[4], nl[4];  // per lane: range received / lo + B computed in the lane's own step (set = lane & 3)
+  u32 ones;          // 0xFFFFFFFF
 };
+// Renormalisation count without the (k, u) pair.  The loop of arithmetic.cpp:133-152 drops t = k + u leading bits,
+// and t is the largest number of halvings after which [nlo, nhi] still lies inside ONE window of the form
+// [m h, m h + 2 h), h = 2^(31 - t) (same top bit: window at an even m; 01.. / 10..: window at an odd m).  With
+// D = nhi - nlo >= 1 and D's top bit at position r, no window narrower than 2^(r+1) holds the interval, and the one
+// of exactly that width does unless adding D to the lower r bits of nlo reaches 2^(r+1):
+//     t = clz( (nlo mod 2^r) + D ),    r = 31 - clz(D)
+// (checked against the literal loop on random and crafted intervals in tests/test_host_cpu.py, and end to end by
+// every parity test).  Five instructions -- ffbh, not, bfe, add, ffbh -- instead of seven, hi is never formed.
+__device__ __forceinline__ u32 renorm_count(u32 nlo, u32 D) {
+  const u32 c = (u32)__builtin_clz(D);                    // D == 0: garbage, found by the caller's exit test
+  const u32 low = __builtin_amdgcn_ubfe(nlo, 0u, ~c);    // width = (31 - c) in the 5 bits the instruction reads
+  return (u32)__builtin_clz(low + D);
+}
 template <int S>
 __device__ __forceinline__ void sys_step(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
   constexpr int Q = S & 3;
@@ -193,22 +216,22 @@ __device__ __forceinline__ void sys_step(SysState &st, u32 &tlo, u32 &tM, const 
   // lane l takes the state lane l-1 produced in the previous step; only the quad of lane S is written
   st.kM[Q] = __builtin_amdgcn_update_dpp(st.kM[Q], tM, 0x138, RM, BM, false);
   const u32 M = st.kM[Q];
-  const u32 A = (u32)(((u64)M * ops.w + __umulhi(M, ops.z)) >> 32);
+  // A - 1 comes for free: the high word of the 64-bit addend is 2^32 - 1 (st.ones: opaque to the compiler, which
+  // would otherwise pull the constant out of the multiply-add and spend an instruction on it)
+  const u32 A1 = (u32)(((u64)M * ops.w + (((u64)st.ones << 32) | __umulhi(M, ops.z))) >> 32);
   const u32 B = (u32)(((u64)M * ops.y + __umulhi(M, ops.x)) >> 32);
-  const u32 W = A - B;  // new range before renormalisation
+  const u32 D = A1 - B;  // new range - 1 = nhi - nlo
   // nl = lo(from lane l-1) + B in one instruction; tlo was written many instructions ago (DPP read hazard)
   asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:%3 bank_mask:%4"
       : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(RM), "n"(BM));
+  // keep the two instructions of renorm_count that only need D behind the asm statement: the compiler assumes the
+  // worst about what an asm statement writes and puts a wait state in front of an instruction that reads its
+  // result right away
+  __builtin_amdgcn_sched_barrier(0);
   const u32 nlo = st.nl[Q];
-  const u32 nhi = nlo + W - 1;
-  const u32 k = (u32)__builtin_clz(nlo ^ nhi);           // x == 0: garbage, found by the caller's exit test
-  const u32 c1 = ((~nlo | nhi) << 1) | 1u;     // see ac_step_plain
-  const u32 Wk = W << k;
-  const u32 u = (u32)__builtin_clz(c1 << k);
-  // renormalising by k + u bits scales the range by 2^(k+u).  tM is finished two instructions before the next
-  // step's DPP move reads it (a DPP read needs two wait states after the write; this way they are not s_nops)
-  tM = Wk << u;
-  tlo = nlo << (k + u);
+  const u32 t = renorm_count(nlo, D);          // D < 2: garbage, found by the caller's exit test
+  tM = (D + 1) << t;                           // renormalising by t bits scales the range by 2^t
+  tlo = nlo << t;
 }
 template <int S, int E>
 struct SysLoop {
@@ -224,6 +247,7 @@ struct SysLoop<E, E> {
 __device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const uint4 &ops) {
   // step 0: every lane starts from the round's state (lane 0 is the one that matters)
   u32 tlo, tM;
+  asm("v_mov_b32 %0, -1" : "=v"(st.ones));
   {
     st.kM[0] = M0;
     st.kM[1] = st.kM[2] = st.kM[3] = 0;
@@ -232,10 +256,8 @@ __device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const ui
     const u32 W = A - B;
     st.nl[0] = lo + B;
     st.nl[1] = st.nl[2] = st.nl[3] = 0;
-    const u32 nlo = st.nl[0], nhi = nlo + W - 1;
-    const u32 k = (u32)__builtin_clz(nlo ^ nhi);
-    const u32 c1 = ((~nlo | nhi) << 1) | 1u;
-    const u32 t = k + (u32)__builtin_clz(c1 << k);
+    const u32 nlo = st.nl[0];
+    const u32 t = renorm_count(nlo, W - 1);
     tM = W << t;
     tlo = nlo << t;
   }
@@ -277,7 +299,20 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   const u8 *s = a.sym + boff;
   const u32 n = (u32)((a.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.nsym - boff) : (u64)AC_BLOCK_SYMS);
   const int lane = lane_id();
-  const bool chain_wave = wave_id() == 0;
+  // Which of the two waves runs the chain?  The chain wave issues an instruction every slot its SIMD gives it, so
+  // two chains on one SIMD both run at half speed -- and that is what happens to ~40 % of the blocks when two
+  // launches (two shards in flight) are resident together, because the dispatcher places waves without knowing
+  // their role.  Each wave therefore looks up how loaded its own SIMD already is (chain = 4, helper = 1, kept in
+  // a device-wide table that every launch shares), and the wave on the lighter SIMD takes the chain.
+  __shared__ u32 role_load[2];
+  const u32 skey = simd_key();
+  if (a.simd_load) {
+    if (lane == 0) role_load[wave_id()] = atomicAdd(&a.simd_load[skey], 1u);
+    __syncthreads();
+  }
+  const int chain_id = (a.simd_load && role_load[1] < role_load[0]) ? 1 : 0;
+  const bool chain_wave = wave_id() == chain_id;
+  if (a.simd_load && chain_wave && lane == 0) atomicAdd(&a.simd_load[skey], 3u);
   const u32 nrounds = (n + 63) >> 6;
 
   if (chain_wave) __builtin_amdgcn_s_setprio(3);  // the chain owns its SIMD's issue slots; whatever else lands there gets the gaps
@@ -503,6 +538,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
     if (lane == 0) a.out_size[blk] = bytes;
     if (__any(over) && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
   }
+  if (a.simd_load && lane == 0) atomicSub(&a.simd_load[skey], chain_wave ? 4u : 1u);
 }
 
 // [u32 size][bytes] framing (arithmetic.cpp:335-336,355-356): block b goes to dst_off[b]

@@ -27,6 +27,7 @@ struct scalce_ctx {
   int32_t *d_bucket_pattern = nullptr;
   u32 *d_bucket_level = nullptr;
   int tok_lds_states = 0;
+  u32 *d_simd_load = nullptr;  // per (XCC, SE, SH, CU, SIMD): coder waves resident there (ac_encode_k's role choice)
 };
 
 static void set_err(scalce_ctx *c, const char *fmt, ...) {
@@ -64,6 +65,8 @@ extern "C" int scalce_ctx_create(int device, scalce_ctx **out) {
     return SCALCE_ERR_HIP;
   }
   *out = c;
+  HIP_TRY(c, hipMalloc(&c->d_simd_load, sizeof(u32) * AC_SIMD_KEYS));
+  HIP_TRY(c, hipMemset(c->d_simd_load, 0, sizeof(u32) * AC_SIMD_KEYS));
   return SCALCE_OK;
 }
 
@@ -78,6 +81,7 @@ static void free_tables(scalce_ctx *c) {
 extern "C" void scalce_ctx_destroy(scalce_ctx *c) {
   if (!c) return;
   free_tables(c);
+  if (c->d_simd_load) hipFree(c->d_simd_load);
   delete c;
 }
 extern "C" const char *scalce_last_error(const scalce_ctx *c) { return c ? c->err.c_str() : "null context"; }
@@ -792,6 +796,7 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
   a.sym = d_sym; a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
   a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
   a.slow_threshold = 32;
+  a.simd_load = c->d_simd_load;
   a.debug = 0;
   if (const char *e = getenv("SCALCE_AC_DEBUG")) a.debug = (u32)atoi(e);  // profiling hook, breaks the output
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook

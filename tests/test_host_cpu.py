@@ -96,3 +96,59 @@ def test_sample_qmap_reads_like_the_reference():
     stat = np.bincount(q[:1000].reshape(-1), minlength=128)
     off_o, vals_o = O.qmap_init(stat, 30)
     assert L == 50 and off == off_o and (vals == vals_o).all()
+
+
+def test_renorm_count_formula_matches_the_literal_loop():
+    """ac_encode_k's systolic step counts the renormalisation shifts of arithmetic.cpp:133-152 as
+    clz((nlo mod 2^r) + D), D = nhi - nlo, r = top bit of D (kernels_ac.hpp: renorm_count).  Check the identity
+    against the literal loop on random and crafted intervals; the only permitted disagreement is where the
+    range renormalises to the full 2^32, which the kernel sends to the general path."""
+    rng = np.random.default_rng(7)
+
+    def literal(lo, hi):
+        k = u = 0
+        while k + u <= 40:
+            if (hi >> 31) == (lo >> 31):
+                k += 1
+            elif (lo >> 30) & 1 and not (hi >> 30) & 1:
+                u += 1
+                lo &= 0x3FFFFFFF
+                hi |= 0x40000000
+            else:
+                break
+            lo = (lo << 1) & 0xFFFFFFFF
+            hi = ((hi << 1) | 1) & 0xFFFFFFFF
+        return k, u
+
+    def clz(x):
+        return 32 - int(x).bit_length()
+
+    checked = 0
+    for it in range(60000):
+        mode = it % 6
+        if mode == 0:
+            a, b = sorted(int(x) for x in rng.integers(0, 2**32, 2))
+        elif mode == 1:
+            a = int(rng.integers(0, 2**32)); b = a + int(rng.integers(1, 1 << int(rng.integers(1, 32))))
+        elif mode == 2:
+            mid = 1 << int(rng.integers(1, 32)); base = int(rng.integers(0, 2**32)) // mid * mid
+            a = base - int(rng.integers(1, 1 << int(rng.integers(1, 20)))); b = base + int(rng.integers(0, 1 << int(rng.integers(1, 20))))
+        elif mode == 3:
+            a = 0x3FFFFFFF - int(rng.integers(0, 1 << 16)); b = 0xC0000000 + int(rng.integers(0, 1 << 16))
+        elif mode == 4:
+            p = int(rng.integers(1, 31)); a = int(rng.integers(0, 2**32)) >> p << p; b = a + (1 << p) - 1
+        else:
+            a = int(rng.integers(0, 2**31)); b = int(rng.integers(2**31, 2**32))
+        a = max(0, min(a, 2**32 - 1)); b = max(0, min(b, 2**32 - 1))
+        if not a < b:
+            continue
+        k, u = literal(a, b)
+        if k == 32:
+            continue
+        D = b - a
+        width = (~clz(D)) & 31                      # v_bfe_u32 reads 5 bits of the width operand
+        t = clz(((a & ((1 << width) - 1)) + D) & 0xFFFFFFFF)
+        full = (((D + 1) << (k + u)) & 0xFFFFFFFF) == 0
+        assert t == k + u or full, (hex(a), hex(b), k, u, t)
+        checked += 1
+    assert checked > 50000
