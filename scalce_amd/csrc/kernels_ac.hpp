@@ -67,9 +67,9 @@ struct AcEncArgs {
   u32 out_cap;      // bytes a block may write (multiple of 4)
   u32 *out_size;
   DevErr *err;
-  u32 debug;           // profiling only: 1 = chain idles, 2 = helper skips pack, 4 = helper skips gather
   u32 slow_threshold;  // 32; tests lower it to drive every pending underflow through the serial path
   u32 *simd_load;      // [AC_SIMD_KEYS] coder waves per SIMD of the device, shared by every launch (may be null)
+  u64 *prof;           // profiling only (SCALCE_AC_PROF): per block {cycles in the 64 steps, cycles in the rest of the round, rounds}
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
 constexpr u32 AC_SIMD_KEYS = 16u << 10;
@@ -290,7 +290,9 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
 
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
-  __shared__ uint2 rec[2][64];
+  __shared__ uint2 rec[2][64];   // chain -> helper: per symbol {hi before the shift, k | u << 8}
+  __shared__ uint4 opsb[2][64];  // helper -> chain: operands of a round (slot = round & 1)
+  __shared__ u32 oflag[2];       // ... and whether the round may take the systolic path
   __shared__ u32 buf[AC_BUF_WORDS];
   __shared__ u32 final_lo;
 
@@ -326,16 +328,6 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   bool over = false;
   // ---- chain-wave state ----
   u32 lo = 0, hi = 0xFFFFFFFFu;
-
-  // operands of the 64 symbols [base, base + 64): lane l serves symbol base + l with both reciprocal fractions
-  // {g(lo), g(hi)} of its interval bounds
-  auto gather = [&](u32 base) -> uint4 {
-    const u32 i = base + lane;
-    if (i < 2 || i >= n) return make_uint4(0, 0, 0, 0);
-    const u32 p0 = s[i - 2], p1 = s[i - 1], c = s[i];
-    if (p0 >= AC_D || p1 >= AC_D || c >= AC_D) return make_uint4(0, 0, 0, 0);  // E_SYMBOL was raised at ingest
-    return a.tab[((u64)p0 * AC_D + p1) * AC_D + c];
-  };
 
   // uniform append of nb <= 32 bits (every lane of the helper wave passes the same values): used by the
   // rare slow path and by the final flush
@@ -424,100 +416,57 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
     pend = pend_out;
   };
 
-  if (!chain_wave) carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
-  // chain wave: operands are fetched a round ahead and the symbols they are looked up with two rounds ahead, so
-  // no load of a round waits for another load of the same round (the table address needs the symbol bytes)
+  u64 prof_sys = 0, prof_rounds = 0;
+  const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
+  // ---- operand pipeline (helper wave) ----
+  // {g(lo), g(hi)} of the 64 symbols of round rr, lane l serving symbol 64 rr + l.  The context of lane l is the
+  // two symbols before it: sy = symbols of round rr (one per lane), sy_prev = those of round rr - 1 for lanes 0, 1.
   auto sym_at = [&](u32 i) -> u32 { return i < n ? (u32)s[i] : 0u; };
-  uint4 cur = chain_wave ? gather(0) : make_uint4(0, 0, 0, 0);
-  u32 sy_cur = chain_wave ? sym_at(lane) : 0u;        // symbols of this round (contexts of the next one's first lanes)
-  u32 sy_nxt = chain_wave ? sym_at(64 + lane) : 0u;   // symbols of the next round
-  // every load of the prologue has landed before the loop starts: otherwise the compiler cannot tell inside the
-  // loop whether `cur` is still in flight and waits for ALL loads (including the ones just issued for the next
-  // round) in front of every round's chain
-  asm volatile("; prologue operands landed" : "+v"(cur.x), "+v"(cur.y), "+v"(cur.z), "+v"(cur.w), "+v"(sy_cur), "+v"(sy_nxt));
-  for (u32 r = 0; r < nrounds; r++) {
-    const u32 base = r << 6;
-    if (chain_wave) {
-      const uint4 ops = cur;
-      uint4 nxt = make_uint4(0, 0, 0, 0);
-      u32 sy_nn = 0;
-      if (base + 64 < n && !(a.debug & 4)) {  // in flight during this round's chain
-        // contexts: p1 = symbol of lane - 1, p0 = symbol of lane - 2; lanes 0 and 1 reach into this round's symbols
-        const u32 e63 = __builtin_amdgcn_readlane(sy_cur, 63), e62 = __builtin_amdgcn_readlane(sy_cur, 62);
-        const u32 p1 = __builtin_amdgcn_update_dpp(e63, sy_nxt, 0x138, 0xF, 0xF, false);
-        const u32 p0 = __builtin_amdgcn_update_dpp(e62, p1, 0x138, 0xF, 0xF, false);
-        const u32 D1 = AC_D - 1;  // symbols >= AC_D raised E_SYMBOL at ingest; stay inside the table regardless
-        const u32 c = sy_nxt < D1 ? sy_nxt : D1, q1 = p1 < D1 ? p1 : D1, q0 = p0 < D1 ? p0 : D1;
-        if (base + 64 + lane < n) nxt = a.tab[(q0 * AC_D + q1) * AC_D + c];
-        sy_nn = sym_at(base + 128 + lane);
-      }
-      if ((a.debug & 1) && lane == 0) {  // profiling: no coder work, only well-formed empty outcomes
-        for (int j = 0; j < 64; j++) rec[r & 1][j] = make_uint2(0u, 0u);
-        if (r + 1 == nrounds) final_lo = 0;
-      }
-      if (!(a.debug & 1)) {
-        const u32 cnt = (n - base) < 64 ? (n - base) : 64;
-        uint2 *rc = rec[r & 1];
-        u32 j = (r == 0) ? 2u : 0u;
-        const u32 M0 = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
-        bool done = false;
-        if (!GENERAL && cnt == 64 && j == 0 && M0 != 0 && !__any(ops.w == 0xFFFFFFFFu)) {
-          SysState st;
-          sys_round(st, lo, M0, ops);
-          // every lane now redoes its own symbol from the state it latched: outcome for the helper wave, exit test
-          const int q = lane & 3;
-          const u32 inM = q == 0 ? st.kM[0] : q == 1 ? st.kM[1] : q == 2 ? st.kM[2] : st.kM[3];
-          const u32 nlo = q == 0 ? st.nl[0] : q == 1 ? st.nl[1] : q == 2 ? st.nl[2] : st.nl[3];
-          const u32 A = (u32)(((u64)inM * ops.w + __umulhi(inM, ops.z)) >> 32);
-          const u32 B = (u32)(((u64)inM * ops.y + __umulhi(inM, ops.x)) >> 32);
-          const u32 W = A - B;
-          const u32 nhi = nlo + W - 1;
-          const u32 x = nlo ^ nhi;
-          const u32 k = ffbh_raw(x);
-          const u32 c1 = ((~nlo | nhi) << 1) | 1u;
-          const u32 u = ffbh_raw(c1 << k);
-          const u32 olo = nlo << (k + u), oM = W << (k + u);
-          // bit 31 of the travelling lo is not cleared in the loop (see sys_step): the lane's nlo / nhi carry the
-          // stray bit of the state it received, which is bit 31 of what its left neighbour sent
-          u32 prev = __builtin_amdgcn_update_dpp(0u, olo, 0x138, 0xF, 0xF, false);
-          const u32 stray = prev & 0x80000000u;
-          const bool bad = x == 0 || oM == 0;   // 32 agreeing bits, or the range renormalised to the full 2^32
-          if (!__any(bad)) {  // else (rare): a step needs the general path; redo the round below
-            lo = __builtin_amdgcn_readlane(olo, 63) & 0x7FFFFFFFu;
-            hi = lo + __builtin_amdgcn_readlane(oM, 63) - 1;
-            rc[lane] = make_uint2(nhi ^ stray, k | (u << 8));
-            done = true;
-          }
-        }
-        if (!done) {  // general steps on lane 0: first round, last-of-context symbols, full interval, tails
-          u32 glo = lo, ghi = hi;
-          if (lane == 0) {
-            for (; j < cnt; j++) {
-              const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops.x, j), __builtin_amdgcn_readlane(ops.y, j),
-                                         __builtin_amdgcn_readlane(ops.z, j), __builtin_amdgcn_readlane(ops.w, j));
-              u32 hbefore;
-              const u32 ku = ac_step<GENERAL>(glo, ghi, g, hbefore);
-              rc[j] = make_uint2(hbefore, ku);
-            }
-          }
-          lo = __builtin_amdgcn_readfirstlane(glo);
-          hi = __builtin_amdgcn_readfirstlane(ghi);
-        }
-        if (r + 1 == nrounds && lane == 0) final_lo = lo;
-      }
-      cur = nxt;
-      sy_cur = sy_nxt;
-      sy_nxt = sy_nn;
-    } else {
-      if (r > 0 && !(a.debug & 2)) {
+  auto lookup = [&](u32 sy_prev, u32 sy, u32 base) -> uint4 {
+    const u32 e63 = __builtin_amdgcn_readlane(sy_prev, 63), e62 = __builtin_amdgcn_readlane(sy_prev, 62);
+    const u32 p1 = __builtin_amdgcn_update_dpp(e63, sy, 0x138, 0xF, 0xF, false);
+    const u32 p0 = __builtin_amdgcn_update_dpp(e62, p1, 0x138, 0xF, 0xF, false);
+    const u32 D1 = AC_D - 1;  // symbols >= AC_D raised E_SYMBOL at ingest; stay inside the table regardless
+    const u32 c = sy < D1 ? sy : D1, q1 = p1 < D1 ? p1 : D1, q0 = p0 < D1 ? p0 : D1;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (base + lane < n) v = a.tab[(q0 * AC_D + q1) * AC_D + c];
+    return v;
+  };
+  // a round may take the systolic path when it is complete, not the first one (two raw symbols) and none of its
+  // symbols is the last one of its context (c_hi == total: hi stays, ac_step)
+  auto plain_ok = [&](const uint4 &v, u32 rr) -> u32 {
+    return (rr > 0 && (rr << 6) + 64 <= n && !__any(v.w == 0xFFFFFFFFu)) ? 1u : 0u;
+  };
+
+  if (!chain_wave) {
+    // ================= helper wave: operands two rounds ahead, bits one round behind =================
+    carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
+    u32 sy_a, sy_b;  // symbols of rounds r + 1 and r + 2
+    {
+      const u32 sy0 = sym_at(lane);
+      sy_a = sym_at(64 + lane);
+      sy_b = sym_at(128 + lane);
+      const uint4 o0 = lookup(0u, sy0, 0), o1 = lookup(sy0, sy_a, 64);
+      opsb[0][lane] = o0;
+      opsb[1][lane] = o1;
+      if (lane == 0) { oflag[0] = 0; oflag[1] = plain_ok(o1, 1); }
+    }
+    __syncthreads();
+    for (u32 r = 0; r < nrounds; r++) {
+      const uint4 o2 = lookup(sy_a, sy_b, (r + 2) << 6);   // lands while the bits of round r - 1 are packed
+      const u32 sy_c = sym_at(((r + 3) << 6) + lane);
+      if (r > 0) {
         const uint2 v = rec[(r - 1) & 1][lane];
         const bool valid = !(r == 1 && lane < 2);  // round 0: the two raw symbols carry no outcome
         pack(valid ? v.x : 0u, valid ? v.y : 0u);
       }
+      opsb[r & 1][lane] = o2;                    // slot of round r: the chain wave took it a round ago
+      const u32 ok2 = plain_ok(o2, r + 2);
+      if (lane == 0) oflag[r & 1] = ok2;
+      sy_a = sy_b;
+      sy_b = sy_c;
+      __syncthreads();
     }
-    __syncthreads();
-  }
-  if (!chain_wave) {
     {  // outcomes of the last round
       const u32 r = nrounds - 1;
       const u32 cnt = n - (r << 6);
@@ -537,6 +486,74 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
     const u32 bytes = (u32)((bits + 7) >> 3);
     if (lane == 0) a.out_size[blk] = bytes;
     if (__any(over) && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
+  } else {
+    // ================= chain wave: nothing but the coder state =================
+    __syncthreads();  // operands of rounds 0 and 1 are in LDS
+    uint4 cur = opsb[0][lane];
+    u32 cur_ok = 0;
+    for (u32 r = 0; r < nrounds; r++) {
+      const u32 base = r << 6;
+      const uint4 ops = cur;
+      const uint4 nxt = opsb[(r + 1) & 1][lane];  // needed at the end of the round
+      const u32 nxt_ok = oflag[(r + 1) & 1];
+      const u32 cnt = (n - base) < 64 ? (n - base) : 64;
+      uint2 *rc = rec[r & 1];
+      const u32 M0 = hi - lo + 1;  // 0 stands for 2^32 (full interval): only the general step can start from it
+      bool done = false;
+      if (!GENERAL && cur_ok && M0 != 0) {
+        SysState st;
+        const u64 pt0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
+        sys_round(st, lo, M0, ops);
+        if (a.prof) { const u64 pt1 = __builtin_amdgcn_s_memtime(); prof_sys += pt1 - pt0; prof_rounds++; }
+        // every lane now redoes its own symbol from the state it latched: outcome for the helper wave, exit test
+        const int q = lane & 3;
+        const u32 inM = q == 0 ? st.kM[0] : q == 1 ? st.kM[1] : q == 2 ? st.kM[2] : st.kM[3];
+        const u32 nlo = q == 0 ? st.nl[0] : q == 1 ? st.nl[1] : q == 2 ? st.nl[2] : st.nl[3];
+        const u32 A = (u32)(((u64)inM * ops.w + __umulhi(inM, ops.z)) >> 32);
+        const u32 B = (u32)(((u64)inM * ops.y + __umulhi(inM, ops.x)) >> 32);
+        const u32 W = A - B;
+        const u32 nhi = nlo + W - 1;
+        const u32 x = nlo ^ nhi;
+        const u32 k = ffbh_raw(x);
+        const u32 c1 = ((~nlo | nhi) << 1) | 1u;
+        const u32 u = ffbh_raw(c1 << k);
+        const u32 olo = nlo << (k + u), oM = W << (k + u);
+        // bit 31 of the travelling lo is not cleared in the loop (see sys_step): the lane's nlo / nhi carry the
+        // stray bit of the state it received, which is bit 31 of what its left neighbour sent
+        u32 prev = __builtin_amdgcn_update_dpp(0u, olo, 0x138, 0xF, 0xF, false);
+        const u32 stray = prev & 0x80000000u;
+        const bool bad = x == 0 || oM == 0;   // 32 agreeing bits, or the range renormalised to the full 2^32
+        if (!__any(bad)) {  // else (rare): a step needs the general path; redo the round below
+          lo = __builtin_amdgcn_readlane(olo, 63) & 0x7FFFFFFFu;
+          hi = lo + __builtin_amdgcn_readlane(oM, 63) - 1;
+          rc[lane] = make_uint2(nhi ^ stray, k | (u << 8));
+          done = true;
+        }
+      }
+      if (!done) {  // general steps on lane 0: first round, last-of-context symbols, full interval, tails
+        u32 glo = lo, ghi = hi;
+        if (lane == 0) {
+          for (u32 j = (r == 0) ? 2u : 0u; j < cnt; j++) {
+            const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops.x, j), __builtin_amdgcn_readlane(ops.y, j),
+                                       __builtin_amdgcn_readlane(ops.z, j), __builtin_amdgcn_readlane(ops.w, j));
+            u32 hbefore;
+            const u32 ku = ac_step<GENERAL>(glo, ghi, g, hbefore);
+            rc[j] = make_uint2(hbefore, ku);
+          }
+        }
+        lo = __builtin_amdgcn_readfirstlane(glo);
+        hi = __builtin_amdgcn_readfirstlane(ghi);
+      }
+      if (r + 1 == nrounds && lane == 0) final_lo = lo;
+      cur = nxt;
+      cur_ok = nxt_ok;
+      __syncthreads();
+    }
+  }
+  if (a.prof && chain_wave && lane == 0) {
+    a.prof[blk * 3 + 0] = prof_sys;
+    a.prof[blk * 3 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
+    a.prof[blk * 3 + 2] = prof_rounds;
   }
   if (a.simd_load && lane == 0) atomicSub(&a.simd_load[skey], chain_wave ? 4u : 1u);
 }

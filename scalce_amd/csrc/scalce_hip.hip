@@ -797,8 +797,8 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
   a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
   a.slow_threshold = 32;
   a.simd_load = c->d_simd_load;
-  a.debug = 0;
-  if (const char *e = getenv("SCALCE_AC_DEBUG")) a.debug = (u32)atoi(e);  // profiling hook, breaks the output
+  a.prof = nullptr;
+  if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * nblk)); }
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
   if (b->ktiming) {
@@ -815,6 +815,15 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
   if (general) LAUNCH(ac_encode_k<true>, nblk, 128, 0, s, a);
   else LAUNCH(ac_encode_k<false>, nblk, 128, 0, s, a);
   if (ke1) hipEventRecord(ke1, s);
+  if (a.prof) {  // profiling only: where do the chain wave's cycles go (100 MHz shader clock ticks)
+    std::vector<u64> h(3 * (size_t)nblk);
+    HIP_TRY(c, hipMemcpy(h.data(), a.prof, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
+    double sys = 0, tot = 0, rounds = 0;
+    for (u32 i = 0; i < nblk; i++) { sys += h[3 * i]; tot += h[3 * i + 1]; rounds += h[3 * i + 2]; }
+    fprintf(stderr, "ac prof: %u blocks, per plain round: %.1f ticks in the 64 steps, %.1f ticks in all (%.0f plain rounds per block)\n",
+            nblk, sys / rounds, tot / rounds, rounds / nblk);
+    hipFree(a.prof);
+  }
   b->k_in_bytes += nsym;
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nblk) + 64));
   exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
