@@ -157,14 +157,14 @@ def main():
         cpu = cpu_baseline(text, n, L, args.cpu_sample)
 
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_v7_bench50m_pmc_fetch_write.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_v9_bench50m_pmc_fetch_write.json")
     if rank == 0 and n == 50_000_000 and L == 100 and os.path.exists(pmc):
         # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of
         # KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM")
         for row in json.load(open(pmc)):
             if "ac_encode_k" in row["kernel"]:
                 traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / max(row["calls"], 1))
-                traffic_src = "profiles/r01_v7_bench50m_pmc_fetch_write.json"
+                traffic_src = "profiles/r01_v9_bench50m_pmc_fetch_write.json"
     if rank == 0:
         total_in = nbytes * world
         ms_per_step = dt / args.steps * 1e3
