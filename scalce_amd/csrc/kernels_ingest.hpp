@@ -283,14 +283,18 @@ __global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
 // predecessors (cross-read predecessors included: the reference's prev[] is static,
 // qualities.cpp:179).  prev0/prev1 = the two symbols before this shard (500 = none).
 //
-// The 80^3 x u64 table (4 MB) does not fit LDS and hot trigrams would serialise global atomics, so
-// the table is built in slices: one launch per group of TRI_W leading symbols p0, the slice
-// (TRI_W x 6400 x u32 = 128 KB) lives in LDS, every workgroup streams the whole q' array with
-// 16-byte loads and counts only the trigrams of its slice with LDS atomics, then adds its non-zero
-// counters to the global table.  Slices whose leading symbols never occur exit at once
-// (symbol histogram from sym_hist_k), so a 40-symbol alphabet costs 8 streaming passes.
-constexpr int TRI_W = 5;
+// The 80^3 x u64 table (4 MB) does not fit LDS and hot trigrams would serialise global atomics, so the
+// table is built in slices of leading symbols p0: the slice lives in LDS, every workgroup streams the whole
+// q' array with 16-byte loads and counts only the trigrams of its slice with LDS atomics, then adds its
+// non-zero counters to the global table.  Only the range [lo, lo + A) of symbols that occur (sym_hist_k, plus
+// the two carried-in ones) is laid out, A^2 counters per leading symbol, so a 39-symbol alphabet (q' 2..40)
+// fits 20 leading symbols into 122 KB and needs 2 streaming passes instead of the 8 that 6400-counter rows
+// of the full 80-symbol alphabet took; a full alphabet still works (4 leading symbols per pass, 20 passes).
+// 512-thread workgroups: a 1024-thread one needs four free wave slots on every SIMD of a CU at once and is
+// not placed at all while another shard's arithmetic coder is resident.
 constexpr int TRI_THREADS = 512;
+constexpr int TRI_CAP = 30500;      // u32 counters in LDS (122 000 B of the CU's 160 KB)
+constexpr int TRI_MAX_PASSES = 20;  // A = 80: 4 leading symbols per pass
 
 __global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist /*[256]*/) {
   __shared__ u32 h[256];
@@ -311,21 +315,38 @@ __global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist 
   if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)h[threadIdx.x]);
 }
 
-template <int TRI_THREADS, int TRI_W>
-__global__ __launch_bounds__(TRI_THREADS) void trigram_slice_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 p0_lo,
-                                                              const u64 *sym_hist, u64 *freq4) {
-  constexpr int TRI_SLICE = TRI_W * 80 * 80;
-  __shared__ u32 tab[TRI_SLICE];  // 128 000 B of the CU's 160 KB
-  {  // nothing to count when none of this slice's leading symbols occurs (incl. the carried-in ones)
-    bool any = false;
-    for (u32 k = 0; k < TRI_W; k++) {
-      const u32 sidx = p0_lo + k;
-      any |= (sidx < 80) && (sym_hist[sidx] != 0 || prev0 == sidx || prev1 == sidx);
+// range[0] = smallest symbol < 80 that occurs, range[1] = A = span of the occurring symbols (0: none)
+__global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, u32 prev0, u32 prev1, u32 *range) {
+  const u32 l = threadIdx.x;
+  const bool live0 = sym_hist[l] != 0 || prev0 == l || prev1 == l;
+  const bool live1 = l + 64 < 80 && (sym_hist[l + 64] != 0 || prev0 == l + 64 || prev1 == l + 64);
+  const u64 m0 = __ballot(live0), m1 = __ballot(live1);
+  if (l == 0) {
+    u32 lo = 0, hi = 0;
+    if (m0 | m1) {
+      lo = m0 ? (u32)__ffsll((long long)m0) - 1 : 64 + (u32)__ffsll((long long)m1) - 1;
+      hi = m1 ? 64 + 63 - (u32)__clzll((long long)m1) : 63 - (u32)__clzll((long long)m0);
+      range[0] = lo;
+      range[1] = hi - lo + 1;
+    } else {
+      range[0] = 0;
+      range[1] = 0;
     }
-    if (!any) return;
   }
-  for (int i = threadIdx.x; i < TRI_SLICE; i += TRI_THREADS) tab[i] = 0;
+}
+
+__global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 pass,
+                                                             const u32 *range, u64 *freq4) {
+  __shared__ u32 tab[TRI_CAP];
+  const u32 lo = range[0], A = range[1];
+  if (A == 0) return;
+  const u32 AA = A * A, width = TRI_CAP / AA;  // leading symbols per pass (>= 4)
+  const u32 d0 = pass * width;
+  if (d0 >= A) return;                          // the alphabet is done
+  const u32 used = (A - d0 < width ? A - d0 : width) * AA;
+  for (u32 i = threadIdx.x; i < used; i += TRI_THREADS) tab[i] = 0;
   __syncthreads();
+  const u32 first = lo + d0;                    // leading symbols [first, first + width) belong to this pass
   const u64 stride = (u64)gridDim.x * TRI_THREADS * 16;
   for (u64 t = ((u64)blockIdx.x * TRI_THREADS + threadIdx.x) * 16; t < n; t += stride) {
     u32 a = t >= 2 ? q[t - 2] : (t == 1 ? prev1 : prev0);
@@ -343,16 +364,19 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_slice_k(const u8 *q, u64 
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const u32 c = (w[k >> 2] >> (8 * (k & 3))) & 255u;
-      const u32 d = a - p0_lo;
-      if (k < cnt && d < (u32)TRI_W && b < 80 && c < 80) atomicAdd(&tab[(d * 80 + b) * 80 + c], 1u);
+      const u32 d = a - first, bb = b - lo, cc = c - lo;  // unsigned: anything outside its range fails the test
+      if (k < cnt && d < width && bb < A && cc < A) atomicAdd(&tab[d * AA + bb * A + cc], 1u);
       a = b;
       b = c;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TRI_SLICE; i += TRI_THREADS) {
+  for (u32 i = threadIdx.x; i < used; i += TRI_THREADS) {
     const u32 v = tab[i];
-    if (v && p0_lo * 6400 + i < 512000) atomicAdd(&freq4[(u64)p0_lo * 6400 + i], (u64)v);
+    if (v) {
+      const u32 d = i / AA, rem = i - d * AA, bb = rem / A, cc = rem - bb * A;
+      atomicAdd(&freq4[((u64)(first + d) * 80 + lo + bb) * 80 + lo + cc], (u64)v);
+    }
   }
 }
 

@@ -407,12 +407,11 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     u64 *hist = b->d_small64 + 16;  // 256 symbol counters live behind the scalar scratch
     HIP_TRY(c, hipMemsetAsync(hist, 0, sizeof(u64) * 256, s));
     LAUNCH(sym_hist_k, 2048, 256, 0, s, b->q[m].as<u8>(), n, hist);
-    // 512-thread workgroups: with 1024 threads a workgroup needs four free wave slots on every SIMD of a CU at once
-    // and does not get placed while another shard's arithmetic coder is resident (measured: the stage then takes as
-    // long as the coder has left to run); 512 threads cost 11 ms more when the stage runs alone
-    for (u32 p0 = 0; p0 < 80; p0 += TRI_W)
-      LAUNCH((trigram_slice_k<TRI_THREADS, TRI_W>), 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0],
-             b->p.qprev[m][1], p0, hist, b->freq4[m].as<u64>());
+    u32 *range = b->d_small + 14;  // {lo, A}: span of the symbols that occur
+    LAUNCH(tri_range_k, 1, 64, 0, s, hist, b->p.qprev[m][0], b->p.qprev[m][1], range);
+    for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
+      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0], b->p.qprev[m][1], pass, range,
+             b->freq4[m].as<u64>());
   }
   return SCALCE_OK;
 }

@@ -311,3 +311,24 @@ def test_empty_shard(ctx):
     b.finish()
     assert b.n_reads == 0
     assert len(b.output(host.OUT_READS, 0)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alphabet", ["full_span", "single", "gaps", "top_only"])
+def test_quality_statistics_on_odd_alphabets(alphabet, ctx, oracle_trie):
+    """The trigram table is built in LDS slices laid out over the span of the symbols that occur
+    (trigram_pass_k): 2 passes for a usual alphabet, 20 when q' spans all 80 values.  Whole path against the
+    oracle on alphabets the generator never produces, so every pass count and both ends of the table are hit."""
+    rng = np.random.default_rng(11)
+    n, L = 6000, 100
+    bases, _ = synth.reads_and_quals(n, L, seed=12)
+    if alphabet == "full_span":      # q' 0..79: 4 leading symbols per pass, 20 passes
+        q = rng.integers(0, 80, size=(n, L))
+    elif alphabet == "single":       # one symbol: A = 1
+        q = np.full((n, L), 37)
+    elif alphabet == "gaps":         # lossy-style alphabet with holes, low and high ends far apart
+        q = rng.choice(np.array([0, 3, 30, 41, 77]), size=(n, L))
+    else:                            # only the last symbols of the table
+        q = rng.integers(76, 80, size=(n, L))
+    quals = (q + 33).astype(np.uint8)
+    check_against_oracle(ctx, oracle_trie, bases, quals, label=alphabet)
