@@ -317,7 +317,10 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   if (a.simd_load && chain_wave && lane == 0) atomicAdd(&a.simd_load[skey], 3u);
   const u32 nrounds = (n + 63) >> 6;
 
-  if (chain_wave) __builtin_amdgcn_s_setprio(3);  // the chain owns its SIMD's issue slots; whatever else lands there gets the gaps
+  // the chain owns its SIMD's issue slots, whatever else lands there gets the gaps; the helper must not fall behind
+  // the chain either when another shard's front stages fill the chip
+  if (chain_wave) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(2);
   // ---- helper-wave state (bit sink) ----
   u32 *dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
   const u32 wcap = a.out_cap / 4;

@@ -21,8 +21,9 @@ def _shard_text(bases, quals, bounds, r):
     return b"".join(out)
 
 
-@pytest.mark.parametrize("world,n,L", [(3, 9000, 100), (2, 230000, 100), (4, 5000, 36)])
-def test_sharded_equals_single_with_one_chunk_per_shard(world, n, L, patterns_blob):
+@pytest.mark.parametrize("world,n,L,deferred", [(3, 9000, 100, False), (2, 230000, 100, False), (4, 5000, 36, False),
+                                                 (2, 230000, 100, True), (3, 9000, 100, True)])
+def test_sharded_equals_single_with_one_chunk_per_shard(world, n, L, deferred, patterns_blob):
     import torch
     from gpu_util import device_bytes
     fourmers = None
@@ -64,7 +65,17 @@ def test_sharded_equals_single_with_one_chunk_per_shard(world, n, L, patterns_bl
     batches = [host.Batch(ctx, L, (cuts[r + 1] - cuts[r]) + 8, len(texts[r]) + 64) for r in range(world)]
 
     def body(comm):
-        return dist.compress_shard(comm, ctx, batches[comm.rank], dtexts[comm.rank].data_ptr(), len(texts[comm.rank]))
+        r = comm.rank
+        if not deferred:
+            return dist.compress_shard(comm, ctx, batches[r], dtexts[r].data_ptr(), len(texts[r]))
+        # the way bench.py keeps shards in flight: front stages on one stream, the coder only enqueued on another
+        front, ent = torch.cuda.Stream(), torch.cuda.Stream()
+        front.wait_stream(torch.cuda.default_stream())
+        with torch.cuda.stream(front):
+            res = dist.compress_shard(comm, ctx, batches[r], dtexts[r].data_ptr(), len(texts[r]),
+                                      stream=front.cuda_stream, ent_stream=ent)
+        batches[r].finish(ent.cuda_stream)
+        return res
 
     results = dist.run_threads(world, body)
     toks = np.concatenate([b.output(host.OUT_TOKENS, 0, np.int32).reshape(-1, 2) for b in batches])
