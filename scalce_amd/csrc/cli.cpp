@@ -14,6 +14,9 @@
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <zlib.h>
+#include <atomic>
+#include <thread>
+#include <algorithm>
 
 #include <cstdarg>
 #include <cstdint>
@@ -50,7 +53,7 @@ static double now() {
 }
 
 struct Options {
-  int lossy = 0, sample = 100000, threads = 1, split = 0;
+  int lossy = 0, sample = 100000, threads = 0, split = 0;
   bool paired = false, use_names = true, no_ac = false, decompress = false;
   uint64_t bucket_set_size = 4ull << 30;  // main.cpp:68
   std::string out, library, patterns, temp = "__temp__", patterns_bin;
@@ -70,7 +73,8 @@ static const char *HELP_TEXT =
     "  -s, --sample-size INT       records sampled for the quality model (default 100000)\n"
     "  -B, --bucket-set-size NUM[M|G]  bucket storage that triggers a spill chunk (default 4G); order follows the reference\n"
     "  -P, --patterns FILE         text list of cores instead of the built-in table\n"
-    "  -T, --threads INT           accepted for compatibility (the hot path runs on the GPU)\n"
+    "  -T, --threads INT           host threads that deflate the gz containers (default: cores - 1, at most 16);\n"
+    "                              the hot path itself runs on the GPU\n"
     "  -t, --temp-directory STR    accepted for compatibility (nothing is spilled)\n"
     "  -S, --split-reads INT       decompression: reads per output part\n"
     "  -d, --decompress    -v, --version    -h, --help\n"
@@ -100,26 +104,65 @@ static bool second_file(const std::string &p, std::string &out) {  // get_second
     if (out[i] == '1') { out[i] = '2'; return true; }
   return false;
 }
+// Output file.  Plain: stdio.  gzip container (-c gz / pigz): the reference hands the stream to a pigz child or to
+// zlib's gzwrite (buffio.cpp:148-188, 190-260); here the bytes are collected and deflated at close() by g_threads
+// host threads, 4 MiB per independent gzip member -- concatenated members are one valid gzip file, which the
+// reference's reader (gzread, decompress.cpp:99-113) and ours accept alike (once the hot path is on
+// the GPU, single-threaded deflate of .scalcer/.scalcen is what the wall clock of a run is made of).
+static int g_threads = 1;
 struct OutFile {
-  gzFile g = nullptr;
+  bool gz = false;
   FILE *f = nullptr;
-  void open(const std::string &path, bool gz) {
-    if (gz) g = gzopen(path.c_str(), "wb"); else f = path == "-" ? stdout : fopen(path.c_str(), "wb");
-    if (!g && !f) FAIL("Cannot create %s\n", path.c_str());
+  std::vector<uint8_t> pending;  // gz only
+  void open(const std::string &path, bool gz_) {
+    gz = gz_;
+    f = path == "-" ? stdout : fopen(path.c_str(), "wb");
+    if (!f) FAIL("Cannot create %s\n", path.c_str());
   }
-  void write(const void *p, size_t n) {
-    const uint8_t *b = static_cast<const uint8_t *>(p);
+  void raw(const uint8_t *b, size_t n) {
     while (n) {
       size_t k = n > (1u << 30) ? (1u << 30) : n;
-      if (g) { if (gzwrite(g, b, (unsigned)k) <= 0) FAIL("write failed\n"); }
-      else if (fwrite(b, 1, k, f) != k) FAIL("write failed\n");
+      if (fwrite(b, 1, k, f) != k) FAIL("write failed\n");
       b += k; n -= k;
     }
   }
+  void write(const void *p, size_t n) {
+    const uint8_t *b = static_cast<const uint8_t *>(p);
+    if (gz) pending.insert(pending.end(), b, b + n);
+    else raw(b, n);
+  }
+  static void deflate_member(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) FAIL("deflateInit2 failed\n");
+    out.resize(deflateBound(&z, (uLong)n) + 64);
+    z.next_in = const_cast<Bytef *>(src); z.avail_in = (uInt)n;
+    z.next_out = out.data(); z.avail_out = (uInt)out.size();
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) FAIL("deflate failed\n");
+    out.resize(z.total_out);
+    deflateEnd(&z);
+  }
   void close() {
-    if (g) gzclose(g);
+    if (gz && f) {
+      const size_t chunk = 4u << 20, nchunks = pending.empty() ? 1 : (pending.size() + chunk - 1) / chunk;
+      std::vector<std::vector<uint8_t>> members(nchunks);
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < nchunks;) {
+          const size_t a = i * chunk, b = std::min(pending.size(), a + chunk);
+          deflate_member(pending.data() + a, b - a, members[i]);
+        }
+      };
+      const int nt = (int)std::min<size_t>((size_t)std::max(1, g_threads), nchunks);
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; t++) pool.emplace_back(work);
+      work();
+      for (auto &t : pool) t.join();
+      for (auto &m : members) raw(m.data(), m.size());
+      pending.clear(); pending.shrink_to_fit();
+    }
     if (f && f != stdout) fclose(f);
-    g = nullptr; f = nullptr;
+    f = nullptr;
   }
 };
 #define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) FAIL("%s: %s\n", #x, hipGetErrorString(e_)); } while (0)
@@ -515,6 +558,10 @@ int main(int argc, char **argv) {
   std::vector<uint8_t> table = load_core_table(o, argv[0], is_text);
   if (is_text) SCOK(ctx, scalce_patterns_load_text(ctx, (const char *)table.data(), table.size()));
   else SCOK(ctx, scalce_patterns_load_bin(ctx, table.data(), table.size()));
+  {
+    const int hw = (int)std::thread::hardware_concurrency();
+    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(16, hw - 1));
+  }
   const int rc = o.decompress ? do_decompress(o, files[0], ctx) : do_compress(o, files, ctx);
   scalce_ctx_destroy(ctx);
   LOG("Done!\n");
