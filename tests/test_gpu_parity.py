@@ -281,6 +281,60 @@ def test_large_shard_properties(ctx):
     assert len(b.output(host.OUT_READS, 0)) == int((counts.astype(np.int64) * recsz).sum() + 12 * (counts > 0).sum())
 
 
+def test_full_size_shard_properties(ctx):
+    """BASELINE.json configs[1] at its full size, 50 M x 100 bp (10.8 GB): size-independent properties checked on the
+    device -- the order is a permutation, buckets come in emission order with the advertised counts, cores end inside
+    the read, the GPU decoder inverts all 477 coded blocks back to the reordered quality stream, the payload sizes are
+    exactly the advertised ones.  (The oracle redoes this path at 1.5 M reads in bench.py and at up to 230 k here.)"""
+    import torch
+    from scalce_amd import synth_gpu
+    dev = torch.device("cuda", 0)
+    n, L = 50_000_000, 100
+    text = synth_gpu.fastq_on_device(n, L, dev, seed=20261003)
+    b = host.Batch(ctx, L, n + 8, text.numel() + 64)
+    b.compress(text.data_ptr(), text.numel())
+    b.finish()
+    assert b.n_reads == n
+
+    def dev_array(which, dtype, count):
+        ptr, nb = b.output_ptr(which, 0)
+        t = torch.empty(count, dtype=dtype, device=dev)
+        assert nb == t.numel() * t.element_size()
+        ctx.copy_d2d(t.data_ptr(), ptr, nb)
+        torch.cuda.synchronize()
+        return t
+
+    perm = dev_array(host.OUT_PERM, torch.int32, n).to(torch.int64)   # values < 2^31
+    seen = torch.zeros(n, dtype=torch.bool, device=dev)
+    seen[perm] = True
+    assert bool(seen.all()), "order is not a permutation"
+    del seen
+    tok = dev_array(host.OUT_TOKENS, torch.int32, 2 * n).view(n, 2)
+    counts = b.output(host.OUT_BUCKET_COUNTS, 0, np.uint64).astype(np.int64)
+    assert counts.sum() == n
+    order = ctx.bucket_patterns()
+    nb1 = len(order)
+    rank = torch.full((ctx.n_patterns + 1,), nb1 - 1, dtype=torch.int64, device=dev)  # last slot: no core (-1)
+    rank[torch.from_numpy(order[:-1].astype(np.int64)).to(dev)] = torch.arange(nb1 - 1, device=dev)
+    bucket = rank[tok[:, 0].to(torch.int64)[perm]]          # index -1 -> last slot
+    assert bool((bucket[1:] >= bucket[:-1]).all()), "buckets not in emission order"
+    assert (torch.bincount(bucket, minlength=nb1).cpu().numpy() == counts).all()
+    lens = torch.from_numpy(np.array([len(ctx.pattern(int(p))) for p in order[:-1]] + [0], dtype=np.int64)).to(dev)
+    end = tok[:, 1].to(torch.int64)[perm]
+    assert bool(((end == 0) == (bucket == nb1 - 1)).all()) and bool((end >= lens[bucket]).all()) and bool((end <= L).all())
+    del bucket, end, perm, tok
+    # decoder round trip of the whole coded stream on the device
+    nsym = n * L
+    out = torch.zeros(nsym, dtype=torch.uint8, device=dev)
+    p, nbytes = b.output_ptr(host.OUT_QUAL, 0)
+    ctx.ac_decode(b.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nsym, out.data_ptr())
+    want = dev_array(host.OUT_QSTREAM, torch.uint8, nsym)
+    assert torch.equal(out, want), "decoded stream differs from the reordered quality stream"
+    recsz = (L - lens.cpu().numpy() + 3) // 4 + 1
+    assert b.output_ptr(host.OUT_READS, 0)[1] == int((counts * recsz).sum() + 12 * (counts > 0).sum())
+    assert b.output_ptr(host.OUT_NAMES, 0)[1] == int(b.output(host.OUT_NAMELEN, 0).astype(np.int64).sum()) + n
+
+
 def test_malformed_input_is_an_error(ctx):
     from gpu_util import device_bytes
     b1, q1 = synth.reads_and_quals(50, 40, seed=3)
