@@ -9,7 +9,7 @@ ranks produce ONE archive (scalce_amd/dist.py: run-wide tie-break, quality model
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (ac_encode_k): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (a port of the reference, single thread) timed on a bounded sample
+  cpu_baseline -- the reference's own hot-path objects (oracle/_ref, else the C port), one thread, on a bounded sample
 """
 import argparse
 import json
@@ -205,7 +205,12 @@ def main():
 
 
 def cpu_baseline(text, n, L, sample):
-    """Time the CPU oracle (port of the reference, -T 1 -c no) on the first `sample` records."""
+    """Time the CPU side on the first `sample` records of the same shard, on this box's host cores.
+
+    kind "reference": oracle/_ref/ref_driver -t -- the reference's OWN hot-path objects (aho_search, output_read,
+    output_quality, aho_trie_bucket, bin_prepare, ac_coder; built in the dev container from /root/reference, the
+    binary travels with the repo) driven by a harness that plays main()/thread() at -T 1.  Falls back to kind
+    "port" (oracle/orc_cli, the plain-C restatement) where that binary is missing."""
     import numpy as np
     sample = min(sample, n)
     approx = sample * (2 * L + 8 + len(str(sample)))
@@ -213,19 +218,28 @@ def cpu_baseline(text, n, L, sample):
     nl = np.flatnonzero(head == 10)
     sample = min(sample, len(nl) // 4)
     end = int(nl[4 * sample - 1]) + 1
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     exe = os.path.join(ROOT, "oracle", "orc_cli")
-    if not os.path.exists(exe):
+    use_ref = os.path.exists(ref) and os.access(ref, os.X_OK)
+    if not use_ref and not os.path.exists(exe):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     with tempfile.TemporaryDirectory() as d:
         fq = os.path.join(d, "s_1.fq")
         head[:end].tofile(fq)
         t0 = time.perf_counter()
-        subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
-                        os.path.join(d, "o"), "-c", "no", "-T", "1"], check=True, capture_output=True)
+        if use_ref:
+            r = subprocess.run([ref, fq, d, "-t"], capture_output=True, text=True)
+            use_ref = r.returncode == 0
+        if not use_ref:
+            t0 = time.perf_counter()
+            subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
+                            os.path.join(d, "o"), "-c", "no", "-T", "1"], check=True, capture_output=True)
         dt = time.perf_counter() - t0
-    return {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": f"first {sample} records ({end} bytes) of the same shard, orc_cli compress -c no -T 1, "
-                      f"{dt:.2f} s wall incl. file I/O", "host_cpus": os.cpu_count()}
+    what = ("oracle/_ref/ref_driver -t (the reference's own objects, one thread)" if use_ref
+            else "orc_cli compress -c no -T 1 (C restatement, one thread)")
+    return {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
+            "sample": f"first {sample} records ({end} bytes) of the same shard, {what}, {dt:.2f} s wall incl. file I/O",
+            "host_cpus": os.cpu_count()}
 
 
 if __name__ == "__main__":

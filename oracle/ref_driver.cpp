@@ -13,14 +13,17 @@
  * framing, bin_dump, compress(), decompress().  Those call f_gets/f_read/f_write,
  * which stay unresolved in this binary and are never called.
  *
- * usage: ref_driver <fastq> <outdir> [-P patterns.txt] [-q qmap.txt] [-n]
+ * usage: ref_driver <fastq> <outdir> [-P patterns.txt] [-q qmap.txt] [-n] [-t]
  *   -P  text core list (read_patterns_from_file) instead of the embedded patterns.bin
  *   -q  file with 129 integers: offset, values[0..127]  (default: offset 33, identity)
  *   -n  names off (-n lib)
+ *   -t  timing mode (bench.py's cpu_baseline of kind "reference"): the compress path only -- no decoder check,
+ *       nothing but ac.bin is written -- and the seconds spent in it go to stderr
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -66,11 +69,15 @@ int main(int argc, char **argv) {
   if (argc < 3) { fprintf(stderr, "usage: ref_driver <fastq> <outdir> [-P txt] [-q qmap] [-n]\n"); return 2; }
   std::string fq = argv[1], out = argv[2];
   const char *ptxt = 0, *qfile = 0;
+  int timing = 0;
   for (int i = 3; i < argc; i++) {
     if (!strcmp(argv[i], "-P") && i + 1 < argc) ptxt = argv[++i];
     else if (!strcmp(argv[i], "-q") && i + 1 < argc) qfile = argv[++i];
     else if (!strcmp(argv[i], "-n")) _use_names = 0;
+    else if (!strcmp(argv[i], "-t")) timing = 1;
   }
+  struct timespec ts0;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
   quality_mapping qm;
   qm.offset = 33;
   for (int i = 0; i < 128; i++) qm.values[i] = i;
@@ -124,11 +131,13 @@ int main(int argc, char **argv) {
   fclose(f);
   reads_count = N;
 
-  dump(out + "/tok.i32", tok.data(), tok.size() * 4);
-  dump(out + "/packed.bin", packed.data(), packed.size());
-  dump(out + "/names.bin", names.data(), names.size());
-  dump(out + "/qual.bin", quals.data(), quals.size());
-  dump(out + "/freq4.u64", ac_freq4[0], sizeof(uint64_t) * AC_DEPTH * AC_DEPTH * AC_DEPTH);
+  if (!timing) {
+    dump(out + "/tok.i32", tok.data(), tok.size() * 4);
+    dump(out + "/packed.bin", packed.data(), packed.size());
+    dump(out + "/names.bin", names.data(), names.size());
+    dump(out + "/qual.bin", quals.data(), quals.size());
+    dump(out + "/freq4.u64", ac_freq4[0], sizeof(uint64_t) * AC_DEPTH * AC_DEPTH * AC_DEPTH);
+  }
 
   /* pattern -> BFS id (reads.cpp:296): walk each core through the automaton */
   int np = 0;
@@ -149,7 +158,7 @@ int main(int argc, char **argv) {
     for (const char *s = patterns[p]; *s && *s != '\n'; s++) c = c->child[getval(*s)];
     ids[p] = (c->output == p) ? c->id : -1;
   }
-  dump(out + "/ids.i32", ids.data(), ids.size() * 4);
+  if (!timing) dump(out + "/ids.i32", ids.data(), ids.size() * 4);
 
   /* emission order: the traversal of aho_output (reads.cpp:466-499) with bin_dump
    * replaced by a walk of the sorted list that bin_prepare leaves behind */
@@ -173,7 +182,7 @@ int main(int argc, char **argv) {
       for (bin_node *b = trie->bin.first; b; b = b->next) order.push_back(b->data.read_length);
     }
   }
-  dump(out + "/order.i64", order.data(), order.size() * 8);
+  if (!timing) dump(out + "/order.i64", order.data(), order.size() * 8);
 
   /* arithmetic coder on the reordered quality stream, factor 1 (N*L < 2^32) */
   std::vector<uint8_t> qs((size_t)N * L);
@@ -192,11 +201,18 @@ int main(int argc, char **argv) {
     uint32_t sz = (uint32_t)(ax.output() - blk.data());
     enc.insert(enc.end(), (uint8_t *)&sz, (uint8_t *)&sz + 4);
     enc.insert(enc.end(), blk.data(), blk.data() + sz);
+    if (timing) continue;
     ac_decoder ad(&as, blk.data());
     ad.read(dec.data(), (int)n);
     if (memcmp(dec.data(), &qs[off], n)) bad++;
   }
   dump(out + "/ac.bin", enc.data(), enc.size());
+  if (timing) {
+    struct timespec ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    fprintf(stderr, "ref_driver timing: %.3f s for the compress path of %lld reads (1 thread)\n",
+            (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec), (long long)N);
+  }
   fprintf(stderr, "ref_driver: %lld reads, L=%d, %d cores, %zu AC bytes, decode %s\n", (long long)N, L, np,
           enc.size(), bad ? "MISMATCH" : "ok");
   return bad ? 1 : 0;
