@@ -288,6 +288,116 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
   if (s + n > 32) atomicOr(&buf[w + 1], (u32)x);
 }
 
+// Bit sink of one block (helper-wave side): takes the per-symbol outcomes of a round -- hi before the shift,
+// k agreed leading bits, u underflow steps -- and appends the bits arithmetic.cpp:133-147 would have written one at a
+// time.  All 64 lanes of the calling wave take part; `buf` is AC_BUF_WORDS words of LDS owned by that wave.
+struct AcSink {
+  u32 *dst = nullptr;  // the block's output words
+  u32 wcap = 0;        // words the block may write
+  u32 gw = 0;          // words already stored
+  u32 c0 = 16;         // bits pending in `carry` (left aligned); a block starts with its two raw symbols
+  u32 carry = 0;
+  u32 pend = 0;        // underflow steps not yet materialised as bits
+  bool over = false;
+
+  // uniform append of nb <= 32 bits (every lane passes the same values): rare slow path and final flush
+  __device__ __forceinline__ void emit_u(u32 *buf, int lane, u32 v, u32 nb) {
+    for (int w = lane; w < 4; w += 64) buf[w] = (w == 0) ? carry : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) lds_place(buf, v, nb, c0);
+    __builtin_amdgcn_wave_barrier();
+    const u32 endbits = c0 + nb;
+    const u32 nfull = endbits >> 5;  // 0 or 1
+    if (nfull && lane == 0) {
+      if (gw < wcap) dst[gw] = __builtin_bswap32(buf[0]);
+      else over = true;
+    }
+    carry = buf[nfull];
+    __builtin_amdgcn_wave_barrier();
+    c0 = endbits & 31;
+    gw += nfull;
+  }
+  __device__ __forceinline__ void emit_run_u(u32 *buf, int lane, u32 bit, u32 count) {
+    while (count) {
+      const u32 m = count < 32 ? count : 32;
+      emit_u(buf, lane, bit ? (m == 32 ? 0xFFFFFFFFu : ((1u << m) - 1)) : 0u, m);
+      count -= m;
+    }
+  }
+  // pack one round: rH = hi before the shift, rK = k | u << 8 per lane (0 for lanes without a symbol)
+  __device__ __forceinline__ void pack(u32 *buf, int lane, u32 slow_threshold, u32 rH, u32 rK) {
+    const u32 k = rK & 0xFF, u = rK >> 8;
+    const bool flag = k != 0;
+    // pending underflow before each symbol: segmented running sum of u, restarted by every emitting symbol
+    const u32 S = wave_inclusive_sum(u);
+    const u64 fm = __ballot(flag);
+    const u64 upto = fm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));  // flags at lanes <= lane
+    const int f = upto ? 63 - __clzll((long long)upto) : -1;             // last emitting lane <= lane
+    const u32 sbase = __shfl(S - u, f < 0 ? 0 : f, 64);                   // sum before that lane
+    const u32 U = f < 0 ? pend + S : S - sbase;                           // pending after this lane
+    u32 P = __shfl_up(U, 1, 64);
+    if (lane == 0) P = pend;
+    const u32 top = flag ? (k == 32 ? rH : (rH >> (32 - k))) : 0u;        // the k agreed bits
+    const u32 msb = flag ? (top >> (k - 1)) : 0u;
+    const u32 rest = (k > 1) ? (top & ((1u << (k - 1)) - 1)) : 0u;
+    const u32 pend_out = __shfl(U, 63, 64);
+    if (__any(flag && P > slow_threshold)) {
+      // an underflow run longer than 32 bits (about once per 2^32 symbols): walk the round serially
+      for (int j = 0; j < 64; j++) {
+        const u32 kj = __builtin_amdgcn_readlane(k, j);
+        if (!kj) continue;
+        const u32 Pj = __builtin_amdgcn_readlane(P, j), mj = __builtin_amdgcn_readlane(msb, j);
+        const u32 rj = __builtin_amdgcn_readlane(rest, j);
+        emit_u(buf, lane, mj, 1);
+        emit_run_u(buf, lane, mj ^ 1, Pj);
+        if (kj > 1) emit_u(buf, lane, rj, kj - 1);
+      }
+      pend = pend_out;
+      return;
+    }
+    const u32 nbits = flag ? k + P : 0u;
+    const u32 incl = wave_inclusive_sum(nbits);
+    const u32 total = __shfl(incl, 63, 64);
+    const u32 o = c0 + incl - nbits;
+    for (int w = lane; w < AC_BUF_WORDS; w += 64) buf[w] = (w == 0) ? carry : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (flag) {
+      const u32 run = (msb || P == 0) ? 0u : (P == 32 ? 0xFFFFFFFFu : ((1u << P) - 1));
+      const u64 v = ((u64)msb << (P + k - 1)) | ((u64)run << (k - 1)) | rest;
+      if (nbits > 32) {
+        lds_place(buf, (u32)(v >> 32), nbits - 32, o);
+        lds_place(buf, (u32)v, 32, o + nbits - 32);
+      } else {
+        lds_place(buf, (u32)v, nbits, o);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const u32 endbits = c0 + total;
+    const u32 nfull = endbits >> 5;
+    for (u32 w = lane; w < nfull; w += 64) {
+      if (gw + w < wcap) dst[gw + w] = __builtin_bswap32(buf[w]);
+      else over = true;
+    }
+    carry = buf[nfull];
+    __builtin_amdgcn_wave_barrier();
+    c0 = endbits & 31;
+    gw += nfull;
+    pend = pend_out;
+  }
+  // flush, arithmetic.cpp:160-169: bit 30 of lo, then pend+1 inverted copies, zero padding to a byte.  Returns bytes.
+  __device__ __forceinline__ u32 finish(u32 *buf, int lane, u32 final_lo) {
+    const u32 b30 = (final_lo >> 30) & 1;
+    emit_u(buf, lane, b30, 1);
+    emit_run_u(buf, lane, b30 ^ 1, pend + 1);
+    const u64 bits = (u64)gw * 32 + c0;
+    if (c0) {
+      if (gw < wcap) { if (lane == 0) dst[gw] = __builtin_bswap32(carry); }
+      else over = true;
+    }
+    return (u32)((bits + 7) >> 3);
+  }
+};
+
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   __shared__ uint2 rec[2][64];   // chain -> helper: per symbol {hi before the shift, k | u << 8}
@@ -322,102 +432,11 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   if (chain_wave) __builtin_amdgcn_s_setprio(3);
   else __builtin_amdgcn_s_setprio(2);
   // ---- helper-wave state (bit sink) ----
-  u32 *dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
-  const u32 wcap = a.out_cap / 4;
-  u32 gw = 0;          // words already stored
-  u32 c0 = 16;         // bits pending in `carry` (left aligned)
-  u32 carry = 0;
-  u32 pend = 0;        // underflow steps not yet materialised as bits
-  bool over = false;
+  AcSink sink;
+  sink.dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
+  sink.wcap = a.out_cap / 4;
   // ---- chain-wave state ----
   u32 lo = 0, hi = 0xFFFFFFFFu;
-
-  // uniform append of nb <= 32 bits (every lane of the helper wave passes the same values): used by the
-  // rare slow path and by the final flush
-  auto emit_u = [&](u32 v, u32 nb) {
-    for (int w = lane; w < 4; w += 64) buf[w] = (w == 0) ? carry : 0u;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) lds_place(buf, v, nb, c0);
-    __builtin_amdgcn_wave_barrier();
-    const u32 endbits = c0 + nb;
-    const u32 nfull = endbits >> 5;  // 0 or 1
-    if (nfull && lane == 0) {
-      if (gw < wcap) dst[gw] = __builtin_bswap32(buf[0]);
-      else over = true;
-    }
-    carry = buf[nfull];
-    __builtin_amdgcn_wave_barrier();
-    c0 = endbits & 31;
-    gw += nfull;
-  };
-  auto emit_run_u = [&](u32 bit, u32 count) {
-    while (count) {
-      const u32 m = count < 32 ? count : 32;
-      emit_u(bit ? (m == 32 ? 0xFFFFFFFFu : ((1u << m) - 1)) : 0u, m);
-      count -= m;
-    }
-  };
-
-  // pack one round: rH = hi before the shift, rK = k | u << 8 per lane (0 for lanes without a symbol)
-  auto pack = [&](u32 rH, u32 rK) {
-    const u32 k = rK & 0xFF, u = rK >> 8;
-    const bool flag = k != 0;
-    // pending underflow before each symbol: segmented running sum of u, restarted by every emitting symbol
-    const u32 S = wave_inclusive_sum(u);
-    const u64 fm = __ballot(flag);
-    const u64 upto = fm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));  // flags at lanes <= lane
-    const int f = upto ? 63 - __clzll((long long)upto) : -1;             // last emitting lane <= lane
-    const u32 sbase = __shfl(S - u, f < 0 ? 0 : f, 64);                   // sum before that lane
-    const u32 U = f < 0 ? pend + S : S - sbase;                           // pending after this lane
-    u32 P = __shfl_up(U, 1, 64);
-    if (lane == 0) P = pend;
-    const u32 top = flag ? (k == 32 ? rH : (rH >> (32 - k))) : 0u;        // the k agreed bits
-    const u32 msb = flag ? (top >> (k - 1)) : 0u;
-    const u32 rest = (k > 1) ? (top & ((1u << (k - 1)) - 1)) : 0u;
-    const u32 pend_out = __shfl(U, 63, 64);
-    if (__any(flag && P > a.slow_threshold)) {
-      // an underflow run longer than 32 bits (about once per 2^32 symbols): walk the round serially
-      for (int j = 0; j < 64; j++) {
-        const u32 kj = __builtin_amdgcn_readlane(k, j);
-        if (!kj) continue;
-        const u32 Pj = __builtin_amdgcn_readlane(P, j), mj = __builtin_amdgcn_readlane(msb, j);
-        const u32 rj = __builtin_amdgcn_readlane(rest, j);
-        emit_u(mj, 1);
-        emit_run_u(mj ^ 1, Pj);
-        if (kj > 1) emit_u(rj, kj - 1);
-      }
-      pend = pend_out;
-      return;
-    }
-    const u32 nbits = flag ? k + P : 0u;
-    const u32 incl = wave_inclusive_sum(nbits);
-    const u32 total = __shfl(incl, 63, 64);
-    const u32 o = c0 + incl - nbits;
-    for (int w = lane; w < AC_BUF_WORDS; w += 64) buf[w] = (w == 0) ? carry : 0u;
-    __builtin_amdgcn_wave_barrier();
-    if (flag) {
-      const u32 run = (msb || P == 0) ? 0u : (P == 32 ? 0xFFFFFFFFu : ((1u << P) - 1));
-      const u64 v = ((u64)msb << (P + k - 1)) | ((u64)run << (k - 1)) | rest;
-      if (nbits > 32) {
-        lds_place(buf, (u32)(v >> 32), nbits - 32, o);
-        lds_place(buf, (u32)v, 32, o + nbits - 32);
-      } else {
-        lds_place(buf, (u32)v, nbits, o);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    const u32 endbits = c0 + total;
-    const u32 nfull = endbits >> 5;
-    for (u32 w = lane; w < nfull; w += 64) {
-      if (gw + w < wcap) dst[gw + w] = __builtin_bswap32(buf[w]);
-      else over = true;
-    }
-    carry = buf[nfull];
-    __builtin_amdgcn_wave_barrier();
-    c0 = endbits & 31;
-    gw += nfull;
-    pend = pend_out;
-  };
 
   u64 prof_sys = 0, prof_rounds = 0;
   const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
 
   if (!chain_wave) {
     // ================= helper wave: operands two rounds ahead, bits one round behind =================
-    carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
+    sink.carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
     u32 sy_a, sy_b;  // symbols of rounds r + 1 and r + 2
     {
       const u32 sy0 = sym_at(lane);
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       if (r > 0) {
         const uint2 v = rec[(r - 1) & 1][lane];
         const bool valid = !(r == 1 && lane < 2);  // round 0: the two raw symbols carry no outcome
-        pack(valid ? v.x : 0u, valid ? v.y : 0u);
+        sink.pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       }
       opsb[r & 1][lane] = o2;                    // slot of round r: the chain wave took it a round ago
       const u32 ok2 = plain_ok(o2, r + 2);
@@ -475,20 +494,11 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       const u32 cnt = n - (r << 6);
       const uint2 v = rec[r & 1][lane];
       const bool valid = (u32)lane < cnt && !(r == 0 && lane < 2);
-      pack(valid ? v.x : 0u, valid ? v.y : 0u);
+      sink.pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
     }
-    // flush, arithmetic.cpp:160-169: bit 30 of lo, then pend+1 inverted copies, zero padding to a byte
-    const u32 b30 = (final_lo >> 30) & 1;
-    emit_u(b30, 1);
-    emit_run_u(b30 ^ 1, pend + 1);
-    const u64 bits = (u64)gw * 32 + c0;
-    if (c0) {
-      if (gw < wcap) { if (lane == 0) dst[gw] = __builtin_bswap32(carry); }
-      else over = true;
-    }
-    const u32 bytes = (u32)((bits + 7) >> 3);
+    const u32 bytes = sink.finish(buf, lane, final_lo);
     if (lane == 0) a.out_size[blk] = bytes;
-    if (__any(over) && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
+    if (__any(sink.over) && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
   } else {
     // ================= chain wave: nothing but the coder state =================
     __syncthreads();  // operands of rounds 0 and 1 are in LDS
