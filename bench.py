@@ -33,6 +33,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="shards in flight per GPU: the coder of shard j runs on its own stream while the front "
                          "stages of shard j+1 run (1 = strictly one after the other)")
+    ap.add_argument("--group", type=int, default=1,
+                    help="shards per coder launch (scalce_batch_entropy_begin_group, four blocks per workgroup); "
+                         "1 = one launch per shard with the one-block-per-workgroup kernel")
+    ap.add_argument("--coders-overlap", action="store_true",
+                    help="let the coders of the shards in flight run side by side instead of queueing (experiment)")
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
     ap.add_argument("--length", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="records of the CPU baseline sample (0 = skip)")
@@ -68,15 +73,18 @@ def main():
     from scalce_amd import format as fmt
     off, vals, Ls = fmt.sample_qmap(head)
     assert Ls == L
-    D = max(1, args.inflight)
+    G = max(1, args.group)                     # shards per coder launch
+    D = max(1, args.inflight) if G == 1 else max(args.inflight, 2 * G)
     batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)]) for _ in range(D)]
     batch = batches[0]
-    # one stream for the front stages (ingest .. emit, and the collectives of a sharded run), one per slot for the
-    # arithmetic coder: ac_encode_k is a long kernel of one wavefront per 10 MiB block that leaves most of the chip
-    # idle, so the next shard's front stages run beside it
+    # one stream for the front stages (ingest .. emit, and the collectives of a sharded run), others for the
+    # arithmetic coder: it is a long kernel of one wavefront per block (or per four) that leaves the memory system
+    # and most lanes idle, so the next shards' front stages run beside it
     front = torch.cuda.Stream()
     ent = [torch.cuda.Stream() for _ in range(D)]
-    busy = [False] * D
+    busy = [None] * D      # stream the slot's coder was enqueued on
+    pending = []           # slots whose front stages are done and whose coder launch is still to come (G > 1)
+    ngroups = [0]
 
     state = {}
     comm = sdist.TorchComm() if world > 1 else None
@@ -88,38 +96,65 @@ def main():
         torch.cuda.synchronize()
 
     def retire(slot):
-        if busy[slot]:
-            batches[slot].finish(ent[slot].cuda_stream)  # waits for the coder, checks the device error word
-            busy[slot] = False
+        if busy[slot] is not None:
+            batches[slot].finish(busy[slot].cuda_stream)  # waits for the coder, checks the device error word
+            busy[slot] = None
 
-    def chain_coders(slot):
-        # one coder at a time: a second ac_encode_k beside the first does not add throughput -- wherever the
+    def chain_coders(stream_now, stream_before):
+        # one coder launch at a time: a second one beside the first does not add throughput -- wherever the
         # dispatcher puts two chain waves on one SIMD the younger one starves (measured: 733 ms instead of 412) --
-        # so the coders queue behind each other and only the front stages of the next shard run beside them
-        if D > 1:
-            ent[slot].wait_stream(ent[(slot - 1) % D])
+        # so the launches queue behind each other and only the front stages of the next shards run beside them
+        if stream_before is not None and not args.coders_overlap:
+            stream_now.wait_stream(stream_before)
 
-    def submit(j):
+    last_coder = [None]
+
+    def launch_group():
+        if not pending:
+            return
+        es = ent[ngroups[0] % D]
+        ngroups[0] += 1
+        chain_coders(es, last_coder[0])
+        host.entropy_begin_group([batches[sl] for sl in pending], front.cuda_stream, es.cuda_stream)
+        for sl in pending:
+            busy[sl] = es
+        last_coder[0] = es
+        pending.clear()
+
+    def submit(j, last):
         slot = j % D
         b = batches[slot]
         retire(slot)
         with torch.cuda.stream(front):
-            if world == 1:
-                b.front(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
-                ent[slot].wait_stream(front)
-                chain_coders(slot)
-                b.entropy_begin(None, ent[slot].cuda_stream)
+            if G == 1:
+                es = ent[slot]
+                if world == 1:
+                    b.front(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
+                    es.wait_stream(front)
+                    chain_coders(es, last_coder[0])
+                    b.entropy_begin(None, es.cuda_stream)
+                else:
+                    chain_coders(es, last_coder[0])
+                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
+                                                       ent_stream=es)
+                busy[slot] = es
+                last_coder[0] = es
             else:
-                chain_coders(slot)
-                state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
-                                                   ent_stream=ent[slot])
-        busy[slot] = True
+                if world == 1:
+                    b.front(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
+                else:
+                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
+                                                       prepare_only=True)
+                pending.append(slot)
+                if len(pending) == G or last:
+                    launch_group()
 
     def run(k):
         for j in range(k):
-            submit(j)
+            submit(j, j + 1 == k)
         for slot in range(D):
             retire(slot)
+        last_coder[0] = None
 
     torch.cuda.synchronize()  # the synthetic shard was generated on the default stream
     warm = max(args.warmup, D) if args.warmup > 0 else 0  # every slot allocates its buffers outside the timed region
@@ -190,7 +225,7 @@ def main():
                        "input_bytes_per_gpu": nbytes, "output_bytes_per_gpu": int(out_bytes),
                        "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if world == 1 else ": read ranges per rank, run-wide tie-break / quality model / 10 MiB blocks (RCCL all-gather, all-reduce, all-to-all)"),
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
-                       "shards_in_flight": D, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
+                       "shards_in_flight": D, "shards_per_coder_launch": G, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
             "roofline": {"bound": "hbm", "kernel": "ac_encode_k", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(per_launch_ms, 3), "alg_bytes_per_launch": int(alg_bytes),

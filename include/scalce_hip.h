@@ -125,12 +125,22 @@ int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void
  * counterpart of the reference coding `-T` blocks per batch on its thread pool (arithmetic.cpp:349-357). */
 int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_table_override, void *stream);
 int scalce_batch_entropy_end(scalce_batch *b, void *stream);
+/* The begin half for several shards at once: ONE coder launch over the blocks of all of them, four blocks per
+ * workgroup (0.57 x the SIMD time per block of the one-block kernel at 1.2 x its latency).  A 50 M-read shard is
+ * 477 blocks = 120 workgroups; two shards fit the chip one workgroup per CU, so every coder wave has a SIMD to
+ * itself by construction and the pair is coded in the time one shard takes.  Tables are prepared on prep_stream
+ * (the host waits there, never behind a running coder), the coder and the framing are enqueued on stream.  Each
+ * shard is completed by its own scalce_batch_entropy_end / scalce_batch_finish on `stream`. */
+int scalce_batch_entropy_begin_group(scalce_batch **batches, int n, void *prep_stream, void *stream);
 /* Sharded runs: code a caller-assembled range of the run-wide reordered stream (it must start on a 10 MiB
  * block boundary) against the run-wide table; result in SCALCE_OUT_QUAL of `mate`. */
 int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
                                 uint64_t nsym, void *stream);
 int scalce_batch_entropy_stream_begin(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
                                       uint64_t nsym, void *stream);
+/* ... or only remembered, to be coded by the next scalce_batch_entropy_begin_group that includes this shard. */
+int scalce_batch_entropy_stream_prepare(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                        uint64_t nsym, void *stream);
 /* Piecewise device copy: dst[piece_dst[p] + i] = src[piece_src[p] + i]; pieces contiguous in src, sorted. */
 int scalce_copy_pieces(scalce_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, const uint64_t *d_piece_src,
                        const uint64_t *d_piece_dst, uint32_t npieces, uint64_t total_bytes, void *stream);

@@ -181,7 +181,8 @@ struct scalce_batch {
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
   DBuf perm_a, perm_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   u32 order_run_members = 0;
-  DBuf out_reads[2], out_names, name_off, ac_tab, ac_cum, ac_blocks, ac_sizes, ac_off, out_qual[2];
+  DBuf out_reads[2], out_names, name_off, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
+  std::vector<AcBlockDesc> ac_desc_host;  // block descriptors of the last coder launch this shard led
   u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
   // host-side results
   u64 out_reads_bytes[2] = {0, 0}, out_names_bytes = 0, out_qual_bytes[2] = {0, 0};
@@ -193,7 +194,7 @@ struct scalce_batch {
   bool timing = false;
   float stage_ms[ST_COUNT] = {0};
   int stage_launches[ST_COUNT] = {0};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_group = nullptr;
   // HIP-event pairs around every ac_encode_k launch (the dominant kernel); read by scalce_batch_kernel_ms
   bool ktiming = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
@@ -201,6 +202,10 @@ struct scalce_batch {
   u64 k_in_bytes = 0, k_out_bytes = 0;
   // entropy launched but its result size not read back yet (scalce_batch_entropy_begin / _end): blocks per mate
   u32 ent_pending[2] = {0, 0};
+  // symbol stream to code per mate: the shard's own reordered stream, or one the caller assembled (sharded runs)
+  const u8 *ent_sym[2] = {nullptr, nullptr};
+  u64 ent_nsym[2] = {0, 0};
+  bool ent_external[2] = {false, false};
 };
 
 static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
@@ -226,8 +231,9 @@ static void free_all(scalce_batch *b) {
                  &b->chosen, &b->G, &b->seg, &b->dirty, &b->cand_place, &b->Gseg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
                  &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S, &b->run_head, &b->run_hcount, &b->run_rank, &b->runid,
                  &b->run_items_a, &b->run_items_b, &b->run_pos,
-                 &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab, &b->ac_cum,
-                 &b->ac_blocks, &b->ac_sizes, &b->ac_off, &b->out_qual[0], &b->out_qual[1]};
+                 &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab[0], &b->ac_cum[0],
+                 &b->ac_blocks[0], &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1],
+                 &b->ac_sizes[1], &b->ac_off[1], &b->ac_desc, &b->out_qual[0], &b->out_qual[1]};
   for (DBuf *d : all)
     if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
   if (b->d_err) hipFree(b->d_err);
@@ -773,68 +779,150 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
 // ---- stage 5: entropy ---------------------------------------------------------------------------------
 // Code one mate's symbol stream `d_sym` (nsym symbols, first symbol = start of a 10 MiB block of the run-wide
 // stream) against `table` (device, 512000 x u32, already scaled).
-static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipStream_t s) {
+// One coder job = one mate's symbol stream of one shard.  A launch codes the blocks of one or more jobs.
+struct AcJob {
+  scalce_batch *b;
+  int m;
+  const u8 *sym;
+  u64 nsym;
+  u32 nblk;
+  bool general;
+};
+static const u64 AC_STRIDE = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
+
+// table -> reciprocal fractions, buffers; one short wait for the largest context total
+static int ac_prepare(AcJob &j, hipStream_t s) {
+  scalce_batch *b = j.b;
   scalce_ctx *c = b->ctx;
+  const int m = j.m;
   u32 *table = b->table[m].as<u32>();
-  ENSURE(b, b->ac_tab, sizeof(uint4) * 512000);
-  ENSURE(b, b->ac_cum, sizeof(u32) * 6400 * 81);
-  HIP_TRY(c, hipMemsetAsync(b->d_small + 12, 0, sizeof(u32), s));
-  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab.as<uint4>(), b->ac_cum.as<u32>(), b->d_small + 12);
+  ENSURE(b, b->ac_tab[m], sizeof(uint4) * 512000);
+  ENSURE(b, b->ac_cum[m], sizeof(u32) * 6400 * 81);
+  HIP_TRY(c, hipMemsetAsync(b->d_small + 12 + m, 0, sizeof(u32), s));
+  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab[m].as<uint4>(), b->ac_cum[m].as<u32>(), b->d_small + 12 + m);
   u32 max_total = 0;
-  { int rc = read_u32(b, b->d_small + 12, &max_total, 1, s); if (rc) return rc; }
+  { int rc = read_u32(b, b->d_small + 12 + m, &max_total, 1, s); if (rc) return rc; }
   // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
   // follows it there bit for bit
-  const bool general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
-  const u32 nblk = cdiv(nsym, AC_BLOCK_SYMS);
-  const u64 stride = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
-  ENSURE(b, b->ac_blocks, (size_t)nblk * stride + 64);
-  ENSURE(b, b->ac_sizes, sizeof(u32) * (nblk + 2));
-  ENSURE(b, b->ac_off, sizeof(u64) * (nblk + 2));
-  if (!nblk) { b->out_qual_bytes[m] = 0; return SCALCE_OK; }
+  j.general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
+  j.nblk = (u32)cdiv(j.nsym, AC_BLOCK_SYMS);
+  ENSURE(b, b->ac_blocks[m], (size_t)j.nblk * AC_STRIDE + 64);
+  ENSURE(b, b->ac_sizes[m], sizeof(u32) * (j.nblk + 2));
+  ENSURE(b, b->ac_off[m], sizeof(u64) * (j.nblk + 2));
+  // the framed stream is sized for the worst case (every block at its cap): no size has to come back from the
+  // device before the frame kernel can be enqueued
+  ENSURE(b, b->out_qual[m], (size_t)j.nblk * (AC_STRIDE + 4) + 64);
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(j.nblk ? j.nblk : 1) + 64));
+  if (!j.nblk) b->out_qual_bytes[m] = 0;
+  return SCALCE_OK;
+}
+
+// ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 = ac_encode4_k.
+static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s) {
+  scalce_batch *lead = jobs[0].b;
+  scalce_ctx *c = lead->ctx;
+  u32 total = 0;
+  bool general = false;
+  for (int i = 0; i < njobs; i++) { total += jobs[i].nblk; general |= jobs[i].general; }
+  if (!total) return SCALCE_OK;
   AcEncArgs a;
-  a.sym = d_sym; a.nsym = nsym; a.tab = b->ac_tab.as<uint4>(); a.out = b->ac_blocks.as<u8>(); a.out_stride = stride;
-  a.out_cap = (u32)stride; a.out_size = b->ac_sizes.as<u32>(); a.err = b->d_err;
+  memset(&a, 0, sizeof a);
   a.slow_threshold = 32;
-  a.simd_load = c->d_simd_load;
-  a.prof = nullptr;
-  if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * nblk)); }
+  a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
-  if (b->ktiming) {
-    if (b->kev_used == b->kev.size()) {
+  if (lead->ktiming) {
+    if (lead->kev_used == lead->kev.size()) {
       hipEvent_t x, y;
       HIP_TRY(c, hipEventCreate(&x));
       HIP_TRY(c, hipEventCreate(&y));
-      b->kev.emplace_back(x, y);
+      lead->kev.emplace_back(x, y);
     }
-    ke0 = b->kev[b->kev_used].first; ke1 = b->kev[b->kev_used].second;
-    b->kev_used++;
-    hipEventRecord(ke0, s);
+    ke0 = lead->kev[lead->kev_used].first; ke1 = lead->kev[lead->kev_used].second;
+    lead->kev_used++;
   }
-  if (general) LAUNCH(ac_encode_k<true>, nblk, 128, 0, s, a);
-  else LAUNCH(ac_encode_k<false>, nblk, 128, 0, s, a);
-  if (ke1) hipEventRecord(ke1, s);
-  if (a.prof) {  // profiling only: where do the chain wave's cycles go (100 MHz shader clock ticks)
-    std::vector<u64> h(3 * (size_t)nblk);
-    HIP_TRY(c, hipMemcpy(h.data(), a.prof, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
-    double sys = 0, tot = 0, rounds = 0;
-    for (u32 i = 0; i < nblk; i++) { sys += h[3 * i]; tot += h[3 * i + 1]; rounds += h[3 * i + 2]; }
-    fprintf(stderr, "ac prof: %u blocks, per plain round: %.1f ticks in the 64 steps, %.1f ticks in all (%.0f plain rounds per block)\n",
-            nblk, sys / rounds, tot / rounds, rounds / nblk);
-    hipFree(a.prof);
+  if (blocks_per_wg == 1) {
+    if (njobs != 1) { set_err(c, "internal: ac_encode_k takes one job"); return SCALCE_ERR_ARG; }
+    scalce_batch *b = jobs[0].b;
+    const int m = jobs[0].m;
+    a.sym = jobs[0].sym; a.nsym = jobs[0].nsym; a.tab = b->ac_tab[m].as<uint4>(); a.out = b->ac_blocks[m].as<u8>();
+    a.out_stride = AC_STRIDE; a.out_cap = (u32)AC_STRIDE; a.out_size = b->ac_sizes[m].as<u32>(); a.err = b->d_err;
+    if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * total)); }
+    if (ke0) hipEventRecord(ke0, s);
+    if (general) LAUNCH(ac_encode_k<true>, total, 128, 0, s, a);
+    else LAUNCH(ac_encode_k<false>, total, 128, 0, s, a);
+    if (ke1) hipEventRecord(ke1, s);
+    if (a.prof) {  // profiling only: where do the chain wave's cycles go (shader clock)
+      std::vector<u64> h(3 * (size_t)total);
+      HIP_TRY(c, hipMemcpy(h.data(), a.prof, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
+      double sys = 0, tot = 0, rounds = 0;
+      for (u32 i = 0; i < total; i++) { sys += h[3 * i]; tot += h[3 * i + 1]; rounds += h[3 * i + 2]; }
+      fprintf(stderr, "ac prof: %u blocks, per plain round: %.1f cycles in the 64 steps, %.1f cycles in all (%.0f plain rounds per block)\n",
+              total, sys / rounds, tot / rounds, rounds / total);
+      hipFree(a.prof);
+    }
+  } else {
+    // block descriptors: the launch may hold blocks of several shards, each with its own table and output
+    std::vector<AcBlockDesc> &d = lead->ac_desc_host;
+    d.clear();
+    d.reserve(total);
+    for (int i = 0; i < njobs; i++) {
+      scalce_batch *b = jobs[i].b;
+      const int m = jobs[i].m;
+      for (u32 k = 0; k < jobs[i].nblk; k++) {
+        AcBlockDesc x;
+        const u64 off = (u64)k * AC_BLOCK_SYMS;
+        x.sym = jobs[i].sym + off;
+        x.tab = b->ac_tab[m].as<uint4>();
+        x.dst = reinterpret_cast<u32 *>(b->ac_blocks[m].as<u8>() + (u64)k * AC_STRIDE);
+        x.out_size = b->ac_sizes[m].as<u32>() + k;
+        x.err = b->d_err;
+        x.n = (u32)std::min<u64>(AC_BLOCK_SYMS, jobs[i].nsym - off);
+        x.index = k;
+        d.push_back(x);
+      }
+    }
+    ENSURE(lead, lead->ac_desc, sizeof(AcBlockDesc) * total);
+    HIP_TRY(c, hipMemcpyAsync(lead->ac_desc.p, d.data(), sizeof(AcBlockDesc) * total, hipMemcpyHostToDevice, s));
+    a.desc = lead->ac_desc.as<AcBlockDesc>();
+    a.nblocks = total;
+    a.out_cap = (u32)AC_STRIDE;
+    if (ke0) hipEventRecord(ke0, s);
+    if (general) LAUNCH(ac_encode4_k<true>, cdiv(total, AC4), 192, 0, s, a);
+    else LAUNCH(ac_encode4_k<false>, cdiv(total, AC4), 192, 0, s, a);
+    if (ke1) hipEventRecord(ke1, s);
   }
-  b->k_in_bytes += nsym;
-  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nblk) + 64));
-  exclusive_scan<u64>(AcFrameLen{b->ac_sizes.as<u32>()}, nblk, StoreTo<u64>{b->ac_off.as<u64>()}, b->scan_ws.as<u64>(),
-                      b->d_small64 + 8 + m, s);
-  // no host round trip here: the framed stream is sized for the worst case (every block at its cap) and the
-  // frame kernel takes the block sizes from the device, so the whole stage is enqueued behind the coder and the
-  // caller may go on with another shard (scalce_batch_entropy_begin); the total is read back by entropy_collect
-  ENSURE(b, b->out_qual[m], (size_t)nblk * (stride + 4) + 64);
-  LAUNCH(ac_frame_k, dim3(cdiv(stride, 16 * 256), nblk), 256, 0, s, b->ac_blocks.as<u8>(), stride, b->ac_sizes.as<u32>(),
-         b->ac_off.as<u64>(), b->out_qual[m].as<u8>());
-  b->ent_pending[m] = nblk;
+  for (int i = 0; i < njobs; i++) lead->k_in_bytes += jobs[i].nsym;
   return SCALCE_OK;
+}
+
+// framing: sizes -> offsets -> [u32 size][bytes] per block, all enqueued; the total is read back by entropy_collect
+static int ac_frame(AcJob &j, hipStream_t s) {
+  scalce_batch *b = j.b;
+  const int m = j.m;
+  if (!j.nblk) return SCALCE_OK;
+  exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, j.nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->scan_ws.as<u64>(),
+                      b->d_small64 + 8 + m, s);
+  LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), j.nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), AC_STRIDE,
+         b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
+  b->ent_pending[m] = j.nblk;
+  return SCALCE_OK;
+}
+
+static int ac_blocks_per_wg() {
+  // one block per workgroup (lowest latency of a block) or four (0.57 x the SIMD time per block, 1.2 x the latency)
+  const char *bpw = getenv("SCALCE_AC_BLOCKS_PER_WG");
+  return (bpw && atoi(bpw) == 4) ? 4 : 1;
+}
+
+// Code one mate's symbol stream `d_sym` (nsym symbols, first symbol = start of a 10 MiB block of the run-wide
+// stream) against `table` (device, 512000 x u32, already scaled).
+static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipStream_t s) {
+  AcJob j{b, m, d_sym, nsym, 0, false};
+  int rc = ac_prepare(j, s);
+  if (rc) return rc;
+  if ((rc = ac_launch(&j, 1, ac_blocks_per_wg(), s))) return rc;
+  return ac_frame(j, s);
 }
 
 // second half of the entropy stage: wait for the coder and read the size of the framed stream(s)
@@ -846,6 +934,19 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
     b->out_qual_bytes[m] = total;
     b->k_out_bytes += total - 4ull * b->ent_pending[m];
     b->ent_pending[m] = 0;
+  }
+  return SCALCE_OK;
+}
+
+// table of one mate: the shard's own statistics, scaled (compress.cpp:297-303), or the caller's run-wide table
+static int ac_table_for(scalce_batch *b, int m, const uint32_t *d_table_override, u64 nsym, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  u32 *table = b->table[m].as<u32>();
+  if (d_table_override) {
+    HIP_TRY(c, hipMemcpyAsync(table, d_table_override + (size_t)m * 512000, sizeof(u32) * 512000, hipMemcpyDeviceToDevice, s));
+  } else {
+    const u32 factor = 1 + (u32)(nsym / 0xFFFFFFFFull);  // compress.cpp:297-303
+    LAUNCH(ac_scale_k, cdiv(512000, 256), 256, 0, s, b->freq4[m].as<u64>(), factor, table);
   }
   return SCALCE_OK;
 }
@@ -862,16 +963,64 @@ extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_tab
       b->out_qual_bytes[m] = nsym;
       continue;
     }
-    u32 *table = b->table[m].as<u32>();
-    if (d_table_override) {
-      HIP_TRY(c, hipMemcpyAsync(table, d_table_override + (size_t)m * 512000, sizeof(u32) * 512000, hipMemcpyDeviceToDevice, s));
-    } else {
-      const u32 factor = 1 + (u32)(nsym / 0xFFFFFFFFull);  // compress.cpp:297-303
-      LAUNCH(ac_scale_k, cdiv(512000, 256), 256, 0, s, b->freq4[m].as<u64>(), factor, table);
-    }
-    int rc = encode_stream(b, m, b->qs[m].as<u8>(), nsym, s);
+    int rc = ac_table_for(b, m, d_table_override, nsym, s);
     if (rc) return rc;
+    if ((rc = encode_stream(b, m, b->qs[m].as<u8>(), nsym, s))) return rc;
   }
+  return SCALCE_OK;
+}
+
+// Several shards, ONE coder launch (four blocks per workgroup): a shard of 477 blocks fills 120 workgroups, so
+// the blocks of two shards fit the 256 CUs one workgroup each -- every chain wave gets a SIMD of its own by
+// construction, which two separate launches cannot guarantee (the dispatcher places waves without knowing their
+// role; where two chains meet the younger one starves).  Tables are prepared on `prep_stream` (the caller's front
+// stream: the host waits there for each table's largest context total, never behind a running coder); coder and
+// framing are enqueued on `stream` behind that.  Shards that called scalce_batch_entropy_stream_prepare code the
+// stream they were given, the others their own reordered stream.
+extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *prep_stream, void *stream) {
+  if (!bs || n <= 0 || n > 16) return SCALCE_ERR_ARG;
+  for (int i = 0; i < n; i++) if (!bs[i] || bs[i]->ctx != bs[0]->ctx) return SCALCE_ERR_ARG;
+  hipStream_t ps = (hipStream_t)prep_stream, s = (hipStream_t)stream;
+  scalce_ctx *c = bs[0]->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<AcJob> jobs;
+  for (int i = 0; i < n; i++) {
+    scalce_batch *b = bs[i];
+    for (int m = 0; m < b->nm; m++) {
+      const u64 own = b->N * (u64)b->L[m];
+      if (b->p.no_ac) { b->out_qual_bytes[m] = own; continue; }
+      AcJob j{b, m, b->ent_external[m] ? b->ent_sym[m] : b->qs[m].as<u8>(), b->ent_external[m] ? b->ent_nsym[m] : own, 0, false};
+      if (!b->ent_external[m]) { int rc = ac_table_for(b, m, nullptr, own, ps); if (rc) return rc; }
+      b->ent_external[m] = false;
+      int rc = ac_prepare(j, ps);
+      if (rc) return rc;
+      jobs.push_back(j);
+    }
+  }
+  if (jobs.empty()) return SCALCE_OK;
+  if (ps != s) {  // the coder stream continues behind the preparation
+    hipEvent_t ev = bs[0]->ev_group;
+    if (!ev) { HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); bs[0]->ev_group = ev; }
+    HIP_TRY(c, hipEventRecord(ev, ps));
+    HIP_TRY(c, hipStreamWaitEvent(s, ev, 0));
+  }
+  int rc = ac_launch(jobs.data(), (int)jobs.size(), 4, s);
+  if (rc) return rc;
+  for (auto &j : jobs) if ((rc = ac_frame(j, s))) return rc;
+  return SCALCE_OK;
+}
+
+// Sharded runs, grouped launch: remember the caller-assembled range of the run-wide stream and its table; the next
+// scalce_batch_entropy_begin_group codes it.
+extern "C" int scalce_batch_entropy_stream_prepare(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
+                                                   uint64_t nsym, void *stream) {
+  if (!b || mate < 0 || mate >= b->nm || !d_table || (nsym && !d_symbols) || b->p.no_ac) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(b->table[mate].p, d_table, sizeof(u32) * 512000, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  b->ent_sym[mate] = d_symbols;
+  b->ent_nsym[mate] = nsym;
+  b->ent_external[mate] = true;
   return SCALCE_OK;
 }
 

@@ -211,7 +211,7 @@ class ShardResult:
     pass
 
 
-def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, stream=0, ent_stream=None):
+def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, stream=0, ent_stream=None, prepare_only=False):
     """SPMD: every rank calls this with its own shard.  Leaves the rank's pieces of the archive in `batch`
     (reads/names payload of the shard, AC blocks of the rank's block range) and returns the metadata needed to
     assemble or to report.
@@ -220,7 +220,9 @@ def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, st
     coder is only enqueued there, behind everything issued so far, and the call returns while it runs: the
     caller owes a `batch.finish(ent_stream.cuda_stream)` before it reads the result or reuses `batch`, and can
     start the next shard's front stages (and their collectives, still issued in program order on every rank)
-    in the meantime."""
+    in the meantime.  With `prepare_only` the coder is not even enqueued: the shard's range of the run-wide stream and
+    the run-wide table are handed to the batch (entropy_stream_prepare) and the caller codes several shards with one
+    launch (host.entropy_begin_group), then finishes each."""
     import torch
     dev = torch.device("cuda", ctx_device(ctx))
     p = batch.params
@@ -299,7 +301,9 @@ def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, st
                 ps = torch.from_numpy(plan["piece_src"].astype(np.int64)).to(dev)
                 pd = torch.from_numpy(plan["piece_dst"].astype(np.int64)).to(dev)
                 ctx.copy_pieces(got.data_ptr(), mine.data_ptr(), ps.data_ptr(), pd.data_ptr(), ps.numel(), got.numel(), stream)
-            if ent_stream is None:
+            if prepare_only:
+                batch.entropy_stream_prepare(m, tables[m].data_ptr(), mine.data_ptr(), plan["hi"] - plan["lo"], stream)
+            elif ent_stream is None:
                 batch.entropy_stream(m, tables[m].data_ptr(), mine.data_ptr(), plan["hi"] - plan["lo"], stream)
                 batch.finish(stream)
             else:

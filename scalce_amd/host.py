@@ -80,6 +80,8 @@ def lib():
     L.scalce_batch_entropy_begin.argtypes = [vp, vp, vp]
     L.scalce_batch_entropy_end.argtypes = [vp, vp]
     L.scalce_batch_entropy_stream_begin.argtypes = [vp, i32, vp, vp, u64, vp]
+    L.scalce_batch_entropy_stream_prepare.argtypes = [vp, i32, vp, vp, u64, vp]
+    L.scalce_batch_entropy_begin_group.argtypes = [C.POINTER(vp), i32, vp, vp]
     L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
     L.scalce_batch_finish.argtypes = [vp, vp]
     L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
@@ -193,6 +195,13 @@ class Context:
             pass
 
 
+def entropy_begin_group(batches, prep_stream=0, stream=0):
+    """ONE coder launch over the blocks of several shards (scalce_batch_entropy_begin_group); each shard is completed
+    by its own entropy_end / finish on `stream`."""
+    arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
+    batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group(arr, len(batches), prep_stream, stream))
+
+
 class Batch:
     """One FASTQ shard in HBM (scalce_batch)."""
 
@@ -269,6 +278,9 @@ class Batch:
 
     def entropy_stream_begin(self, mate, d_table, d_symbols, nsym, stream=0):
         self._check(self.L.scalce_batch_entropy_stream_begin(self.h, mate, d_table, d_symbols, int(nsym), stream))
+
+    def entropy_stream_prepare(self, mate, d_table, d_symbols, nsym, stream=0):
+        self._check(self.L.scalce_batch_entropy_stream_prepare(self.h, mate, d_table, d_symbols, int(nsym), stream))
 
     def front(self, d_text1, n1, d_text2=None, n2=0, stream=0):
         """Every stage before the entropy coder (ingest .. emit) on `stream`."""

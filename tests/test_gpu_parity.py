@@ -386,3 +386,42 @@ def test_quality_statistics_on_odd_alphabets(alphabet, ctx, oracle_trie):
         q = rng.integers(76, 80, size=(n, L))
     quals = (q + 33).astype(np.uint8)
     check_against_oracle(ctx, oracle_trie, bases, quals, label=alphabet)
+
+
+@pytest.mark.gpu
+def test_grouped_coder_launch_equals_separate_launches(ctx, monkeypatch):
+    """scalce_batch_entropy_begin_group: ONE coder launch (four blocks per workgroup, per-block descriptors) over three
+    shards of different sizes and alphabets -- so workgroups hold blocks of different shards, tables and lengths --
+    gives every shard the bytes its own launch gives it (one-block and four-block kernel)."""
+    from gpu_util import device_bytes
+    rng = np.random.default_rng(5)
+    specs = [(230_000, 100, 31), (120_000, 100, 32), (70_000, 36, 33)]   # 3, 2 and 1 blocks, the last ones short
+    texts, alone = [], []
+    for n, L, seed in specs:
+        bases, quals = synth.reads_and_quals(n, L, seed=seed)
+        if seed == 32:
+            quals = (rng.integers(0, 80, size=(n, L)) + 33).astype(np.uint8)
+        fq = synth.fastq_bytes_fast(bases, quals)
+        texts.append((device_bytes(fq), len(fq), n, L))
+    for variant in ("1", "4"):
+        monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", variant)
+        outs = []
+        for t, nb, n, L in texts:
+            b = host.Batch(ctx, L, n + 8, nb + 64)
+            b.compress(t.data_ptr(), nb)
+            b.finish()
+            outs.append(b.output(host.OUT_QUAL, 0).copy())
+        alone.append(outs)
+    monkeypatch.delenv("SCALCE_AC_BLOCKS_PER_WG")
+    for a1, a4 in zip(*alone):
+        assert len(a1) == len(a4) and (a1 == a4).all()
+    group = []
+    for t, nb, n, L in texts:
+        b = host.Batch(ctx, L, n + 8, nb + 64)
+        b.front(t.data_ptr(), nb)
+        group.append(b)
+    host.entropy_begin_group(group)
+    for b, want in zip(group, alone[0]):
+        b.finish()
+        got = b.output(host.OUT_QUAL, 0)
+        assert len(got) == len(want) and (got == want).all()
