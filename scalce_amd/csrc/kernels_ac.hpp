@@ -347,12 +347,11 @@ struct AcSink {
     const int f = upto ? 63 - __clzll((long long)upto) : -1;             // last emitting lane <= lane
     const u32 sbase = __shfl(S - u, f < 0 ? 0 : f, 64);                   // sum before that lane
     const u32 U = f < 0 ? pend + S : S - sbase;                           // pending after this lane
-    u32 P = __shfl_up(U, 1, 64);
-    if (lane == 0) P = pend;
+    const u32 P = __builtin_amdgcn_update_dpp(pend, U, 0x138, 0xF, 0xF, false);  // wave_shr:1, lane 0 keeps pend
     const u32 top = flag ? (k == 32 ? rH : (rH >> (32 - k))) : 0u;        // the k agreed bits
     const u32 msb = flag ? (top >> (k - 1)) : 0u;
     const u32 rest = (k > 1) ? (top & ((1u << (k - 1)) - 1)) : 0u;
-    const u32 pend_out = __shfl(U, 63, 64);
+    const u32 pend_out = __builtin_amdgcn_readlane(U, 63);
     if (__any(flag && P > slow_threshold)) {
       // an underflow run longer than 32 bits (about once per 2^32 symbols): walk the round serially
       for (int j = 0; j < 64; j++) {
@@ -369,7 +368,7 @@ struct AcSink {
     }
     const u32 nbits = flag ? k + P : 0u;
     const u32 incl = wave_inclusive_sum(nbits);
-    const u32 total = __shfl(incl, 63, 64);
+    const u32 total = __builtin_amdgcn_readlane(incl, 63);
     const u32 o = c0 + incl - nbits;
     for (int w = lane; w < AC_BUF_WORDS; w += 64) buf[w] = (w == 0) ? carry : 0u;
     __builtin_amdgcn_wave_barrier();
@@ -642,6 +641,7 @@ __global__ __launch_bounds__(192) void ac_encode4_k(AcEncArgs a) {
 
   if (wv != 0) {
     // ================= helper waves: two blocks each =================
+    __builtin_amdgcn_s_setprio(2);  // must not fall behind the chain when other shards' front stages fill the chip
     const int h = wv - 1;
     u32 *buf = bufs[h];
     AcSink sink[2];

@@ -25,6 +25,19 @@ __device__ __forceinline__ T wave_inclusive_sum(T v) {
   }
   return v;
 }
+// 32-bit sums stay in the DPP network: four shifted adds inside each 16-lane row, then the row totals travel with
+// row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).  Six v_add_u32_dpp instead of six
+// ds_bpermute round trips through the LDS crossbar (each ~100 cycles of dependent latency).
+template <>
+__device__ __forceinline__ u32 wave_inclusive_sum<u32>(u32 v) {
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xF, 0xF, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xF, 0xF, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, true);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, true);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
 
 // Exclusive prefix over a block of NW waves.  smem must hold NW entries.  Ends with a barrier,
 // so smem may be reused right after.

@@ -35,9 +35,19 @@ def stages(b, s):
 
 print("alone      :", stages(B, s2))
 A.front(text.data_ptr(), nbytes, None, 0, s1.cuda_stream)
+GROUP = int(os.environ.get("PROBE_GROUP", "1"))
+if GROUP > 1:
+    A2 = host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)])
+    A2.compress(text.data_ptr(), nbytes, None, 0, s1.cuda_stream); A2.finish(s1.cuda_stream)
+    A2.front(text.data_ptr(), nbytes, None, 0, s1.cuda_stream)
 t0 = time.perf_counter()
-A.entropy_begin(None, s1.cuda_stream)
+if GROUP > 1:
+    host.entropy_begin_group([A, A2], s1.cuda_stream, s1.cuda_stream)
+else:
+    A.entropy_begin(None, s1.cuda_stream)
 time.sleep(0.02)
 print("beside AC  :", stages(B, s2), "(front took %.0f ms of host time)" % ((time.perf_counter() - t0) * 1e3))
+if GROUP > 1:
+    print("beside AC 2:", stages(B, s2))
 A.finish(s1.cuda_stream)
 print("AC total   : %.0f ms" % ((time.perf_counter() - t0) * 1e3))
