@@ -30,10 +30,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="shards in flight per GPU: the coder of shard j runs on its own stream while the front "
                          "stages of shard j+1 run (1 = strictly one after the other)")
-    ap.add_argument("--group", type=int, default=1,
+    ap.add_argument("--group", type=int, default=2,
                     help="shards per coder launch (scalce_batch_entropy_begin_group, four blocks per workgroup); "
                          "1 = one launch per shard with the one-block-per-workgroup kernel")
     ap.add_argument("--coders-overlap", action="store_true",
@@ -192,14 +192,16 @@ def main():
         cpu = cpu_baseline(text, n, L, args.cpu_sample)
 
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_v9_bench50m_pmc_fetch_write.json")
+    kname = "ac_encode4_k" if G > 1 else "ac_encode_k"
+    pmc = os.path.join(ROOT, "profiles", "r01_v10_bench50m_pmc_fetch_write.json" if G > 1 else "r01_v9_bench50m_pmc_fetch_write.json")
     if rank == 0 and n == 50_000_000 and L == 100 and os.path.exists(pmc):
         # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of
         # KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM")
         for row in json.load(open(pmc)):
-            if "ac_encode_k" in row["kernel"]:
-                traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / max(row["calls"], 1))
-                traffic_src = "profiles/r01_v9_bench50m_pmc_fetch_write.json"
+            if kname + "<" in row["kernel"]:
+                units = row.get("shards", row["calls"]) / G  # launches of G shards the profiled bytes stand for
+                traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / max(units, 1))
+                traffic_src = os.path.relpath(pmc, ROOT)
     if rank == 0:
         total_in = nbytes * world
         ms_per_step = dt / args.steps * 1e3
@@ -226,12 +228,14 @@ def main():
                        "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if world == 1 else ": read ranges per rank, run-wide tie-break / quality model / 10 MiB blocks (RCCL all-gather, all-reduce, all-to-all)"),
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
                        "shards_in_flight": D, "shards_per_coder_launch": G, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
-            "roofline": {"bound": "hbm", "kernel": "ac_encode_k", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(per_launch_ms, 3), "alg_bytes_per_launch": int(alg_bytes),
                          "ns_per_symbol_per_block": round(per_launch_ms * 1e6 / min(max(k["bytes_in"] / max(k["launches"], 1), 1), 10 * 1024 * 1024), 2),
-                         "note": "serial coder chain per 10 MiB block: latency-bound (ns per symbol per block is the figure "
-                                 "to watch); blocks run concurrently, one 2-wave workgroup each"},
+                         "shards_per_launch": G,
+                         "note": "serial coder chain per 10 MiB block: bound by the issue slots of one wavefront, not by "
+                                 "bandwidth (ns per symbol per block is the figure to watch); blocks run concurrently, "
+                                 + ("four per 3-wave workgroup, one launch for %d shards" % G if G > 1 else "one 2-wave workgroup each")},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -22,7 +22,7 @@ def _shard_text(bases, quals, bounds, r):
 
 
 @pytest.mark.parametrize("world,n,L,deferred", [(3, 9000, 100, False), (2, 230000, 100, False), (4, 5000, 36, False),
-                                                 (2, 230000, 100, True), (3, 9000, 100, True)])
+                                                 (2, 230000, 100, True), (3, 9000, 100, True), (2, 230000, 100, "group")])
 def test_sharded_equals_single_with_one_chunk_per_shard(world, n, L, deferred, patterns_blob):
     import torch
     from gpu_util import device_bytes
@@ -68,6 +68,13 @@ def test_sharded_equals_single_with_one_chunk_per_shard(world, n, L, deferred, p
         r = comm.rank
         if not deferred:
             return dist.compress_shard(comm, ctx, batches[r], dtexts[r].data_ptr(), len(texts[r]))
+        if deferred == "group":
+            # the way bench.py --group does it: the shard only hands its range of the run-wide stream to the batch,
+            # the coder launch comes later and may hold other shards' blocks as well (here: this rank's shard alone)
+            res = dist.compress_shard(comm, ctx, batches[r], dtexts[r].data_ptr(), len(texts[r]), prepare_only=True)
+            host.entropy_begin_group([batches[r]])
+            batches[r].finish()
+            return res
         # the way bench.py keeps shards in flight: front stages on one stream, the coder only enqueued on another
         front, ent = torch.cuda.Stream(), torch.cuda.Stream()
         front.wait_stream(torch.cuda.default_stream())

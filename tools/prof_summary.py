@@ -2,7 +2,7 @@
 """Condense rocprofv3 output directories into the small summaries kept under profiles/.
 
   prof_summary.py stats <dir> <out.csv>           kernel-trace --stats run: per-kernel calls / total / avg / min / max (ms)
-  prof_summary.py pmc <fetch_dir> <write_dir> <out.json>   two --pmc runs (FETCH_SIZE, WRITE_SIZE): KB per kernel
+  prof_summary.py pmc <fetch_dir> <write_dir> <out.json> [shards]   two --pmc runs (FETCH_SIZE, WRITE_SIZE): KB per kernel
 """
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -42,10 +42,13 @@ def counters(d, name):
     return acc, calls
 
 
-def pmc(fd, wd, out):
+def pmc(fd, wd, out, shards=None):
     fe, calls = counters(fd, "FETCH_SIZE")
     wr, _ = counters(wd, "WRITE_SIZE")
     rows = [{"kernel": k, "calls": calls[k], "FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0)} for k in fe]
+    if shards:  # shards the profiled run pushed through every stage (a coder launch may hold several)
+        for r in rows:
+            r["shards"] = shards
     rows.sort(key=lambda r: -(r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"]))
     json.dump(rows, open(out, "w"), indent=1)
 
@@ -54,4 +57,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else None)
