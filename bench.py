@@ -82,7 +82,7 @@ def main():
     # and most lanes idle, so the next shards' front stages run beside it
     front = torch.cuda.Stream()
     ent = [torch.cuda.Stream() for _ in range(D)]
-    busy = [None] * D      # stream the slot's coder was enqueued on
+    busy = [None] * D      # event behind the slot's coder launch
     pending = []           # slots whose front stages are done and whose coder launch is still to come (G > 1)
     ngroups = [0]
 
@@ -96,8 +96,12 @@ def main():
         torch.cuda.synchronize()
 
     def retire(slot):
+        # wait for the shard's coder on an EVENT and read its results over the front stream: HIP streams share a few
+        # hardware queues, and a read-back submitted on the coder's own (finished) stream can land in a queue behind
+        # the next coder launch and wait for all of it (measured: 400 ms per second pair of shards)
         if busy[slot] is not None:
-            batches[slot].finish(busy[slot].cuda_stream)  # waits for the coder, checks the device error word
+            busy[slot].synchronize()
+            batches[slot].finish(front.cuda_stream)  # sizes of the coded streams, device error word
             busy[slot] = None
 
     def chain_coders(stream_now, stream_before):
@@ -109,6 +113,11 @@ def main():
 
     last_coder = [None]
 
+    coder_done = [None]  # event behind the last coder launch
+
+    def coder_idle():
+        return coder_done[0] is None or coder_done[0].query()
+
     def launch_group():
         if not pending:
             return
@@ -116,15 +125,27 @@ def main():
         ngroups[0] += 1
         chain_coders(es, last_coder[0])
         host.entropy_begin_group([batches[sl] for sl in pending], front.cuda_stream, es.cuda_stream)
+        coder_done[0] = torch.cuda.Event()
+        coder_done[0].record(es)
         for sl in pending:
-            busy[sl] = es
+            busy[sl] = coder_done[0]
         last_coder[0] = es
         pending.clear()
+
+    trace = os.environ.get("BENCH_TRACE")
+    tr0 = [time.perf_counter()]
+
+    def mark(what):
+        if trace and rank == 0:
+            t = time.perf_counter()
+            print("  [%8.1f ms] %s" % ((t - tr0[0]) * 1e3, what), file=sys.stderr)
 
     def submit(j, last):
         slot = j % D
         b = batches[slot]
+        mark(f"shard {j}: retire slot {slot}")
         retire(slot)
+        mark(f"shard {j}: front")
         with torch.cuda.stream(front):
             if G == 1:
                 es = ent[slot]
@@ -137,7 +158,8 @@ def main():
                     chain_coders(es, last_coder[0])
                     state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
                                                        ent_stream=es)
-                busy[slot] = es
+                busy[slot] = torch.cuda.Event()
+                busy[slot].record(es)
                 last_coder[0] = es
             else:
                 if world == 1:
@@ -146,8 +168,10 @@ def main():
                     state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
                                                        prepare_only=True)
                 pending.append(slot)
+                mark(f"shard {j}: front done")
                 if len(pending) == G or last:
                     launch_group()
+                    mark(f"shard {j}: coder launched")
 
     def run(k):
         for j in range(k):
@@ -155,6 +179,7 @@ def main():
         for slot in range(D):
             retire(slot)
         last_coder[0] = None
+        coder_done[0] = None
 
     torch.cuda.synchronize()  # the synthetic shard was generated on the default stream
     warm = max(args.warmup, D) if args.warmup > 0 else 0  # every slot allocates its buffers outside the timed region

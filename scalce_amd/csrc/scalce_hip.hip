@@ -818,7 +818,9 @@ static int ac_prepare(AcJob &j, hipStream_t s) {
 }
 
 // ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 = ac_encode4_k.
-static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s) {
+// `ps` = the stream the tables were prepared on: the block descriptors are uploaded there (never behind a coder that
+// is still running on `s`), and `s` is made to wait for it.
+static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, hipStream_t ps) {
   scalce_batch *lead = jobs[0].b;
   scalce_ctx *c = lead->ctx;
   u32 total = 0;
@@ -830,6 +832,14 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s) {
   a.slow_threshold = 32;
   a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
+  auto join = [&]() -> int {  // `s` continues behind everything enqueued on `ps` so far
+    if (ps == s) return SCALCE_OK;
+    hipEvent_t ev = lead->ev_group;
+    if (!ev) { HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); lead->ev_group = ev; }
+    HIP_TRY(c, hipEventRecord(ev, ps));
+    HIP_TRY(c, hipStreamWaitEvent(s, ev, 0));
+    return SCALCE_OK;
+  };
   hipEvent_t ke0 = nullptr, ke1 = nullptr;
   if (lead->ktiming) {
     if (lead->kev_used == lead->kev.size()) {
@@ -848,6 +858,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s) {
     a.sym = jobs[0].sym; a.nsym = jobs[0].nsym; a.tab = b->ac_tab[m].as<uint4>(); a.out = b->ac_blocks[m].as<u8>();
     a.out_stride = AC_STRIDE; a.out_cap = (u32)AC_STRIDE; a.out_size = b->ac_sizes[m].as<u32>(); a.err = b->d_err;
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * total)); }
+    { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
     if (general) LAUNCH(ac_encode_k<true>, total, 128, 0, s, a);
     else LAUNCH(ac_encode_k<false>, total, 128, 0, s, a);
@@ -883,10 +894,11 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s) {
       }
     }
     ENSURE(lead, lead->ac_desc, sizeof(AcBlockDesc) * total);
-    HIP_TRY(c, hipMemcpyAsync(lead->ac_desc.p, d.data(), sizeof(AcBlockDesc) * total, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(lead->ac_desc.p, d.data(), sizeof(AcBlockDesc) * total, hipMemcpyHostToDevice, ps));
     a.desc = lead->ac_desc.as<AcBlockDesc>();
     a.nblocks = total;
     a.out_cap = (u32)AC_STRIDE;
+    { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
     if (general) LAUNCH(ac_encode4_k<true>, cdiv(total, AC4), 192, 0, s, a);
     else LAUNCH(ac_encode4_k<false>, cdiv(total, AC4), 192, 0, s, a);
@@ -921,7 +933,7 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
   AcJob j{b, m, d_sym, nsym, 0, false};
   int rc = ac_prepare(j, s);
   if (rc) return rc;
-  if ((rc = ac_launch(&j, 1, ac_blocks_per_wg(), s))) return rc;
+  if ((rc = ac_launch(&j, 1, ac_blocks_per_wg(), s, s))) return rc;
   return ac_frame(j, s);
 }
 
@@ -998,13 +1010,7 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
     }
   }
   if (jobs.empty()) return SCALCE_OK;
-  if (ps != s) {  // the coder stream continues behind the preparation
-    hipEvent_t ev = bs[0]->ev_group;
-    if (!ev) { HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); bs[0]->ev_group = ev; }
-    HIP_TRY(c, hipEventRecord(ev, ps));
-    HIP_TRY(c, hipStreamWaitEvent(s, ev, 0));
-  }
-  int rc = ac_launch(jobs.data(), (int)jobs.size(), 4, s);
+  int rc = ac_launch(jobs.data(), (int)jobs.size(), 4, s, ps);
   if (rc) return rc;
   for (auto &j : jobs) if ((rc = ac_frame(j, s))) return rc;
   return SCALCE_OK;
