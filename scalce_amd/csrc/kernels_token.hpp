@@ -291,6 +291,31 @@ __global__ __launch_bounds__(256) void finalize_k(FinalizeArgs a) {
   a.tokens[2 * r + 1] = (int32_t)e;
 }
 
+// After a sweep only the buckets whose `chosen` flags moved (dirty != none) need new prefix sums, and a decision only
+// ever looks at differences inside one bucket's segment: one workgroup per bucket redoes the prefix of its own segment
+// (G[pos] = Gseg[b] + flags before pos inside the segment) and the bucket's read count, all others return at once.  The
+// 61 M-event global scan per sweep (47 sweeps) this replaces cost as much as the sweeps themselves.
+__global__ __launch_bounds__(256) void seg_rescan_k(u32 nb1, const u32 *seg, const u32 *dirty, const u8 *chosen, u32 *G,
+                                                   const u32 *Gseg, u64 *counts) {
+  __shared__ u32 sm[4];
+  const u32 b = blockIdx.x;
+  if (b >= nb1 || dirty[b] == 0xFFFFFFFFu) return;
+  const u32 start = seg[b], end = seg[b + 1];
+  u32 running = Gseg[b];
+  for (u32 base = start; base < end; base += 256 * 16) {
+    const u32 p0 = base + threadIdx.x * 16;
+    u32 f[16], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { f[i] = (p0 + i < end) ? (u32)chosen[p0 + i] : 0u; mine += f[i]; }
+    u32 tot;
+    u32 ex = running + block_exclusive_sum<u32, 4>(mine, &tot, sm);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { if (p0 + i < end) G[p0 + i] = ex; ex += f[i]; }
+    running += tot;
+  }
+  if (threadIdx.x == 0) counts[b] = (u64)(running - Gseg[b]);
+}
+
 // reads per bucket from the converged prefix sums
 __global__ __launch_bounds__(256) void bucket_counts_k(u32 nb1, const u32 *G, const u32 *seg, u64 *counts, u32 *Gseg) {
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -548,7 +548,7 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   *changed = 0;
-  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie, nev = b->nev;
+  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie;
   if (!b->N || !ntie) return SCALCE_OK;
   u32 *d0 = b->dirty.as<u32>(), *d1 = d0 + nb1 + 64;
   u32 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
@@ -570,10 +570,8 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   { int rc = read_u32(b, b->d_small + 4, ch, 2, s); if (rc) return rc; }
   b->jacobi_iters++;
   *changed = ch[0] ? 1 : 0;
-  if (ch[0]) {
-    exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, b->scan_ws.as<u32>(), G + nev, s);
-    LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>(), b->Gseg.as<u32>());
-  }
+  if (ch[0])  // new prefix sums and counts for the buckets whose flags moved in this sweep
+    LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, b->seg.as<u32>(), dirty_out, b->chosen.as<u8>(), G, b->Gseg.as<u32>(), b->counts.as<u64>());
   return SCALCE_OK;
 }
 
