@@ -93,29 +93,50 @@ struct TieArgs {
   const u32 *tok_bucket;
   u32 *cand_bucket, *cand_pos;
   u32 *tie_ncand;
+  u32 lds_states;
 };
 
-__global__ __launch_bounds__(256) void tie_candidates_k(TieArgs a) {
+template <bool USE_LDS>
+__global__ __launch_bounds__(TOK_THREADS) void tie_candidates_k(TieArgs a) {
+  // same staging of the shallow (hot) states as tokenize_k: the second walk used to go to global memory for every
+  // transition and took half as long as the first walk for a fifth of the reads
+  extern __shared__ uint4 lds_dyn[];
+  uint4 *l_next = lds_dyn;
+  u32 *l_out = reinterpret_cast<u32 *>(lds_dyn + a.lds_states);
+  if (USE_LDS) {
+    for (u32 i = threadIdx.x; i < a.lds_states; i += TOK_THREADS) {
+      l_next[i] = a.next[i];
+      l_out[i] = a.outinfo[i];
+    }
+    __syncthreads();
+  }
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.ntie) return;
   const u32 r = a.tie_read[t];
   const u32 off = a.tie_off[t];
   const u32 lvmax = a.bucket_level[a.tok_bucket[r]];
-  const u8 *row = a.packed + (u64)r * a.stride;
+  const u32 *row = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
   u32 state = 0, k = 0;
-  for (int i = 0; i < a.L; i++) {
-    const uint4 nx = a.next[state];
-    const u32 c = base_at(row, i);
-    state = c == 0 ? nx.x : (c == 1 ? nx.y : (c == 2 ? nx.z : nx.w));
-    const u32 info = a.outinfo[state];
-    if (info != kNoOutD && (info >> kLevelShiftD) == lvmax) {
-      const u32 b = info & kBucketMaskD;
-      bool seen = false;
-      for (u32 j = 0; j < k; j++) seen |= (a.cand_bucket[off + j] == b);
-      if (!seen) {
-        a.cand_bucket[off + k] = b;
-        a.cand_pos[off + k] = (u32)i;
-        k++;
+  const int nw = (a.L + 15) >> 4;
+  for (int w = 0; w < nw; w++) {
+    const u32 word = row[w];
+    const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
+    for (int q = 0; q < cnt; q++) {
+      const u32 c = (word >> (8 * (q >> 2) + 6 - 2 * (q & 3))) & 3u;
+      uint4 nx;
+      if (USE_LDS && state < a.lds_states) nx = l_next[state]; else nx = a.next[state];
+      state = c == 0 ? nx.x : (c == 1 ? nx.y : (c == 2 ? nx.z : nx.w));
+      u32 info;
+      if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state];
+      if (info != kNoOutD && (info >> kLevelShiftD) == lvmax) {
+        const u32 bk = info & kBucketMaskD;
+        bool seen = false;
+        for (u32 j = 0; j < k; j++) seen |= (a.cand_bucket[off + j] == bk);
+        if (!seen) {
+          a.cand_bucket[off + k] = bk;
+          a.cand_pos[off + k] = (u32)(16 * w + q);
+          k++;
+        }
       }
     }
   }

@@ -488,7 +488,9 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.bucket_level = c->d_bucket_level;
     a.tok_bucket = b->tok_bucket.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_pos = b->cand_pos.as<u32>();
     a.tie_ncand = b->tie_ncand.as<u32>();
-    LAUNCH(tie_candidates_k, cdiv(ntie, 256), 256, 0, s, a);
+    a.lds_states = (u32)c->tok_lds_states;
+    if (a.lds_states) LAUNCH(tie_candidates_k<true>, cdiv(ntie, TOK_THREADS), TOK_THREADS, (size_t)a.lds_states * 20, s, a);
+    else LAUNCH(tie_candidates_k<false>, cdiv(ntie, TOK_THREADS), TOK_THREADS, 0, s, a);
     HIP_TRY(c, hipMemsetAsync(b->choice.p, 0, sizeof(u32) * ntie, s));
   }
   // events in read order, stable-sorted by bucket
