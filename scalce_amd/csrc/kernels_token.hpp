@@ -21,7 +21,7 @@ constexpr u32 kBucketMaskD = (1u << kLevelShiftD) - 1;
 
 // Top of the automaton staged in LDS: states are numbered in BFS order, so ids < LDS_STATES are
 // the shallowest (most visited) ones.  20 bytes per state.
-constexpr int TOK_THREADS = 256;
+constexpr int TOK_THREADS = 512;  // 16 waves per CU share two 60 KB copies of the hot states (256: 8 waves, 30.7 ms)
 
 struct TokArgs {
   const uint4 *next;    // 4 x u32 per state
