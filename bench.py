@@ -28,16 +28,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="shards in flight per GPU: the coder of shard j runs on its own stream while the front "
                          "stages of shard j+1 run (1 = strictly one after the other)")
-    ap.add_argument("--group", type=int, default=2,
+    ap.add_argument("--group", type=int, default=3,
                     help="shards per coder launch (scalce_batch_entropy_begin_group, four blocks per workgroup); "
                          "1 = one launch per shard with the one-block-per-workgroup kernel")
-    ap.add_argument("--coders-overlap", action="store_true",
-                    help="let the coders of the shards in flight run side by side instead of queueing (experiment)")
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
     ap.add_argument("--length", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="records of the CPU baseline sample (0 = skip)")
@@ -81,7 +79,11 @@ def main():
     # arithmetic coder: it is a long kernel of one wavefront per block (or per four) that leaves the memory system
     # and most lanes idle, so the next shards' front stages run beside it
     front = torch.cuda.Stream()
-    ent = [torch.cuda.Stream() for _ in range(D)]
+    # ONE coder stream: launches queue behind each other anyway (see chain_coders), and HIP maps streams onto a handful
+    # of hardware queues -- with a coder stream per slot, one of them ended up in the front stream's hardware queue and
+    # every read-back of the front stream then waited behind a 400 ms coder kernel
+    coder_stream = torch.cuda.Stream()
+    ent = [coder_stream] * D
     busy = [None] * D      # event behind the slot's coder launch
     pending = []           # slots whose front stages are done and whose coder launch is still to come (G > 1)
     ngroups = [0]
@@ -95,12 +97,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("BENCH_TRACE")
+    tr0 = [time.perf_counter()]
+
+    def mark(what):
+        if trace and rank == 0:
+            t = time.perf_counter()
+            print("  [%8.1f ms] %s" % ((t - tr0[0]) * 1e3, what), file=sys.stderr)
+
     def retire(slot):
         # wait for the shard's coder on an EVENT and read its results over the front stream: HIP streams share a few
         # hardware queues, and a read-back submitted on the coder's own (finished) stream can land in a queue behind
         # the next coder launch and wait for all of it (measured: 400 ms per second pair of shards)
         if busy[slot] is not None:
             busy[slot].synchronize()
+            mark(f"  slot {slot}: coder event reached")
             batches[slot].finish(front.cuda_stream)  # sizes of the coded streams, device error word
             busy[slot] = None
 
@@ -108,7 +119,7 @@ def main():
         # one coder launch at a time: a second one beside the first does not add throughput -- wherever the
         # dispatcher puts two chain waves on one SIMD the younger one starves (measured: 733 ms instead of 412) --
         # so the launches queue behind each other and only the front stages of the next shards run beside them
-        if stream_before is not None and not args.coders_overlap:
+        if stream_before is not None and stream_before is not stream_now:
             stream_now.wait_stream(stream_before)
 
     last_coder = [None]
@@ -131,14 +142,6 @@ def main():
             busy[sl] = coder_done[0]
         last_coder[0] = es
         pending.clear()
-
-    trace = os.environ.get("BENCH_TRACE")
-    tr0 = [time.perf_counter()]
-
-    def mark(what):
-        if trace and rank == 0:
-            t = time.perf_counter()
-            print("  [%8.1f ms] %s" % ((t - tr0[0]) * 1e3, what), file=sys.stderr)
 
     def submit(j, last):
         slot = j % D

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u
   }
 }
 
-// one 10 MiB block of a coder launch that spans several symbol streams (ac_encode4_k)
+// one 10 MiB block of a coder launch that spans several symbol streams (ac_encode_rows_k)
 struct AcBlockDesc {
   const u8 *sym;        // first symbol of the block
   const uint4 *tab;     // reciprocal-fraction table of the block's stream
@@ -80,7 +80,7 @@ struct AcEncArgs {
   u32 slow_threshold;  // 32; tests lower it to drive every pending underflow through the serial path
   u32 *simd_load;      // [AC_SIMD_KEYS] coder waves per SIMD of the device, shared by every launch (may be null)
   u64 *prof;           // profiling only (SCALCE_AC_PROF): per block {cycles in the 64 steps, cycles in the rest of the round, rounds}
-  const AcBlockDesc *desc;  // ac_encode4_k: one entry per block of the launch
+  const AcBlockDesc *desc;  // ac_encode_rows_k: one entry per block of the launch
   u32 nblocks;
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
@@ -583,55 +583,88 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   if (a.simd_load && lane == 0) atomicSub(&a.simd_load[skey], chain_wave ? 4u : 1u);
 }
 
-// ---- encoder, four blocks per workgroup ---------------------------------------------------------
+// ---- encoder, several blocks per workgroup -------------------------------------------------------
 // Same coder, laid out for SIMD time instead of latency.  ac_encode_k spends a whole wavefront on one chain: 63 of
-// 64 lanes execute garbage in every step.  Here the 16-lane rows of the chain wave carry four independent blocks:
-// the state of block i walks the 16 lanes of row i (DPP row_ror:1 -- lane 0 of a row takes what lane 15 left, so
-// rounds follow each other without any hand-over) while the same 14 instructions + 1 wait state serve all four
-// rows.  A round is 16 symbols per block; the parallel recomputation runs after every round, operands, outcomes
-// and the barrier with the helpers go by super-rounds of 64 symbols per block as in ac_encode_k.  Two helper waves
-// (two blocks each) gather operands and pack bits.  Per 64 symbols of four blocks the chain wave spends ~5000
-// cycles instead of 4 x 4400: 0.57 x the SIMD time per block, at 1.2 x the latency of a block.
-template <int S>
-__device__ __forceinline__ void sys_step16(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
+// 64 lanes execute garbage in every step.  Here groups of R lanes of the chain wave carry independent blocks
+// (R = 16: four blocks, R = 8: eight): the state of a block walks the R lanes of its group while the same 14
+// instructions + 1 wait state serve all groups.  A round is R symbols per block; the parallel recomputation runs
+// after every round; operands, outcomes and the barrier with the helpers go by super-rounds of 64 symbols per block
+// as in ac_encode_k.  Helper waves (two blocks each) gather operands and pack bits.
+//   R = 16: DPP row_ror:1 in every step -- lane 0 of a row takes what lane 15 left, rounds follow each other without
+//           any hand-over.  Per 64 symbols of four blocks the chain wave spends ~5000 cycles instead of 4 x 4400:
+//           0.57 x the SIMD time per block at 1.13 x its latency.
+//   R = 8:  no DPP mode rotates inside 8 lanes, so a round starts with one row_ror:9 of the state (lane 0 <- lane 7,
+//           lane 8 <- lane 15), step 0 reads its own lane, steps 1..7 shift by one.  ~0.35 x the SIMD time per block.
+template <int R, int S>
+__device__ __forceinline__ void sys_step_rows(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
   constexpr int Q = S & 3;
-  constexpr int BM = 1 << (S >> 2);  // the quad of lane S of every row
-  st.kM[Q] = __builtin_amdgcn_update_dpp(st.kM[Q], tM, 0x121 /* row_ror:1 */, 0xF, BM, false);
+  // write enable: the quad of lane S of every group (R = 8: two groups per 16-lane row)
+  constexpr int BM = R == 16 ? (1 << (S >> 2)) : ((1 << (S >> 2)) | (1 << ((S >> 2) + 2)));
+  constexpr int CTRL = R == 16 ? 0x121 /* row_ror:1 */ : (S == 0 ? 0xE4 /* quad_perm:[0,1,2,3] */ : 0x111 /* row_shr:1 */);
+  st.kM[Q] = __builtin_amdgcn_update_dpp(st.kM[Q], tM, CTRL, 0xF, BM, false);
   const u32 M = st.kM[Q];
   const u32 A1 = (u32)(((u64)M * ops.w + (((u64)st.ones << 32) | __umulhi(M, ops.z))) >> 32);
   const u32 B = (u32)(((u64)M * ops.y + __umulhi(M, ops.x)) >> 32);
   const u32 D = A1 - B;
-  asm("v_add_u32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
+  if constexpr (R == 16)
+    asm("v_add_u32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
+  else if constexpr (S == 0)
+    asm("v_add_u32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
+  else
+    asm("v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
   __builtin_amdgcn_sched_barrier(0);
   const u32 nlo = st.nl[Q];
   const u32 t = renorm_count(nlo, D);
   tM = (D + 1) << t;
   tlo = nlo << t;
 }
-template <int S, int E>
-struct SysLoop16 {
+template <int R, int S, int E>
+struct SysLoopRows {
   static __device__ __forceinline__ void run(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
-    sys_step16<S>(st, tlo, tM, ops);
-    SysLoop16<S + 1, E>::run(st, tlo, tM, ops);
+    sys_step_rows<R, S>(st, tlo, tM, ops);
+    SysLoopRows<R, S + 1, E>::run(st, tlo, tM, ops);
   }
 };
-template <int E>
-struct SysLoop16<E, E> {
+template <int R, int E>
+struct SysLoopRows<R, E, E> {
   static __device__ __forceinline__ void run(SysState &, u32 &, u32 &, const uint4 &) {}
 };
+// one round of R symbols for every group of the wave
+template <int R>
+__device__ __forceinline__ void sys_round_rows(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
+  if constexpr (R == 8) {  // the state of a group sits in its last lane: bring it to its first one
+    tlo = __builtin_amdgcn_update_dpp(tlo, tlo, 0x129 /* row_ror:9 */, 0xF, 0xF, false);
+    tM = __builtin_amdgcn_update_dpp(tM, tM, 0x129, 0xF, 0xF, false);
+  }
+  SysLoopRows<R, 0, R>::run(st, tlo, tM, ops);
+}
 
-constexpr int AC4 = 4;  // blocks per workgroup
-
-template <bool GENERAL>
-__global__ __launch_bounds__(192) void ac_encode4_k(AcEncArgs a) {
+template <bool GENERAL, int R>
+__global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs a) {
+  constexpr int NB = 64 / R;   // blocks per workgroup
+  constexpr int NH = NB / 2;   // helper waves
+  constexpr int NQ = 64 / R;   // rounds per super-round
+  constexpr int AC4 = NB;
   __shared__ uint2 rec[2][AC4][64];   // chain -> helpers: per symbol {hi before the shift, k | u << 8}
   __shared__ uint4 opsb[2][AC4][64];  // helpers -> chain: operands of a super-round (slot = super-round & 1)
   __shared__ u32 oflag[2][AC4];       // ... and whether that block's super-round may take the systolic path
-  __shared__ u32 bufs[2][AC_BUF_WORDS];
+  __shared__ u32 bufs[NH][AC_BUF_WORDS];
+  __shared__ u32 wave_simd[1 + NH];
   __shared__ u32 final_lo[AC4];
 
   const int lane = lane_id();
-  const int wv = wave_id();  // 0 chain, 1 and 2 helpers
+  // Roles.  The chain wave must have a SIMD to itself; the waves of a workgroup go to the CU's four SIMDs in turn, so
+  // with five waves (R = 8) two of them share one.  The chain is the first wave whose SIMD no other wave of the
+  // workgroup sits on, the others are helpers in wave order.
+  if (lane == 0) wave_simd[wave_id()] = simd_key() & 3u;
+  __syncthreads();
+  int chain_w = 0;
+  for (int w = NH; w >= 0; w--) {
+    bool alone = true;
+    for (int v = 0; v <= NH; v++) alone = alone && (v == w || wave_simd[v] != wave_simd[w]);
+    if (alone) chain_w = w;
+  }
+  const int wv = wave_id() == chain_w ? 0 : (wave_id() < chain_w ? wave_id() + 1 : wave_id());  // 0 chain, 1.. helpers
   const u32 blk0 = blockIdx.x * AC4;
   auto block_len = [&](u32 b) -> u32 { return b < a.nblocks ? a.desc[b].n : 0u; };
   // super-rounds of the workgroup = those of its longest block (the last block of a stream may be short)
@@ -641,7 +674,8 @@ __global__ __launch_bounds__(192) void ac_encode4_k(AcEncArgs a) {
 
   if (wv != 0) {
     // ================= helper waves: two blocks each =================
-    __builtin_amdgcn_s_setprio(2);  // must not fall behind the chain when other shards' front stages fill the chip
+    // default priority: with several blocks per chain wave the helpers have slack, and the front stages of the next
+    // shards need the SIMDs they sit on more than they do (measured: front 230 -> ? ms per shard)
     const int h = wv - 1;
     u32 *buf = bufs[h];
     AcSink sink[2];
@@ -721,39 +755,38 @@ __global__ __launch_bounds__(192) void ac_encode4_k(AcEncArgs a) {
       if (__any(sink[e].over) && lane == 0) dev_fail(dsc.err, E_ACOVERFLOW, dsc.index, bytes);
     }
   } else {
-    // ================= chain wave: four coder states, one per 16-lane row =================
+    // ================= chain wave: NB coder states, one per group of R lanes =================
     __builtin_amdgcn_s_setprio(3);
-    const int row = lane >> 4, col = lane & 15;
+    const int row = lane / R, col = lane % R;
     const u32 n_row = block_len(blk0 + row);
     const u32 nsr_row = (n_row + 63) >> 6;
     SysState st;
     asm("v_mov_b32 %0, -1" : "=v"(st.ones));
     st.kM[0] = st.kM[1] = st.kM[2] = st.kM[3] = 0;
     st.nl[0] = st.nl[1] = st.nl[2] = st.nl[3] = 0;
-    // the travelling state; between rounds the one that matters sits in lane 15 of the row.  M = 0 stands for 2^32.
+    // the travelling state; between rounds the one that matters sits in the last lane of the group.  M = 0 stands for 2^32.
     u32 tlo = 0, tM = 0;
     __syncthreads();  // operands of super-rounds 0 and 1 are in LDS
-    uint4 cur[4];
+    uint4 cur[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; q++) cur[q] = opsb[0][row][q * 16 + col];
+    for (int q = 0; q < NQ; q++) cur[q] = opsb[0][row][q * R + col];
     u32 cur_ok = 0;
     for (u32 r = 0; r < nsr; r++) {
-      uint4 ops[4], nxt[4];
+      uint4 ops[NQ], nxt[NQ];
 #pragma unroll
-      for (int q = 0; q < 4; q++) { ops[q] = cur[q]; nxt[q] = opsb[(r + 1) & 1][row][q * 16 + col]; }
+      for (int q = 0; q < NQ; q++) { ops[q] = cur[q]; nxt[q] = opsb[(r + 1) & 1][row][q * R + col]; }
       const u32 nxt_ok = oflag[(r + 1) & 1][row];
       uint2 *rc = rec[r & 1][row];
-      const u32 s_lo = tlo, s_M = tM;  // state at the start of the super-round (lane 15 of each row)
+      const u32 s_lo = tlo, s_M = tM;  // state at the start of the super-round (last lane of each group)
       // which rows may run the systolic path: flagged complete + plain by the helper, and not the full interval
-      const u64 m15 = __ballot(col == 15 && s_M != 0);
-      const bool row_plain = !GENERAL && cur_ok && ((m15 >> (row * 16 + 15)) & 1);
+      const u64 m15 = __ballot(col == R - 1 && s_M != 0);
+      const bool row_plain = !GENERAL && cur_ok && ((m15 >> (row * R + R - 1)) & 1);
       const bool row_live = r < nsr_row;
       bool bad = false;
       if (!GENERAL && __any(row_plain)) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const u32 tlo_in = tlo;  // lane 15: what lane 0 is about to receive
-          SysLoop16<0, 16>::run(st, tlo, tM, ops[q]);
+        for (int q = 0; q < NQ; q++) {
+          sys_round_rows<R>(st, tlo, tM, ops[q]);
           // every lane redoes its own symbol from the state it latched: outcome for the helper, exit test
           const int sq = col & 3;
           const u32 inM = sq == 0 ? st.kM[0] : sq == 1 ? st.kM[1] : sq == 2 ? st.kM[2] : st.kM[3];
@@ -766,33 +799,31 @@ __global__ __launch_bounds__(192) void ac_encode4_k(AcEncArgs a) {
           const u32 k = ffbh_raw(x);
           const u32 c1 = ((~nlo | nhi) << 1) | 1u;
           const u32 u = ffbh_raw(c1 << k);
-          const u32 olo = nlo << (k + u), oM = W << (k + u);
-          // stray bit 31 of the lo this lane received = bit 31 of what its left neighbour sent (lane 0: lane 15 of
-          // the previous round)
-          const u32 src = col == 15 ? tlo_in : olo;
-          const u32 prev = __builtin_amdgcn_update_dpp(0u, src, 0x121, 0xF, 0xF, false);
+          const u32 oM = W << (k + u);
+          // stray bit 31 of the lo this lane received (it travels uncleared, see sys_step): nlo = received + B
+          const u32 stray = (nlo - B) & 0x80000000u;
           bad = bad || x == 0 || oM == 0;
-          rc[q * 16 + col] = make_uint2(nhi ^ (prev & 0x80000000u), k | (u << 8));
+          rc[q * R + col] = make_uint2(nhi ^ stray, k | (u << 8));
         }
       }
       const u64 badm = __ballot(bad);
-      const bool row_bad = ((badm >> (row * 16)) & 0xFFFFull) != 0;
+      const bool row_bad = ((badm >> (row * R)) & ((1ull << R) - 1)) != 0;
       const bool need_general = row_live && (!row_plain || row_bad);
       const u64 gm = __ballot(need_general);
       if (gm) {  // rare: first super-round, tails, a step that needs the general path -- row by row on lane 0
         for (int rw = 0; rw < AC4; rw++) {
-          if (!((gm >> (rw * 16)) & 1)) continue;
+          if (!((gm >> (rw * R)) & 1)) continue;
           const u32 nr = block_len(blk0 + rw);
           const u32 rest = nr - (r << 6);
           const u32 jend = rest < 64 ? rest : 64, jstart = (r == 0) ? 2u : 0u;
-          u32 glo = __builtin_amdgcn_readlane(s_lo, rw * 16 + 15) & 0x7FFFFFFFu;
-          u32 ghi = glo + __builtin_amdgcn_readlane(s_M, rw * 16 + 15) - 1;
+          u32 glo = __builtin_amdgcn_readlane(s_lo, rw * R + R - 1) & 0x7FFFFFFFu;
+          u32 ghi = glo + __builtin_amdgcn_readlane(s_M, rw * R + R - 1) - 1;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            for (u32 c = 0; c < 16; c++) {
-              const u32 j = q * 16 + c;
-              const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops[q].x, rw * 16 + c), __builtin_amdgcn_readlane(ops[q].y, rw * 16 + c),
-                                         __builtin_amdgcn_readlane(ops[q].z, rw * 16 + c), __builtin_amdgcn_readlane(ops[q].w, rw * 16 + c));
+          for (int q = 0; q < NQ; q++) {
+            for (u32 c = 0; c < (u32)R; c++) {
+              const u32 j = q * R + c;
+              const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops[q].x, rw * R + c), __builtin_amdgcn_readlane(ops[q].y, rw * R + c),
+                                         __builtin_amdgcn_readlane(ops[q].z, rw * R + c), __builtin_amdgcn_readlane(ops[q].w, rw * R + c));
               if (j >= jstart && j < jend && lane == 0) {
                 u32 hbefore;
                 const u32 ku = ac_step<GENERAL>(glo, ghi, g, hbefore);
@@ -802,12 +833,12 @@ __global__ __launch_bounds__(192) void ac_encode4_k(AcEncArgs a) {
           }
           glo = __builtin_amdgcn_readfirstlane(glo);
           ghi = __builtin_amdgcn_readfirstlane(ghi);
-          if (lane == rw * 16 + 15) { tlo = glo; tM = ghi - glo + 1; }
+          if (lane == rw * R + R - 1) { tlo = glo; tM = ghi - glo + 1; }
         }
       }
-      if (col == 15 && r + 1 == nsr_row) final_lo[row] = tlo & 0x7FFFFFFFu;
+      if (col == R - 1 && r + 1 == nsr_row) final_lo[row] = tlo & 0x7FFFFFFFu;
 #pragma unroll
-      for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+      for (int q = 0; q < NQ; q++) cur[q] = nxt[q];
       cur_ok = nxt_ok;
       __syncthreads();
     }

@@ -817,7 +817,7 @@ static int ac_prepare(AcJob &j, hipStream_t s) {
   return SCALCE_OK;
 }
 
-// ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 = ac_encode4_k.
+// ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 / 8 = ac_encode_rows_k.
 // `ps` = the stream the tables were prepared on: the block descriptors are uploaded there (never behind a coder that
 // is still running on `s`), and `s` is made to wait for it.
 static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, hipStream_t ps) {
@@ -900,8 +900,13 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
-    if (general) LAUNCH(ac_encode4_k<true>, cdiv(total, AC4), 192, 0, s, a);
-    else LAUNCH(ac_encode4_k<false>, cdiv(total, AC4), 192, 0, s, a);
+    if (blocks_per_wg == 8) {
+      if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
+      else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
+    } else {
+      if (general) LAUNCH((ac_encode_rows_k<true, 16>), cdiv(total, 4), 192, 0, s, a);
+      else LAUNCH((ac_encode_rows_k<false, 16>), cdiv(total, 4), 192, 0, s, a);
+    }
     if (ke1) hipEventRecord(ke1, s);
   }
   for (int i = 0; i < njobs; i++) lead->k_in_bytes += jobs[i].nsym;
@@ -924,7 +929,8 @@ static int ac_frame(AcJob &j, hipStream_t s) {
 static int ac_blocks_per_wg() {
   // one block per workgroup (lowest latency of a block) or four (0.57 x the SIMD time per block, 1.2 x the latency)
   const char *bpw = getenv("SCALCE_AC_BLOCKS_PER_WG");
-  return (bpw && atoi(bpw) == 4) ? 4 : 1;
+  const int v = bpw ? atoi(bpw) : 1;
+  return (v == 4 || v == 8) ? v : 1;
 }
 
 // Code one mate's symbol stream `d_sym` (nsym symbols, first symbol = start of a 10 MiB block of the run-wide
@@ -1010,7 +1016,13 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
     }
   }
   if (jobs.empty()) return SCALCE_OK;
-  int rc = ac_launch(jobs.data(), (int)jobs.size(), 4, s, ps);
+  // blocks per workgroup: as few as keep the launch at one workgroup per CU (256 CUs), so that every coder wave has
+  // a SIMD to itself -- four for up to two 50 M-read shards, eight beyond
+  u32 total = 0;
+  for (auto &j : jobs) total += j.nblk;
+  int bpw = total <= 4 * 256 ? 4 : 8;
+  if (ac_blocks_per_wg() != 1) bpw = ac_blocks_per_wg();
+  int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);
   if (rc) return rc;
   for (auto &j : jobs) if ((rc = ac_frame(j, s))) return rc;
   return SCALCE_OK;

@@ -310,7 +310,8 @@ def compress_shard(comm, ctx, batch, d_text, nbytes, d_text2=None, nbytes2=0, st
                 ent_stream.wait_stream(torch.cuda.current_stream())
                 batch.entropy_stream_begin(m, tables[m].data_ptr(), mine.data_ptr(), plan["hi"] - plan["lo"],
                                            ent_stream.cuda_stream)
-            keep.append((local, got, mine, tables[m]))
+            # only what the coder reads after this call returns; `local` and `got` were consumed on this stream
+            keep.append((mine, tables[m]))
             res.plans.append(plan)
     batch._keep_alive = keep  # read by the coder after this call returns
     return res
