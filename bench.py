@@ -220,13 +220,15 @@ def main():
         cpu = cpu_baseline(text, n, L, args.cpu_sample)
 
     traffic, traffic_src = None, None
-    kname = "ac_encode4_k" if G > 1 else "ac_encode_k"
-    pmc = os.path.join(ROOT, "profiles", "r01_v10_bench50m_pmc_fetch_write.json" if G > 1 else "r01_v9_bench50m_pmc_fetch_write.json")
+    kname = "ac_encode_rows_k" if G > 1 else "ac_encode_k"
+    pmc = os.path.join(ROOT, "profiles", "r01_v11_bench50m_pmc_fetch_write.json" if G > 1 else "r01_v9_bench50m_pmc_fetch_write.json")
     if rank == 0 and n == 50_000_000 and L == 100 and os.path.exists(pmc):
         # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of
         # KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM")
         for row in json.load(open(pmc)):
-            if kname + "<" in row["kernel"]:
+            nblocks = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
+            want = kname + ("<false, 8>" if nblocks > 1024 else "<false, 16>") if G > 1 else kname + "<"
+            if want in row["kernel"]:
                 units = row.get("shards", row["calls"]) / G  # launches of G shards the profiled bytes stand for
                 traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / max(units, 1))
                 traffic_src = os.path.relpath(pmc, ROOT)
@@ -263,7 +265,8 @@ def main():
                          "shards_per_launch": G,
                          "note": "serial coder chain per 10 MiB block: bound by the issue slots of one wavefront, not by "
                                  "bandwidth (ns per symbol per block is the figure to watch); blocks run concurrently, "
-                                 + ("four per 3-wave workgroup, one launch for %d shards" % G if G > 1 else "one 2-wave workgroup each")},
+                                 + ("four or eight per chain wave, one launch for %d shards at one workgroup per CU" % G
+                                    if G > 1 else "one 2-wave workgroup each")},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
