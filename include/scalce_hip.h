@@ -125,12 +125,14 @@ int scalce_batch_entropy(scalce_batch *b, const uint32_t *d_table_override, void
  * counterpart of the reference coding `-T` blocks per batch on its thread pool (arithmetic.cpp:349-357). */
 int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_table_override, void *stream);
 int scalce_batch_entropy_end(scalce_batch *b, void *stream);
-/* The begin half for several shards at once: ONE coder launch over the blocks of all of them, four blocks per
- * workgroup (0.57 x the SIMD time per block of the one-block kernel at 1.2 x its latency).  A 50 M-read shard is
- * 477 blocks = 120 workgroups; two shards fit the chip one workgroup per CU, so every coder wave has a SIMD to
- * itself by construction and the pair is coded in the time one shard takes.  Tables are prepared on prep_stream
- * (the host waits there, never behind a running coder), the coder and the framing are enqueued on stream.  Each
- * shard is completed by its own scalce_batch_entropy_end / scalce_batch_finish on `stream`. */
+/* The begin half for several shards at once: ONE coder launch over the blocks of all of them, with several blocks per
+ * chain wavefront (four: 0.57 x the SIMD time per block of the one-block kernel at 1.13 x its latency; eight: ~0.35 x
+ * at 1.3 x).  The library picks the fewest blocks per wave that keep the launch at one workgroup per CU -- two
+ * 50 M-read shards are 954 blocks = 239 workgroups of four, three shards 179 workgroups of eight -- so every coder wave
+ * has a SIMD to itself by construction and the group is coded in little more than the time one shard takes.  Tables
+ * are prepared on prep_stream (the host waits there, never behind a running coder), the coder and the framing are
+ * enqueued on stream.  Each shard is completed by its own scalce_batch_entropy_end / scalce_batch_finish (on any
+ * stream, after `stream` has reached the end of the launch). */
 int scalce_batch_entropy_begin_group(scalce_batch **batches, int n, void *prep_stream, void *stream);
 /* Sharded runs: code a caller-assembled range of the run-wide reordered stream (it must start on a 10 MiB
  * block boundary) against the run-wide table; result in SCALCE_OUT_QUAL of `mate`. */
