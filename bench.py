@@ -30,10 +30,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="shards in flight per GPU: the coder of shard j runs on its own stream while the front "
                          "stages of shard j+1 run (1 = strictly one after the other)")
-    ap.add_argument("--group", type=int, default=3,
+    ap.add_argument("--group", type=int, default=None,
                     help="shards per coder launch (scalce_batch_entropy_begin_group, four blocks per workgroup); "
                          "1 = one launch per shard with the one-block-per-workgroup kernel")
     ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU")
@@ -71,8 +71,13 @@ def main():
     from scalce_amd import format as fmt
     off, vals, Ls = fmt.sample_qmap(head)
     assert Ls == L
-    G = max(1, args.group)                     # shards per coder launch
-    D = max(1, args.inflight) if G == 1 else max(args.inflight, 2 * G)
+    # shards per coder launch / shards in flight.  One GPU: 3 / 6 (199 GB of the 288 GB HBM at 50 M reads per shard).  A
+    # sharded run also holds every in-flight shard's block range of the run-wide quality stream and the all-to-all
+    # buffers (measured with the 2-rank rehearsal: ~1.7 GB per million reads of a shard on top), so it keeps 2 / 4.
+    G = max(1, args.group if args.group is not None else (3 if world == 1 else 2))
+    D = max(1, args.inflight) if args.inflight is not None else 2 * G
+    if G > 1:
+        D = max(D, 2 * G)
     batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)]) for _ in range(D)]
     batch = batches[0]
     # one stream for the front stages (ingest .. emit, and the collectives of a sharded run), others for the
@@ -203,6 +208,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm_used_gb = round((total_b - free_b) / 1e9, 1)
     ks = [b.kernel_ms() for b in batches]
     k = {key: sum(x[key] for x in ks) for key in ks[0]}
     stats = batch.stats()
@@ -257,7 +264,7 @@ def main():
                        "input_bytes_per_gpu": nbytes, "output_bytes_per_gpu": int(out_bytes),
                        "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if world == 1 else ": read ranges per rank, run-wide tie-break / quality model / 10 MiB blocks (RCCL all-gather, all-reduce, all-to-all)"),
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
-                       "shards_in_flight": D, "shards_per_coder_launch": G, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
+                       "shards_in_flight": D, "shards_per_coder_launch": G, "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": round(per_launch_ms, 3), "alg_bytes_per_launch": int(alg_bytes),
