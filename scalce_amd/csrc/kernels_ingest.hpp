@@ -223,12 +223,17 @@ __global__ __launch_bounds__(256) void unpack_k(UnpackArgs a) {
 
 // tiled form: a workgroup copies the contiguous text of UNP_RPB records into LDS with 16-byte loads, the
 // threads then work out of LDS, and the q' rows leave through LDS as one contiguous, coalesced block.
+// The two tiles are sized for the shard's read length at launch (dynamic LDS: text_cap + 32 + q_cap bytes): 40 KB at
+// L = 100, so four workgroups share a CU instead of the two that tiles sized for L = 160 allowed.
 constexpr int UNP_RPB = 128;
-constexpr int UNP_TEXT_CAP = 44 * 1024;
 constexpr int UNP_Q_CAP = 20 * 1024;  // UNP_RPB * L must fit: L <= 160
+__host__ __device__ inline u32 unp_text_cap(int L) { return (u32)(((UNP_RPB * (2 * L + 20) + 64) + 15) & ~15); }
+__host__ __device__ inline u32 unp_q_cap(int L) { return (u32)((UNP_RPB * L + 15) & ~15); }
 __global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
-  __shared__ __attribute__((aligned(16))) u8 tile[UNP_TEXT_CAP + 32];
-  __shared__ __attribute__((aligned(16))) u8 qt[UNP_Q_CAP];
+  extern __shared__ __attribute__((aligned(16))) u8 unp_lds[];
+  const u32 UNP_TEXT_CAP = unp_text_cap(a.L);
+  u8 *tile = unp_lds;
+  u8 *qt = unp_lds + UNP_TEXT_CAP + 32;
   __shared__ u8 lut[128];
   const int tid = threadIdx.x;
   lut[tid] = a.qlut[tid];

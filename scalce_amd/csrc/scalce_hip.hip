@@ -390,7 +390,8 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
     a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
     a.packed = b->packed[mate].as<u8>(); a.q = b->q[mate].as<u8>(); a.namelen = b->namelen.as<u8>();
     a.qlut = b->d_qlut[mate]; a.err = b->d_err;
-    if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP) LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), UNP_RPB, 0, s, a);
+    if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
+      LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
     else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
   }
   b->ingested[mate] = true;
