@@ -82,6 +82,7 @@ struct AcEncArgs {
   u64 *prof;           // profiling only (SCALCE_AC_PROF): per block {cycles in the 64 steps, cycles in the rest of the round, rounds}
   const AcBlockDesc *desc;  // ac_encode_rows_k: one entry per block of the launch
   u32 nblocks;
+  u32 chain_prio;      // s_setprio of the chain waves (ac_encode_rows_k)
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
 constexpr u32 AC_SIMD_KEYS = 16u << 10;
@@ -756,7 +757,12 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     }
   } else {
     // ================= chain wave: NB coder states, one per group of R lanes =================
-    __builtin_amdgcn_s_setprio(3);
+    switch (a.chain_prio) {  // an immediate in the instruction
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
     const int row = lane / R, col = lane % R;
     const u32 n_row = block_len(blk0 + row);
     const u32 nsr_row = (n_row + 63) >> 6;

@@ -831,6 +831,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
   AcEncArgs a;
   memset(&a, 0, sizeof a);
   a.slow_threshold = 32;
+  a.chain_prio = getenv("SCALCE_AC_CHAIN_PRIO") ? (u32)atoi(getenv("SCALCE_AC_CHAIN_PRIO")) : 3u;
   a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
   auto join = [&]() -> int {  // `s` continues behind everything enqueued on `ps` so far
