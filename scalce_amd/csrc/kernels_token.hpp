@@ -60,12 +60,15 @@ __global__ __launch_bounds__(TOK_THREADS) void tokenize_k(TokArgs a) {
     const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
     for (int k = 0; k < cnt; k++) {
       const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
-      uint4 nx;
-      if (USE_LDS && state < a.lds_states) nx = l_next[state]; else nx = a.next[state];
-      state = c == 0 ? nx.x : (c == 1 ? nx.y : (c == 2 ? nx.z : nx.w));
-      u32 info;
-      if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state];
-      if (info != kNoOutD) {
+      // one 4-byte transition (a 16-byte row per lane costs four times the LDS bank accesses); bit 31 = the target
+      // state has an output
+      u32 t;
+      if (USE_LDS && state < a.lds_states) t = reinterpret_cast<const u32 *>(l_next)[state * 4 + c];
+      else t = reinterpret_cast<const u32 *>(a.next)[(u64)state * 4 + c];
+      state = t & 0x7FFFFFFFu;
+      if (t >> 31) {
+        u32 info;
+        if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state];
         const u32 lv = info >> kLevelShiftD, b = info & kBucketMaskD;
         if (lv > best_lv) {
           best_lv = lv; best_b = b; best_pos = 16 * w + k; hits = 1; tie = 0;
@@ -123,11 +126,12 @@ __global__ __launch_bounds__(TOK_THREADS) void tie_candidates_k(TieArgs a) {
     const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
     for (int q = 0; q < cnt; q++) {
       const u32 c = (word >> (8 * (q >> 2) + 6 - 2 * (q & 3))) & 3u;
-      uint4 nx;
-      if (USE_LDS && state < a.lds_states) nx = l_next[state]; else nx = a.next[state];
-      state = c == 0 ? nx.x : (c == 1 ? nx.y : (c == 2 ? nx.z : nx.w));
-      u32 info;
-      if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state];
+      u32 tr;
+      if (USE_LDS && state < a.lds_states) tr = reinterpret_cast<const u32 *>(l_next)[state * 4 + c];
+      else tr = reinterpret_cast<const u32 *>(a.next)[(u64)state * 4 + c];
+      state = tr & 0x7FFFFFFFu;
+      u32 info = kNoOutD;
+      if (tr >> 31) { if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state]; }
       if (info != kNoOutD && (info >> kLevelShiftD) == lvmax) {
         const u32 bk = info & kBucketMaskD;
         bool seen = false;

@@ -94,7 +94,13 @@ static int upload_tables(scalce_ctx *c) {
   HIP_TRY(c, hipMalloc(&c->d_outinfo, sizeof(u32) * (size_t)A.n_states));
   HIP_TRY(c, hipMalloc(&c->d_bucket_pattern, sizeof(int32_t) * A.bucket_pattern.size()));
   HIP_TRY(c, hipMalloc(&c->d_bucket_level, sizeof(u32) * A.bucket_level.size()));
-  HIP_TRY(c, hipMemcpy(c->d_next, A.next.data(), sizeof(u32) * A.next.size(), hipMemcpyHostToDevice));
+  {  // transitions carry, in bit 31, whether the state they lead to ends a core (itself or through a suffix): the
+     // tokenizer then looks the output up only where there is one (~1 % of the positions of a read)
+    std::vector<u32> nx(A.next.begin(), A.next.end());
+    for (auto &t : nx)
+      if (A.outinfo[t] != kNoOutD) t |= 0x80000000u;
+    HIP_TRY(c, hipMemcpy(c->d_next, nx.data(), sizeof(u32) * nx.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(c, hipMemcpy(c->d_outinfo, A.outinfo.data(), sizeof(u32) * A.outinfo.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_bucket_pattern, A.bucket_pattern.data(), sizeof(int32_t) * A.bucket_pattern.size(),
                        hipMemcpyHostToDevice));
