@@ -340,8 +340,13 @@ __global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, u32 prev0
   }
 }
 
+// Work is handed out in 64 KB tiles per WAVE through a global counter (one per pass), not by a fixed stride: while
+// another shard's arithmetic coder is resident, the waves that share a SIMD with one of its chain waves run at a
+// fraction of the speed of the others, and with equal shares the whole workgroup -- and the kernel, one workgroup per
+// CU -- waited for them (4.4 -> 14 ms per pass).
+constexpr u32 TRI_TILE = 64 * 1024;
 __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 pass,
-                                                             const u32 *range, u64 *freq4) {
+                                                             const u32 *range, u64 *freq4, unsigned long long *tile_counter) {
   __shared__ u32 tab[TRI_CAP];
   const u32 lo = range[0], A = range[1];
   if (A == 0) return;
@@ -352,8 +357,15 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
   for (u32 i = threadIdx.x; i < used; i += TRI_THREADS) tab[i] = 0;
   __syncthreads();
   const u32 first = lo + d0;                    // leading symbols [first, first + width) belong to this pass
-  const u64 stride = (u64)gridDim.x * TRI_THREADS * 16;
-  for (u64 t = ((u64)blockIdx.x * TRI_THREADS + threadIdx.x) * 16; t < n; t += stride) {
+  const int lane = lane_id();
+  for (;;) {
+    u64 tile = 0;
+    if (lane == 0) tile = atomicAdd(tile_counter + pass, 1ull);
+    tile = ((u64)__builtin_amdgcn_readfirstlane((u32)(tile >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)tile);
+    const u64 tbase = tile * TRI_TILE;
+    if (tbase >= n) break;
+    const u64 tend = tbase + TRI_TILE < n ? tbase + TRI_TILE : n;
+  for (u64 t = tbase + (u64)lane * 16; t < tend; t += 64 * 16) {
     u32 a = t >= 2 ? q[t - 2] : (t == 1 ? prev1 : prev0);
     u32 b = t >= 1 ? q[t - 1] : prev1;
     u32 w[4];
@@ -374,6 +386,7 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
       a = b;
       b = c;
     }
+  }
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i < used; i += TRI_THREADS) {

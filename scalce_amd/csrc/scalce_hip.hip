@@ -422,9 +422,11 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     LAUNCH(sym_hist_k, 2048, 256, 0, s, b->q[m].as<u8>(), n, hist);
     u32 *range = b->d_small + 14;  // {lo, A}: span of the symbols that occur
     LAUNCH(tri_range_k, 1, 64, 0, s, hist, b->p.qprev[m][0], b->p.qprev[m][1], range);
+    unsigned long long *tiles = reinterpret_cast<unsigned long long *>(b->d_small64 + 300);  // one tile counter per pass
+    HIP_TRY(c, hipMemsetAsync(tiles, 0, sizeof(u64) * TRI_MAX_PASSES, s));
     for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
       LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0], b->p.qprev[m][1], pass, range,
-             b->freq4[m].as<u64>());
+             b->freq4[m].as<u64>(), tiles);
   }
   return SCALCE_OK;
 }
