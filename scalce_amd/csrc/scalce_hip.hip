@@ -985,6 +985,25 @@ extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_tab
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
   const u64 N = b->N;
+  if (b->nm == 2 && !b->p.no_ac && ac_blocks_per_wg() == 1) {
+    // paired reads: both mates' streams in ONE launch (several blocks per chain wave) instead of two launches of the
+    // one-block kernel behind each other -- the same chip, half the time
+    AcJob jobs[2];
+    u32 total = 0;
+    for (int m = 0; m < 2; m++) {
+      const u64 nsym = N * (u64)b->L[m];
+      int rc = ac_table_for(b, m, d_table_override, nsym, s);
+      if (rc) return rc;
+      jobs[m] = AcJob{b, m, b->qs[m].as<u8>(), nsym, 0, false};
+      if ((rc = ac_prepare(jobs[m], s))) return rc;
+      total += jobs[m].nblk;
+    }
+    int rc = ac_launch(jobs, 2, total <= 4 * 256 ? 4 : 8, s, s);
+    if (rc) return rc;
+    for (int m = 0; m < 2; m++)
+      if ((rc = ac_frame(jobs[m], s))) return rc;
+    return SCALCE_OK;
+  }
   for (int m = 0; m < b->nm; m++) {
     const u64 nsym = N * (u64)b->L[m];
     if (b->p.no_ac) {  // -A: raw q' bytes (compress.cpp:389-390)
