@@ -48,6 +48,7 @@ def main():
 
     from scalce_amd import dist as sdist
     from scalce_amd import host, synth_gpu
+    from scalce_amd.pipeline import ShardPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,19 +81,6 @@ def main():
         D = max(D, 2 * G)
     batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)]) for _ in range(D)]
     batch = batches[0]
-    # one stream for the front stages (ingest .. emit, and the collectives of a sharded run), others for the
-    # arithmetic coder: it is a long kernel of one wavefront per block (or per four) that leaves the memory system
-    # and most lanes idle, so the next shards' front stages run beside it
-    front = torch.cuda.Stream()
-    # ONE coder stream: launches queue behind each other anyway (see chain_coders), and HIP maps streams onto a handful
-    # of hardware queues -- with a coder stream per slot, one of them ended up in the front stream's hardware queue and
-    # every read-back of the front stream then waited behind a 400 ms coder kernel
-    coder_stream = torch.cuda.Stream()
-    ent = [coder_stream] * D
-    busy = [None] * D      # event behind the slot's coder launch
-    pending = []           # slots whose front stages are done and whose coder launch is still to come (G > 1)
-    ngroups = [0]
-
     state = {}
     comm = sdist.TorchComm() if world > 1 else None
 
@@ -107,87 +95,29 @@ def main():
 
     def mark(what):
         if trace and rank == 0:
-            t = time.perf_counter()
-            print("  [%8.1f ms] %s" % ((t - tr0[0]) * 1e3, what), file=sys.stderr)
+            print("  [%8.1f ms] %s" % ((time.perf_counter() - tr0[0]) * 1e3, what), file=sys.stderr)
 
-    def retire(slot):
-        # wait for the shard's coder on an EVENT and read its results over the front stream: HIP streams share a few
-        # hardware queues, and a read-back submitted on the coder's own (finished) stream can land in a queue behind
-        # the next coder launch and wait for all of it (measured: 400 ms per second pair of shards)
-        if busy[slot] is not None:
-            busy[slot].synchronize()
-            mark(f"  slot {slot}: coder event reached")
-            batches[slot].finish(front.cuda_stream)  # sizes of the coded streams, device error word
-            busy[slot] = None
-
-    def chain_coders(stream_now, stream_before):
-        # one coder launch at a time: a second one beside the first does not add throughput -- wherever the
-        # dispatcher puts two chain waves on one SIMD the younger one starves (measured: 733 ms instead of 412) --
-        # so the launches queue behind each other and only the front stages of the next shards run beside them
-        if stream_before is not None and stream_before is not stream_now:
-            stream_now.wait_stream(stream_before)
-
-    last_coder = [None]
-
-    coder_done = [None]  # event behind the last coder launch
-
-    def coder_idle():
-        return coder_done[0] is None or coder_done[0].query()
-
-    def launch_group():
-        if not pending:
-            return
-        es = ent[ngroups[0] % D]
-        ngroups[0] += 1
-        chain_coders(es, last_coder[0])
-        host.entropy_begin_group([batches[sl] for sl in pending], front.cuda_stream, es.cuda_stream)
-        coder_done[0] = torch.cuda.Event()
-        coder_done[0].record(es)
-        for sl in pending:
-            busy[sl] = coder_done[0]
-        last_coder[0] = es
-        pending.clear()
-
-    def submit(j, last):
-        slot = j % D
-        b = batches[slot]
-        mark(f"shard {j}: retire slot {slot}")
-        retire(slot)
-        mark(f"shard {j}: front")
-        with torch.cuda.stream(front):
-            if G == 1:
-                es = ent[slot]
-                if world == 1:
-                    b.front(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
-                    es.wait_stream(front)
-                    chain_coders(es, last_coder[0])
-                    b.entropy_begin(None, es.cuda_stream)
-                else:
-                    chain_coders(es, last_coder[0])
-                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
-                                                       ent_stream=es)
-                busy[slot] = torch.cuda.Event()
-                busy[slot].record(es)
-                last_coder[0] = es
-            else:
-                if world == 1:
-                    b.front(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
-                else:
-                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=front.cuda_stream,
-                                                       prepare_only=True)
-                pending.append(slot)
-                mark(f"shard {j}: front done")
-                if len(pending) == G or last:
-                    launch_group()
-                    mark(f"shard {j}: coder launched")
+    # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
+    # previous ones on another, `G` shards per coder launch, shards retired on events
+    pipe = ShardPipeline(batches, group=G, sharded=world > 1, trace=mark if trace else None)
+    front = pipe.front
 
     def run(k):
         for j in range(k):
-            submit(j, j + 1 == k)
-        for slot in range(D):
-            retire(slot)
-        last_coder[0] = None
-        coder_done[0] = None
+            slot, b = pipe.acquire()
+            mark(f"shard {j}: front (slot {slot})")
+            with torch.cuda.stream(pipe.front):
+                if world == 1:
+                    b.front(text.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream)
+                elif G == 1:
+                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=pipe.front.cuda_stream,
+                                                       ent_stream=pipe.coder)
+                else:
+                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=pipe.front.cuda_stream,
+                                                       prepare_only=True)
+            mark(f"shard {j}: front done")
+            pipe.submit(slot, tag=j, flush=j + 1 == k)
+        pipe.drain()
 
     torch.cuda.synchronize()  # the synthetic shard was generated on the default stream
     warm = max(args.warmup, D) if args.warmup > 0 else 0  # every slot allocates its buffers outside the timed region

@@ -1,0 +1,102 @@
+"""Shards in flight: the host-side scheduling loop around the C ABI's split entropy stage.
+
+The reference keeps its cores busy by handing `-T` blocks per batch to coder threads while the reader goes on
+(arithmetic.cpp:349-357, compress.cpp:781-786).  The device-side counterpart: the arithmetic coder is a long kernel
+of one wavefront per 10 MiB block (or per four / eight blocks) that leaves the memory system and most lanes idle, so
+the front stages (ingest .. emit, and in a sharded run their collectives) of the NEXT shards run beside it on another
+stream.  What the measurements on MI355X fixed:
+
+* exactly two streams, `front` and `coder`: HIP maps streams onto a handful of hardware queues, and any read-back that
+  lands in a queue behind a 0.4 s coder kernel waits for all of it;
+* shards are retired on an EVENT recorded behind their coder launch and read back over the front stream;
+* one coder launch at a time (two side by side do not add throughput: where the dispatcher puts two chain waves on
+  one SIMD the younger one starves), but a launch takes `group` shards (scalce_batch_entropy_begin_group: several
+  blocks per chain wave, one workgroup per CU);
+* `slots >= 2 * group` batches, so that the front stages of one group run while the previous group is coded.
+
+Usage:
+    pipe = ShardPipeline(batches, group=3)
+    for shard in shards:
+        slot, batch = pipe.acquire()          # waits for the batch's previous shard, calls on_retire for it
+        ... front stages of `shard` into `batch` on pipe.front (a torch stream; torch.cuda.stream(pipe.front)) ...
+        pipe.submit(slot, tag=shard)          # coder launch once `group` shards are waiting (or flush=True)
+    pipe.drain()
+"""
+from . import host
+
+
+class ShardPipeline:
+    def __init__(self, batches, group=1, on_retire=None, sharded=False, trace=None):
+        import torch
+        self.torch = torch
+        self.batches = list(batches)
+        self.D = len(self.batches)
+        self.G = max(1, int(group))
+        if self.G > 1 and self.D < 2 * self.G:
+            raise ValueError("a grouped pipeline needs at least 2 * group batches")
+        self.front = torch.cuda.Stream()
+        self.coder = torch.cuda.Stream()
+        self.on_retire = on_retire
+        self.sharded = sharded          # shards arrive prepared (dist.compress_shard(prepare_only=True) / ent_stream)
+        self.trace = trace
+        self._busy = [None] * self.D    # event behind the slot's coder launch
+        self._tag = [None] * self.D
+        self._pending = []
+        self._next = 0
+
+    # -- slots ---------------------------------------------------------------------------------------------
+    def acquire(self):
+        """Next batch in round-robin order, free to be overwritten (its previous shard retired)."""
+        slot = self._next
+        self._next = (self._next + 1) % self.D
+        if slot in self._pending:  # caller never submitted enough shards to launch: flush before reuse
+            self.flush()
+        self.retire(slot)
+        return slot, self.batches[slot]
+
+    def retire(self, slot):
+        ev = self._busy[slot]
+        if ev is None:
+            return
+        ev.synchronize()
+        if self.trace:
+            self.trace(f"slot {slot}: coder event reached")
+        self.batches[slot].finish(self.front.cuda_stream)  # sizes of the coded streams, device error word
+        self._busy[slot] = None
+        if self.on_retire:
+            self.on_retire(slot, self.batches[slot], self._tag[slot])
+        self._tag[slot] = None
+
+    # -- coder launches ------------------------------------------------------------------------------------
+    def submit(self, slot, tag=None, flush=False):
+        """The front stages of `slot` are enqueued on `self.front`: launch the coder now or with the next shards."""
+        self._tag[slot] = tag
+        if self.G == 1:
+            b = self.batches[slot]
+            if not self.sharded:  # a sharded caller has already enqueued the coder on self.coder (ent_stream)
+                self.coder.wait_stream(self.front)
+                b.entropy_begin(None, self.coder.cuda_stream)
+            ev = self.torch.cuda.Event()
+            ev.record(self.coder)
+            self._busy[slot] = ev
+            return
+        self._pending.append(slot)
+        if len(self._pending) == self.G or flush:
+            self.flush()
+
+    def flush(self):
+        if not self._pending:
+            return
+        host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, self.coder.cuda_stream)
+        ev = self.torch.cuda.Event()
+        ev.record(self.coder)
+        for sl in self._pending:
+            self._busy[sl] = ev
+        self._pending = []
+        if self.trace:
+            self.trace("coder launched")
+
+    def drain(self):
+        self.flush()
+        for slot in range(self.D):
+            self.retire(slot)

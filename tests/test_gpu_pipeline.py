@@ -1,0 +1,50 @@
+"""-m gpu: shards in flight (scalce_amd/pipeline.py, the loop bench.py times) give every shard exactly the streams a
+one-shot scalce_batch_compress gives it -- batches reused round-robin, several shards per coder launch, shards retired on
+events while the next ones are already in their front stages."""
+import numpy as np
+import pytest
+
+from scalce_amd import host, synth
+from scalce_amd.pipeline import ShardPipeline
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("group,slots", [(1, 1), (1, 2), (2, 4), (3, 6)])
+def test_pipelined_shards_equal_one_shot_compress(group, slots, patterns_blob):
+    import torch
+    from gpu_util import device_bytes
+    ctx = host.Context(0, patterns_bin=patterns_blob)
+    L = 100
+    sizes = [40_000, 120_000, 5_000, 230_000, 60_000, 110_000, 90_000, 30_000]   # 1 .. 3 coder blocks, all different
+    shards = []
+    for i, n in enumerate(sizes):
+        bases, quals = synth.reads_and_quals(n, L, seed=100 + i, dup_frac=0.1)
+        fq = synth.fastq_bytes_fast(bases, quals, prefix=f"p{i}.")
+        shards.append((device_bytes(fq), len(fq), n))
+    want = []
+    for t, nb, n in shards:   # one shard at a time, one-block-per-workgroup coder
+        b = host.Batch(ctx, L, n + 8, nb + 64)
+        b.compress(t.data_ptr(), nb)
+        b.finish()
+        want.append({w: b.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)})
+    nmax, bmax = max(sizes), max(s[1] for s in shards)
+    batches = [host.Batch(ctx, L, nmax + 8, bmax + 64) for _ in range(slots)]
+    got = {}
+
+    def on_retire(slot, batch, tag):
+        got[tag] = {w: batch.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)}
+
+    pipe = ShardPipeline(batches, group=group, on_retire=on_retire)
+    torch.cuda.synchronize()
+    for rep in range(2):   # every slot is reused several times
+        for i, (t, nb, n) in enumerate(shards):
+            slot, b = pipe.acquire()
+            with torch.cuda.stream(pipe.front):
+                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream)
+            pipe.submit(slot, tag=(rep, i), flush=(i + 1 == len(shards)))
+    pipe.drain()
+    assert len(got) == 2 * len(shards)
+    for (rep, i), g in got.items():
+        for w, name in ((host.OUT_QUAL, "qualities"), (host.OUT_READS, "reads"), (host.OUT_NAMES, "names")):
+            assert len(g[w]) == len(want[i][w]) and (g[w] == want[i][w]).all(), f"shard {i} (pass {rep}): {name} differ"
