@@ -790,6 +790,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const bool row_live = r < nsr_row;
       bool bad = false;
       if (!GENERAL && __any(row_plain)) {
+        u32 badacc = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
           sys_round_rows<R>(st, tlo, tM, ops[q]);
@@ -808,9 +809,10 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
           const u32 oM = W << (k + u);
           // stray bit 31 of the lo this lane received (it travels uncleared, see sys_step): nlo = received + B
           const u32 stray = (nlo - B) & 0x80000000u;
-          bad = bad || x == 0 || oM == 0;
+          badacc = min(badacc, min(x, oM));  // one v_min3_u32: 0 iff 32 agreeing bits or the range reached 2^32
           rc[q * R + col] = make_uint2(nhi ^ stray, k | (u << 8));
         }
+        bad = badacc == 0;
       }
       const u64 badm = __ballot(bad);
       const bool row_bad = ((badm >> (row * R)) & ((1ull << R) - 1)) != 0;
