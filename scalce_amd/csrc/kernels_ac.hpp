@@ -777,6 +777,8 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
 #pragma unroll
     for (int q = 0; q < NQ; q++) cur[q] = opsb[0][row][q * R + col];
     u32 cur_ok = 0;
+    u64 prof_wait = 0;
+    const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     for (u32 r = 0; r < nsr; r++) {
       uint4 ops[NQ], nxt[NQ];
 #pragma unroll
@@ -848,7 +850,18 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
 #pragma unroll
       for (int q = 0; q < NQ; q++) cur[q] = nxt[q];
       cur_ok = nxt_ok;
-      __syncthreads();
+      if (a.prof) {
+        const u64 w0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        prof_wait += __builtin_amdgcn_s_memtime() - w0;
+      } else {
+        __syncthreads();
+      }
+    }
+    if (a.prof && lane == 0) {
+      a.prof[blockIdx.x * 3 + 0] = prof_wait;
+      a.prof[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
+      a.prof[blockIdx.x * 3 + 2] = nsr;
     }
   }
 }

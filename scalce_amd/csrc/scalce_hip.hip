@@ -910,6 +910,8 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
+    const u32 nwg = cdiv(total, (u32)blocks_per_wg);
+    if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 3 * nwg)); }
     if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
@@ -918,6 +920,16 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
       else LAUNCH((ac_encode_rows_k<false, 16>), cdiv(total, 4), 192, 0, s, a);
     }
     if (ke1) hipEventRecord(ke1, s);
+    if (a.prof) {  // profiling only (blocks the host): share of the chain waves' time spent waiting at the barrier
+      std::vector<u64> h(3 * (size_t)nwg);
+      HIP_TRY(c, hipStreamSynchronize(s));
+      HIP_TRY(c, hipMemcpy(h.data(), a.prof, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
+      double wait = 0, tot = 0;
+      for (u32 i = 0; i < nwg; i++) { wait += h[3 * i]; tot += h[3 * i + 1]; }
+      fprintf(stderr, "ac prof (rows): %u workgroups, chain waves waited at the barrier %.1f %% of their time (%.0f of %.0f Mcycles each)\n",
+              nwg, 100.0 * wait / tot, wait / nwg / 1e6, tot / nwg / 1e6);
+      hipFree(a.prof);
+    }
   }
   for (int i = 0; i < njobs; i++) lead->k_in_bytes += jobs[i].nsym;
   return SCALCE_OK;
