@@ -83,6 +83,7 @@ struct AcEncArgs {
   const AcBlockDesc *desc;  // ac_encode_rows_k: one entry per block of the launch
   u32 nblocks;
   u32 chain_prio;      // s_setprio of the chain waves (ac_encode_rows_k)
+  u32 test_poison;     // test hook: every test_poison-th super-round pretends a step hit the full-range exit (0 = off)
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
 constexpr u32 AC_SIMD_KEYS = 16u << 10;
@@ -646,7 +647,10 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
   constexpr int NH = NB / 2;   // helper waves
   constexpr int NQ = 64 / R;   // rounds per super-round
   constexpr int AC4 = NB;
-  __shared__ uint2 rec[2][AC4][64];   // chain -> helpers: per symbol {hi before the shift, k | u << 8}
+  // chain -> helpers, per symbol: {range received, lo + B} as latched by the systolic path (the helper redoes the symbol
+  // from them: hi before the shift, k, u) or, from the general path, the outcome itself {hi before the shift, k | u << 8}
+  __shared__ uint2 rec[2][AC4][64];
+  __shared__ u32 recfmt[2][AC4];      // 1: that block's super-round holds latched states
   __shared__ uint4 opsb[2][AC4][64];  // helpers -> chain: operands of a super-round (slot = super-round & 1)
   __shared__ u32 oflag[2][AC4];       // ... and whether that block's super-round may take the systolic path
   __shared__ u32 bufs[NH][AC_BUF_WORDS];
@@ -694,6 +698,21 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       if (base + lane < nb[e]) v = tabp[e][(q0 * AC_D + q1) * AC_D + c];
       return v;
     };
+    // outcome of a symbol from what its lane latched in the chain wave (the "parallel recomputation" of ac_encode_k,
+    // done here where there is slack): hi before the shift, k agreed bits, u underflow steps
+    auto outcome = [&](const uint2 v, const uint4 &o, u32 fmt) -> uint2 {
+      if (!fmt) return v;
+      const u32 inM = v.x, nlo = v.y;
+      const u32 A = (u32)(((u64)inM * o.w + __umulhi(inM, o.z)) >> 32);
+      const u32 B = (u32)(((u64)inM * o.y + __umulhi(inM, o.x)) >> 32);
+      const u32 nhi = nlo + (A - B) - 1;
+      const u32 k = ffbh_raw(nlo ^ nhi);
+      const u32 c1 = ((~nlo | nhi) << 1) | 1u;
+      const u32 u = ffbh_raw(c1 << k);
+      // lo travels with bit 31 uncleared (sys_step): nlo = received + B, the stray bit is bit 31 of what was received
+      return make_uint2(nhi ^ ((nlo - B) & 0x80000000u), k | (u << 8));
+    };
+    uint4 hist[2][3];  // operands of super-rounds r - 1, r, r + 1 (the chain wave has long overwritten their LDS slots)
     auto plain_ok = [&](int e, const uint4 &v, u32 rr) -> u32 {
       return (rr > 0 && (rr << 6) + 64 <= nb[e] && !__any(v.w == 0xFFFFFFFFu)) ? 1u : 0u;
     };
@@ -713,6 +732,9 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const uint4 o0 = lookup(e, 0u, sy0, 0), o1 = lookup(e, sy0, sy_a[e], 64);
       opsb[0][2 * h + e][lane] = o0;
       opsb[1][2 * h + e][lane] = o1;
+      hist[e][0] = make_uint4(0, 0, 0, 0);
+      hist[e][1] = o0;
+      hist[e][2] = o1;
       const u32 ok1 = plain_ok(e, o1, 1);
       if (lane == 0) { oflag[0][2 * h + e] = 0; oflag[1][2 * h + e] = ok1; }
     }
@@ -728,7 +750,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       if (r > 0) {
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          const uint2 v = rec[(r - 1) & 1][2 * h + e][lane];
+          const uint2 v = outcome(rec[(r - 1) & 1][2 * h + e][lane], hist[e][0], recfmt[(r - 1) & 1][2 * h + e]);
           const bool valid = (((r - 1) << 6) + lane < nb[e]) && !(r == 1 && lane < 2);
           sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
         }
@@ -740,6 +762,9 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
         if (lane == 0) oflag[r & 1][2 * h + e] = ok2;
         sy_a[e] = sy_b[e];
         sy_b[e] = sy_c[e];
+        hist[e][0] = hist[e][1];
+        hist[e][1] = hist[e][2];
+        hist[e][2] = o2[e];
       }
       __syncthreads();
     }
@@ -747,7 +772,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     for (int e = 0; e < 2; e++) {
       if (!nb[e]) continue;
       const u32 r = nsr - 1;
-      const uint2 v = rec[r & 1][2 * h + e][lane];
+      const uint2 v = outcome(rec[r & 1][2 * h + e][lane], hist[e][0], recfmt[r & 1][2 * h + e]);
       const bool valid = ((r << 6) + lane < nb[e]) && !(r == 0 && lane < 2);
       sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       const u32 bytes = sink[e].finish(buf, lane, final_lo[2 * h + e]);
@@ -790,35 +815,26 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const u64 m15 = __ballot(col == R - 1 && s_M != 0);
       const bool row_plain = !GENERAL && cur_ok && ((m15 >> (row * R + R - 1)) & 1);
       const bool row_live = r < nsr_row;
-      bool bad = false;
       if (!GENERAL && __any(row_plain)) {
-        u32 badacc = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
           sys_round_rows<R>(st, tlo, tM, ops[q]);
-          // every lane redoes its own symbol from the state it latched: outcome for the helper, exit test
+          // every lane hands the state it latched in its own step to the helper, which redoes the symbol from it
           const int sq = col & 3;
           const u32 inM = sq == 0 ? st.kM[0] : sq == 1 ? st.kM[1] : sq == 2 ? st.kM[2] : st.kM[3];
           const u32 nlo = sq == 0 ? st.nl[0] : sq == 1 ? st.nl[1] : sq == 2 ? st.nl[2] : st.nl[3];
-          const u32 A = (u32)(((u64)inM * ops[q].w + __umulhi(inM, ops[q].z)) >> 32);
-          const u32 B = (u32)(((u64)inM * ops[q].y + __umulhi(inM, ops[q].x)) >> 32);
-          const u32 W = A - B;
-          const u32 nhi = nlo + W - 1;
-          const u32 x = nlo ^ nhi;
-          const u32 k = ffbh_raw(x);
-          const u32 c1 = ((~nlo | nhi) << 1) | 1u;
-          const u32 u = ffbh_raw(c1 << k);
-          const u32 oM = W << (k + u);
-          // stray bit 31 of the lo this lane received (it travels uncleared, see sys_step): nlo = received + B
-          const u32 stray = (nlo - B) & 0x80000000u;
-          badacc = min(badacc, min(x, oM));  // one v_min3_u32: 0 iff 32 agreeing bits or the range reached 2^32
-          rc[q * R + col] = make_uint2(nhi ^ stray, k | (u << 8));
+          rc[q * R + col] = make_uint2(inM, nlo);
         }
-        bad = badacc == 0;
       }
-      const u64 badm = __ballot(bad);
-      const bool row_bad = ((badm >> (row * R)) & ((1ull << R) - 1)) != 0;
+      // Exit test.  The host only selects this path when no context total exceeds 2^29: every symbol then keeps an
+      // interval of at least two values (range > 2^30), so "all 32 bits agree" cannot happen.  The other exit, a range
+      // that renormalises to the full 2^32, leaves M = 0 behind -- and M = 0 is absorbing in the plain step
+      // (D + 1 = 0 whatever the operands), so it is still there in the last lane at the end of the super-round.
+      if (a.test_poison && r % a.test_poison == 0) tM = 0;  // tests: drive the redo path
+      const u64 badm = __ballot(col == R - 1 && tM == 0);
+      const bool row_bad = ((badm >> (row * R + R - 1)) & 1) != 0;
       const bool need_general = row_live && (!row_plain || row_bad);
+      if (col == R - 1) recfmt[r & 1][row] = need_general ? 0u : 1u;
       const u64 gm = __ballot(need_general);
       if (gm) {  // rare: first super-round, tails, a step that needs the general path -- row by row on lane 0
         for (int rw = 0; rw < AC4; rw++) {

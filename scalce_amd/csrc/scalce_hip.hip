@@ -796,6 +796,7 @@ struct AcJob {
   u64 nsym;
   u32 nblk;
   bool general;
+  u32 max_total = 0;
 };
 static const u64 AC_STRIDE = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
 
@@ -814,6 +815,7 @@ static int ac_prepare(AcJob &j, hipStream_t s) {
   // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
   // follows it there bit for bit
   j.general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
+  j.max_total = max_total;
   j.nblk = (u32)cdiv(j.nsym, AC_BLOCK_SYMS);
   ENSURE(b, b->ac_blocks[m], (size_t)j.nblk * AC_STRIDE + 64);
   ENSURE(b, b->ac_sizes[m], sizeof(u32) * (j.nblk + 2));
@@ -834,12 +836,18 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
   scalce_ctx *c = lead->ctx;
   u32 total = 0;
   bool general = false;
-  for (int i = 0; i < njobs; i++) { total += jobs[i].nblk; general |= jobs[i].general; }
+  for (int i = 0; i < njobs; i++) {
+    total += jobs[i].nblk;
+    general |= jobs[i].general;
+    // the rows coder's exit test (see ac_encode_rows_k) needs every symbol to keep an interval of two values or more
+    if (blocks_per_wg != 1 && jobs[i].max_total > (1u << 29)) general = true;
+  }
   if (!total) return SCALCE_OK;
   AcEncArgs a;
   memset(&a, 0, sizeof a);
   a.slow_threshold = 32;
   a.chain_prio = getenv("SCALCE_AC_CHAIN_PRIO") ? (u32)atoi(getenv("SCALCE_AC_CHAIN_PRIO")) : 3u;
+  a.test_poison = getenv("SCALCE_AC_TEST_POISON") ? (u32)atoi(getenv("SCALCE_AC_TEST_POISON")) : 0u;  // test hook
   a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
   auto join = [&]() -> int {  // `s` continues behind everything enqueued on `ps` so far

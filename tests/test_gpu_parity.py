@@ -425,3 +425,16 @@ def test_grouped_coder_launch_equals_separate_launches(ctx, monkeypatch):
         b.finish()
         got = b.output(host.OUT_QUAL, 0)
         assert len(got) == len(want) and (got == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks_per_wave", ["4", "8"])
+def test_rows_coder_redo_path(blocks_per_wave, ctx, oracle_trie, monkeypatch):
+    """ac_encode_rows_k finds a step that needed the general path by the absorbing state it leaves behind (range = 2^32
+    -> M = 0 in the last lane at the end of the super-round) and redoes the block's super-round on the general path.
+    SCALCE_AC_TEST_POISON makes every third super-round pretend that happened: state restored, outcomes rewritten in
+    the raw format, same bytes as the oracle."""
+    monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", blocks_per_wave)
+    monkeypatch.setenv("SCALCE_AC_TEST_POISON", "3")
+    bases, quals = synth.reads_and_quals(150_000, 100, seed=77)   # two blocks, the second one short
+    check_against_oracle(ctx, oracle_trie, bases, quals, label="poison" + blocks_per_wave)
