@@ -258,9 +258,9 @@ template <int E>
 struct SysLoop<E, E> {
   static __device__ __forceinline__ void run(SysState &, u32 &, u32 &, const uint4 &) {}
 };
-__device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const uint4 &ops) {
-  // step 0: every lane starts from the round's state (lane 0 is the one that matters)
-  u32 tlo, tM;
+__device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const uint4 &ops, u32 &tlo, u32 &tM) {
+  // step 0: every lane starts from the round's state (lane 0 is the one that matters); the state after the round is
+  // what lane 63 leaves in (tlo, tM)
   asm("v_mov_b32 %0, -1" : "=v"(st.ones));
   {
     st.kM[0] = M0;
@@ -413,7 +413,10 @@ struct AcSink {
 
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
-  __shared__ uint2 rec[2][64];   // chain -> helper: per symbol {hi before the shift, k | u << 8}
+  // chain -> helper, per symbol: {range received, lo + B} as latched by the systolic path (the helper redoes the symbol
+  // from them) or, from the general path, the outcome itself {hi before the shift, k | u << 8}
+  __shared__ uint2 rec[2][64];
+  __shared__ u32 recfmt[2];      // 1: the round holds latched states
   __shared__ uint4 opsb[2][64];  // helper -> chain: operands of a round (slot = round & 1)
   __shared__ u32 oflag[2];       // ... and whether the round may take the systolic path
   __shared__ u32 buf[AC_BUF_WORDS];
@@ -473,10 +476,26 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
     return (rr > 0 && (rr << 6) + 64 <= n && !__any(v.w == 0xFFFFFFFFu)) ? 1u : 0u;
   };
 
+  // outcome of a symbol from what its lane latched in the chain wave: hi before the shift, k agreed bits, u underflow
+  // steps (the chain wave used to redo this itself after every round; the helper has the slack)
+  auto outcome = [&](const uint2 v, const uint4 &o, u32 fmt) -> uint2 {
+    if (!fmt) return v;
+    const u32 inM = v.x, nlo = v.y;
+    const u32 A = (u32)(((u64)inM * o.w + __umulhi(inM, o.z)) >> 32);
+    const u32 B = (u32)(((u64)inM * o.y + __umulhi(inM, o.x)) >> 32);
+    const u32 nhi = nlo + (A - B) - 1;
+    const u32 k = ffbh_raw(nlo ^ nhi);
+    const u32 c1 = ((~nlo | nhi) << 1) | 1u;
+    const u32 u = ffbh_raw(c1 << k);
+    // lo travels with bit 31 uncleared (sys_step): nlo = received + B, the stray bit is bit 31 of what was received
+    return make_uint2(nhi ^ ((nlo - B) & 0x80000000u), k | (u << 8));
+  };
+
   if (!chain_wave) {
     // ================= helper wave: operands two rounds ahead, bits one round behind =================
     sink.carry = ((u32)s[0] << 24) | ((n > 1 ? (u32)s[1] : 0u) << 16);  // raw first two symbols (:110-120)
     u32 sy_a, sy_b;  // symbols of rounds r + 1 and r + 2
+    uint4 hist[3];   // operands of rounds r - 1, r, r + 1 (their LDS slots are long overwritten)
     {
       const u32 sy0 = sym_at(lane);
       sy_a = sym_at(64 + lane);
@@ -484,6 +503,9 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       const uint4 o0 = lookup(0u, sy0, 0), o1 = lookup(sy0, sy_a, 64);
       opsb[0][lane] = o0;
       opsb[1][lane] = o1;
+      hist[0] = make_uint4(0, 0, 0, 0);
+      hist[1] = o0;
+      hist[2] = o1;
       const u32 ok1 = plain_ok(o1, 1);  // a wave-wide vote: not under the lane-0 branch
       if (lane == 0) { oflag[0] = 0; oflag[1] = ok1; }
     }
@@ -492,7 +514,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       const uint4 o2 = lookup(sy_a, sy_b, (r + 2) << 6);   // lands while the bits of round r - 1 are packed
       const u32 sy_c = sym_at(((r + 3) << 6) + lane);
       if (r > 0) {
-        const uint2 v = rec[(r - 1) & 1][lane];
+        const uint2 v = outcome(rec[(r - 1) & 1][lane], hist[0], recfmt[(r - 1) & 1]);
         const bool valid = !(r == 1 && lane < 2);  // round 0: the two raw symbols carry no outcome
         sink.pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       }
@@ -501,12 +523,15 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       if (lane == 0) oflag[r & 1] = ok2;
       sy_a = sy_b;
       sy_b = sy_c;
+      hist[0] = hist[1];
+      hist[1] = hist[2];
+      hist[2] = o2;
       __syncthreads();
     }
     {  // outcomes of the last round
       const u32 r = nrounds - 1;
       const u32 cnt = n - (r << 6);
-      const uint2 v = rec[r & 1][lane];
+      const uint2 v = outcome(rec[r & 1][lane], hist[0], recfmt[r & 1]);
       const bool valid = (u32)lane < cnt && !(r == 0 && lane < 2);
       sink.pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
     }
@@ -530,36 +555,30 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       if (!GENERAL && cur_ok && M0 != 0) {
         SysState st;
         const u64 pt0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
-        sys_round(st, lo, M0, ops);
+        u32 tlo, tM;
+        sys_round(st, lo, M0, ops, tlo, tM);
         if (a.prof) { const u64 pt1 = __builtin_amdgcn_s_memtime(); prof_sys += pt1 - pt0; prof_rounds++; }
-        // every lane now redoes its own symbol from the state it latched: outcome for the helper wave, exit test
+        // every lane hands the state it latched in its own step to the helper, which redoes the symbol from it
         const int q = lane & 3;
         const u32 inM = q == 0 ? st.kM[0] : q == 1 ? st.kM[1] : q == 2 ? st.kM[2] : st.kM[3];
         const u32 nlo = q == 0 ? st.nl[0] : q == 1 ? st.nl[1] : q == 2 ? st.nl[2] : st.nl[3];
-        const u32 A = (u32)(((u64)inM * ops.w + __umulhi(inM, ops.z)) >> 32);
-        const u32 B = (u32)(((u64)inM * ops.y + __umulhi(inM, ops.x)) >> 32);
-        const u32 W = A - B;
-        const u32 nhi = nlo + W - 1;
-        const u32 x = nlo ^ nhi;
-        const u32 k = ffbh_raw(x);
-        const u32 c1 = ((~nlo | nhi) << 1) | 1u;
-        const u32 u = ffbh_raw(c1 << k);
-        const u32 olo = nlo << (k + u), oM = W << (k + u);
-        // bit 31 of the travelling lo is not cleared in the loop (see sys_step): the lane's nlo / nhi carry the
-        // stray bit of the state it received, which is bit 31 of what its left neighbour sent
-        u32 prev = __builtin_amdgcn_update_dpp(0u, olo, 0x138, 0xF, 0xF, false);
-        const u32 stray = prev & 0x80000000u;
-        const bool bad = x == 0 || oM == 0;   // 32 agreeing bits, or the range renormalised to the full 2^32
-        if (!__any(bad)) {  // else (rare): a step needs the general path; redo the round below
-          lo = __builtin_amdgcn_readlane(olo, 63) & 0x7FFFFFFFu;
-          hi = lo + __builtin_amdgcn_readlane(oM, 63) - 1;
-          rc[lane] = make_uint2(nhi ^ stray, k | (u << 8));
+        // Exit test.  The host only selects this path when no context total exceeds 2^29: every symbol then keeps an
+        // interval of at least two values, so "all 32 bits agree" cannot happen; a range that renormalises to the full
+        // 2^32 leaves M = 0 behind, which is absorbing in the plain step (D + 1 = 0 whatever the operands) and so is
+        // still there in lane 63 at the end of the round.
+        const u32 Mfin = __builtin_amdgcn_readlane(tM, 63);
+        if (Mfin != 0 && !(a.test_poison && r % a.test_poison == 0)) {  // else (rare): redo the round below
+          lo = __builtin_amdgcn_readlane(tlo, 63) & 0x7FFFFFFFu;
+          hi = lo + Mfin - 1;
+          rc[lane] = make_uint2(inM, nlo);
+          if (lane == 0) recfmt[r & 1] = 1;
           done = true;
         }
       }
       if (!done) {  // general steps on lane 0: first round, last-of-context symbols, full interval, tails
         u32 glo = lo, ghi = hi;
         if (lane == 0) {
+          recfmt[r & 1] = 0;
           for (u32 j = (r == 0) ? 2u : 0u; j < cnt; j++) {
             const uint4 g = make_uint4(__builtin_amdgcn_readlane(ops.x, j), __builtin_amdgcn_readlane(ops.y, j),
                                        __builtin_amdgcn_readlane(ops.z, j), __builtin_amdgcn_readlane(ops.w, j));

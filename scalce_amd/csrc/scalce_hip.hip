@@ -839,8 +839,8 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
   for (int i = 0; i < njobs; i++) {
     total += jobs[i].nblk;
     general |= jobs[i].general;
-    // the rows coder's exit test (see ac_encode_rows_k) needs every symbol to keep an interval of two values or more
-    if (blocks_per_wg != 1 && jobs[i].max_total > (1u << 29)) general = true;
+    // the plain path's exit test (see ac_encode_k) needs every symbol to keep an interval of two values or more
+    if (jobs[i].max_total > (1u << 29)) general = true;
   }
   if (!total) return SCALCE_OK;
   AcEncArgs a;

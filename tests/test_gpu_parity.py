@@ -428,9 +428,9 @@ def test_grouped_coder_launch_equals_separate_launches(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks_per_wave", ["4", "8"])
+@pytest.mark.parametrize("blocks_per_wave", ["1", "4", "8"])
 def test_rows_coder_redo_path(blocks_per_wave, ctx, oracle_trie, monkeypatch):
-    """ac_encode_rows_k finds a step that needed the general path by the absorbing state it leaves behind (range = 2^32
+    """The coder kernels find a step that needed the general path by the absorbing state it leaves behind (range = 2^32
     -> M = 0 in the last lane at the end of the super-round) and redoes the block's super-round on the general path.
     SCALCE_AC_TEST_POISON makes every third super-round pretend that happened: state restored, outcomes rewritten in
     the raw format, same bytes as the oracle."""
