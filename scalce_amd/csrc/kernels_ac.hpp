@@ -83,6 +83,7 @@ struct AcEncArgs {
   const AcBlockDesc *desc;  // ac_encode_rows_k: one entry per block of the launch
   u32 nblocks;
   u32 chain_prio;      // s_setprio of the chain waves (ac_encode_rows_k)
+  u32 helper_prio;     // s_setprio of the helper waves (ac_encode_rows_k)
   u32 test_poison;     // test hook: every test_poison-th super-round pretends a step hit the full-range exit (0 = off)
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
@@ -411,6 +412,79 @@ struct AcSink {
   }
 };
 
+// Two blocks' rounds packed side by side (helper waves of ac_encode_rows_k serve two blocks each).  The same
+// computation as AcSink::pack, written phase by phase for both blocks: a pack is a chain of LDS round trips (shuffle,
+// zero fill, OR-ing the bits in, reading the finished words back), and one after the other the two chains added up to
+// more than the helper's share of a SIMD allows once another shard's front stages run beside the coder (the chain wave
+// then waited at the barrier for 27 % of its time).  Interleaved, one block's latency hides behind the other's work.
+__device__ __forceinline__ void ac_pack2(AcSink *sk, u32 *buf0, u32 *buf1, int lane, u32 slow_threshold, const u32 *rH,
+                                         const u32 *rK) {
+  u32 *bufs[2] = {buf0, buf1};
+  u32 k[2], P[2], msb[2], rest[2], pend_out[2], nbits[2], o[2], total[2];
+  bool flag[2];
+  bool slow = false;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    k[e] = rK[e] & 0xFF;
+    const u32 u = rK[e] >> 8;
+    flag[e] = k[e] != 0;
+    const u32 S = wave_inclusive_sum(u);
+    const u64 fm = __ballot(flag[e]);
+    const u64 upto = fm & ((lane == 63) ? ~0ull : ((2ull << lane) - 1));
+    const int f = upto ? 63 - __clzll((long long)upto) : -1;
+    const u32 sbase = __shfl(S - u, f < 0 ? 0 : f, 64);
+    const u32 U = f < 0 ? sk[e].pend + S : S - sbase;
+    P[e] = __builtin_amdgcn_update_dpp(sk[e].pend, U, 0x138, 0xF, 0xF, false);
+    const u32 top = flag[e] ? (k[e] == 32 ? rH[e] : (rH[e] >> (32 - k[e]))) : 0u;
+    msb[e] = flag[e] ? (top >> (k[e] - 1)) : 0u;
+    rest[e] = (k[e] > 1) ? (top & ((1u << (k[e] - 1)) - 1)) : 0u;
+    pend_out[e] = __builtin_amdgcn_readlane(U, 63);
+    slow = slow || __any(flag[e] && P[e] > slow_threshold);
+  }
+  if (slow) {  // an underflow run longer than 32 bits (about once per 2^32 symbols): the serial walk, block by block
+    sk[0].pack(buf0, lane, slow_threshold, rH[0], rK[0]);
+    sk[1].pack(buf1, lane, slow_threshold, rH[1], rK[1]);
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    nbits[e] = flag[e] ? k[e] + P[e] : 0u;
+    const u32 incl = wave_inclusive_sum(nbits[e]);
+    total[e] = __builtin_amdgcn_readlane(incl, 63);
+    o[e] = sk[e].c0 + incl - nbits[e];
+    for (int w = lane; w < AC_BUF_WORDS; w += 64) bufs[e][w] = (w == 0) ? sk[e].carry : 0u;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    if (flag[e]) {
+      const u32 run = (msb[e] || P[e] == 0) ? 0u : (P[e] == 32 ? 0xFFFFFFFFu : ((1u << P[e]) - 1));
+      const u64 v = ((u64)msb[e] << (P[e] + k[e] - 1)) | ((u64)run << (k[e] - 1)) | rest[e];
+      if (nbits[e] > 32) {
+        lds_place(bufs[e], (u32)(v >> 32), nbits[e] - 32, o[e]);
+        lds_place(bufs[e], (u32)v, 32, o[e] + nbits[e] - 32);
+      } else {
+        lds_place(bufs[e], (u32)v, nbits[e], o[e]);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const u32 endbits = sk[e].c0 + total[e];
+    const u32 nfull = endbits >> 5;
+    for (u32 w = lane; w < nfull; w += 64) {
+      if (sk[e].gw + w < sk[e].wcap) sk[e].dst[sk[e].gw + w] = __builtin_bswap32(bufs[e][w]);
+      else sk[e].over = true;
+    }
+    sk[e].carry = bufs[e][nfull];
+    sk[e].c0 = endbits & 31;
+    sk[e].gw += nfull;
+    sk[e].pend = pend_out[e];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <bool GENERAL>
 __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   // chain -> helper, per symbol: {range received, lo + B} as latched by the systolic path (the helper redoes the symbol
@@ -672,7 +746,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
   __shared__ u32 recfmt[2][AC4];      // 1: that block's super-round holds latched states
   __shared__ uint4 opsb[2][AC4][64];  // helpers -> chain: operands of a super-round (slot = super-round & 1)
   __shared__ u32 oflag[2][AC4];       // ... and whether that block's super-round may take the systolic path
-  __shared__ u32 bufs[NH][AC_BUF_WORDS];
+  __shared__ u32 bufs[NH][2][AC_BUF_WORDS];
   __shared__ u32 wave_simd[1 + NH];
   __shared__ u32 final_lo[AC4];
 
@@ -698,14 +772,21 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
 
   if (wv != 0) {
     // ================= helper waves: two blocks each =================
-    // default priority: with several blocks per chain wave the helpers have slack, and the front stages of the next
-    // shards need the SIMDs they sit on more than they do (measured: front 230 -> ? ms per shard)
+    // beside other shards' front stages it is the helpers, not the chain, that fall behind (SCALCE_AC_PROF: the chain
+    // waves then wait at the barrier for 27 % of their time, 0.9 % alone)
+    switch (a.helper_prio) {
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      default: break;
+    }
     const int h = wv - 1;
-    u32 *buf = bufs[h];
+    u32 *buf0 = bufs[h][0], *buf1 = bufs[h][1];
     AcSink sink[2];
     const u8 *sp[2];
     const uint4 *tabp[2];
-    u32 nb[2], sy_a[2], sy_b[2];
+    u32 nb[2], sy_a[2], sy_b[2];  // sy_a, sy_b: symbols of super-rounds r + 2 and r + 3
+    uint4 o_pend[2];              // operands of super-round r + 2, in flight since the last iteration
     auto sym_at = [&](int e, u32 i) -> u32 { return i < nb[e] ? (u32)sp[e][i] : 0u; };
     auto lookup = [&](int e, u32 sy_prev, u32 sy, u32 base) -> uint4 {
       const u32 e63 = __builtin_amdgcn_readlane(sy_prev, 63), e62 = __builtin_amdgcn_readlane(sy_prev, 62);
@@ -745,10 +826,13 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sink[e].dst = dsc.dst;
       sink[e].wcap = a.out_cap / 4;
       if (nb[e]) sink[e].carry = ((u32)sp[e][0] << 24) | ((nb[e] > 1 ? (u32)sp[e][1] : 0u) << 16);
-      const u32 sy0 = sym_at(e, lane);
-      sy_a[e] = sym_at(e, 64 + lane);
-      sy_b[e] = sym_at(e, 128 + lane);
-      const uint4 o0 = lookup(e, 0u, sy0, 0), o1 = lookup(e, sy0, sy_a[e], 64);
+      // table rows are fetched two super-rounds before the chain wave needs them and the symbols they are addressed
+      // with a super-round before that: beside other shards' front stages a fetch can take longer than a super-round
+      const u32 sy0 = sym_at(e, lane), sy1 = sym_at(e, 64 + lane);
+      sy_a[e] = sym_at(e, 128 + lane);
+      sy_b[e] = sym_at(e, 192 + lane);
+      const uint4 o0 = lookup(e, 0u, sy0, 0), o1 = lookup(e, sy0, sy1, 64);
+      o_pend[e] = lookup(e, sy1, sy_a[e], 128);
       opsb[0][2 * h + e][lane] = o0;
       opsb[1][2 * h + e][lane] = o1;
       hist[e][0] = make_uint4(0, 0, 0, 0);
@@ -759,20 +843,24 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     }
     __syncthreads();
     for (u32 r = 0; r < nsr; r++) {
-      uint4 o2[2];
+      uint4 o2[2], o3[2];
       u32 sy_c[2];
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        o2[e] = lookup(e, sy_a[e], sy_b[e], (r + 2) << 6);
-        sy_c[e] = sym_at(e, ((r + 3) << 6) + lane);
+        o2[e] = o_pend[e];
+        o3[e] = lookup(e, sy_a[e], sy_b[e], (r + 3) << 6);
+        sy_c[e] = sym_at(e, ((r + 4) << 6) + lane);
       }
       if (r > 0) {
+        u32 rH[2], rK[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const uint2 v = outcome(rec[(r - 1) & 1][2 * h + e][lane], hist[e][0], recfmt[(r - 1) & 1][2 * h + e]);
           const bool valid = (((r - 1) << 6) + lane < nb[e]) && !(r == 1 && lane < 2);
-          sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
+          rH[e] = valid ? v.x : 0u;
+          rK[e] = valid ? v.y : 0u;
         }
+        ac_pack2(sink, buf0, buf1, lane, a.slow_threshold, rH, rK);
       }
 #pragma unroll
       for (int e = 0; e < 2; e++) {
@@ -781,6 +869,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
         if (lane == 0) oflag[r & 1][2 * h + e] = ok2;
         sy_a[e] = sy_b[e];
         sy_b[e] = sy_c[e];
+        o_pend[e] = o3[e];
         hist[e][0] = hist[e][1];
         hist[e][1] = hist[e][2];
         hist[e][2] = o2[e];
@@ -793,6 +882,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const u32 r = nsr - 1;
       const uint2 v = outcome(rec[r & 1][2 * h + e][lane], hist[e][0], recfmt[r & 1][2 * h + e]);
       const bool valid = ((r << 6) + lane < nb[e]) && !(r == 0 && lane < 2);
+      u32 *buf = e ? buf1 : buf0;
       sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       const u32 bytes = sink[e].finish(buf, lane, final_lo[2 * h + e]);
       const AcBlockDesc dsc = a.desc[blk0 + 2 * h + e];

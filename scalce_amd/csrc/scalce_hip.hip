@@ -207,6 +207,8 @@ struct scalce_batch {
   size_t kev_used = 0;
   u64 k_in_bytes = 0, k_out_bytes = 0;
   // entropy launched but its result size not read back yet (scalce_batch_entropy_begin / _end): blocks per mate
+  u64 *prof_ptr = nullptr;  // SCALCE_AC_PROF of the last rows-coder launch this shard led
+  u32 prof_n = 0;
   u32 ent_pending[2] = {0, 0};
   // symbol stream to code per mate: the shard's own reordered stream, or one the caller assembled (sharded runs)
   const u8 *ent_sym[2] = {nullptr, nullptr};
@@ -847,6 +849,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
   memset(&a, 0, sizeof a);
   a.slow_threshold = 32;
   a.chain_prio = getenv("SCALCE_AC_CHAIN_PRIO") ? (u32)atoi(getenv("SCALCE_AC_CHAIN_PRIO")) : 3u;
+  a.helper_prio = getenv("SCALCE_AC_HELPER_PRIO") ? (u32)atoi(getenv("SCALCE_AC_HELPER_PRIO")) : 0u;
   a.test_poison = getenv("SCALCE_AC_TEST_POISON") ? (u32)atoi(getenv("SCALCE_AC_TEST_POISON")) : 0u;  // test hook
   a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
@@ -928,15 +931,9 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
       else LAUNCH((ac_encode_rows_k<false, 16>), cdiv(total, 4), 192, 0, s, a);
     }
     if (ke1) hipEventRecord(ke1, s);
-    if (a.prof) {  // profiling only (blocks the host): share of the chain waves' time spent waiting at the barrier
-      std::vector<u64> h(3 * (size_t)nwg);
-      HIP_TRY(c, hipStreamSynchronize(s));
-      HIP_TRY(c, hipMemcpy(h.data(), a.prof, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
-      double wait = 0, tot = 0;
-      for (u32 i = 0; i < nwg; i++) { wait += h[3 * i]; tot += h[3 * i + 1]; }
-      fprintf(stderr, "ac prof (rows): %u workgroups, chain waves waited at the barrier %.1f %% of their time (%.0f of %.0f Mcycles each)\n",
-              nwg, 100.0 * wait / tot, wait / nwg / 1e6, tot / nwg / 1e6);
-      hipFree(a.prof);
+    if (a.prof) {  // profiling only: read back when the lead shard is collected (the launch keeps running beside others)
+      lead->prof_ptr = a.prof;
+      lead->prof_n = nwg;
     }
   }
   for (int i = 0; i < njobs; i++) lead->k_in_bytes += jobs[i].nsym;
@@ -975,6 +972,16 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
 
 // second half of the entropy stage: wait for the coder and read the size of the framed stream(s)
 static int entropy_collect(scalce_batch *b, hipStream_t s) {
+  if (b->prof_ptr) {  // profiling only: share of the chain waves' time spent waiting at the barrier
+    std::vector<u64> h(3 * (size_t)b->prof_n);
+    HIP_TRY(b->ctx, hipMemcpy(h.data(), b->prof_ptr, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
+    double wait = 0, tot = 0;
+    for (u32 i = 0; i < b->prof_n; i++) { wait += h[3 * i]; tot += h[3 * i + 1]; }
+    fprintf(stderr, "ac prof (rows): %u workgroups, chain waves waited at the barrier %.1f %% of their time (%.0f of %.0f Mcycles each)\n",
+            b->prof_n, 100.0 * wait / tot, wait / b->prof_n / 1e6, tot / b->prof_n / 1e6);
+    hipFree(b->prof_ptr);
+    b->prof_ptr = nullptr;
+  }
   for (int m = 0; m < b->nm; m++) {
     if (!b->ent_pending[m]) continue;
     u64 total = 0;
