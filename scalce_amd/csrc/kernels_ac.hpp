@@ -842,6 +842,8 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       if (lane == 0) { oflag[0][2 * h + e] = 0; oflag[1][2 * h + e] = ok1; }
     }
     __syncthreads();
+    u64 hprof_wait = 0;
+    const u64 hprof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     for (u32 r = 0; r < nsr; r++) {
       uint4 o2[2], o3[2];
       u32 sy_c[2];
@@ -874,7 +876,17 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
         hist[e][1] = hist[e][2];
         hist[e][2] = o2[e];
       }
-      __syncthreads();
+      if (a.prof && h == 0) {
+        const u64 w0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        hprof_wait += __builtin_amdgcn_s_memtime() - w0;
+      } else {
+        __syncthreads();
+      }
+    }
+    if (a.prof && h == 0 && lane == 0) {
+      a.prof[blockIdx.x * 5 + 3] = hprof_wait;
+      a.prof[blockIdx.x * 5 + 4] = __builtin_amdgcn_s_memtime() - hprof_t0;
     }
 #pragma unroll
     for (int e = 0; e < 2; e++) {
@@ -984,9 +996,9 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       }
     }
     if (a.prof && lane == 0) {
-      a.prof[blockIdx.x * 3 + 0] = prof_wait;
-      a.prof[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
-      a.prof[blockIdx.x * 3 + 2] = nsr;
+      a.prof[blockIdx.x * 5 + 0] = prof_wait;
+      a.prof[blockIdx.x * 5 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
+      a.prof[blockIdx.x * 5 + 2] = nsr;
     }
   }
 }

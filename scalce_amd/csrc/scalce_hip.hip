@@ -922,7 +922,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
     const u32 nwg = cdiv(total, (u32)blocks_per_wg);
-    if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 3 * nwg)); }
+    if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * nwg)); }
     if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
@@ -973,12 +973,13 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
 // second half of the entropy stage: wait for the coder and read the size of the framed stream(s)
 static int entropy_collect(scalce_batch *b, hipStream_t s) {
   if (b->prof_ptr) {  // profiling only: share of the chain waves' time spent waiting at the barrier
-    std::vector<u64> h(3 * (size_t)b->prof_n);
+    std::vector<u64> h(5 * (size_t)b->prof_n);
     HIP_TRY(b->ctx, hipMemcpy(h.data(), b->prof_ptr, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
-    double wait = 0, tot = 0;
-    for (u32 i = 0; i < b->prof_n; i++) { wait += h[3 * i]; tot += h[3 * i + 1]; }
-    fprintf(stderr, "ac prof (rows): %u workgroups, chain waves waited at the barrier %.1f %% of their time (%.0f of %.0f Mcycles each)\n",
-            b->prof_n, 100.0 * wait / tot, wait / b->prof_n / 1e6, tot / b->prof_n / 1e6);
+    double wait = 0, tot = 0, hwait = 0, htot = 0;
+    for (u32 i = 0; i < b->prof_n; i++) { wait += h[5 * i]; tot += h[5 * i + 1]; hwait += h[5 * i + 3]; htot += h[5 * i + 4]; }
+    fprintf(stderr, "ac prof (rows): %u workgroups, chain waves waited at the barrier %.1f %% of their time (%.0f of %.0f Mcycles each), "
+            "the first helper wave %.1f %%\n",
+            b->prof_n, 100.0 * wait / tot, wait / b->prof_n / 1e6, tot / b->prof_n / 1e6, 100.0 * hwait / (htot > 0 ? htot : 1));
     hipFree(b->prof_ptr);
     b->prof_ptr = nullptr;
   }
