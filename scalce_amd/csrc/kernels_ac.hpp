@@ -1028,6 +1028,56 @@ __global__ __launch_bounds__(256) void ac_frame_k(const u8 *blocks, u64 stride, 
 //   count >= cum[s]  <=>  v >= floor(range * cum[s] / total),   count < cum[s+1]  <=>  v < floor(range * cum[s+1] / total),
 // so the search is equivalent and no division is left.  The table row of the context is the one dependent
 // memory access per symbol (the context is only known once the previous symbol is out).
+// Bit reader of one block, one wavefront: the 64 lanes hold the next 64 big-endian words of the stream (one coalesced
+// load per 2048 bits, the following window already in flight), a word is handed out by v_readlane.  (Read byte by
+// byte at the point of use, each refill cost four dependent memory round trips: a third of the decoder's time.)
+struct AcBitReader {
+  const u8 *in;
+  u32 insz;      // bytes of the block; zeros are read past its end
+  u32 base;      // byte position of lane 0's word of the current window
+  u32 wcur, wnext;
+  u32 wi;        // next word of the current window (wave-uniform)
+  u64 win;       // the next `wb` bits, left aligned
+  u32 wb;
+  __device__ __forceinline__ u32 load_window(u32 pos0, int lane) const {
+    const u32 pos = pos0 + 4u * (u32)lane;
+    u32 w = 0;
+    if (pos + 4 <= insz) {
+      u32 raw;
+      __builtin_memcpy(&raw, in + pos, 4);  // any alignment
+      w = __builtin_bswap32(raw);
+    } else {
+      for (int k = 0; k < 4; k++) w = (w << 8) | (pos + k < insz ? (u32)in[pos + k] : 0u);
+    }
+    return w;
+  }
+  __device__ __forceinline__ void start(const u8 *p, u32 n, u32 pos0, int lane) {
+    in = p; insz = n; base = pos0;
+    wcur = load_window(pos0, lane);
+    wnext = load_window(pos0 + 256, lane);
+    wi = 0; win = 0; wb = 0;
+    refill(lane);
+    refill(lane);
+  }
+  __device__ __forceinline__ void refill(int lane) {  // wb <= 32: append one word
+    const u32 w = __builtin_amdgcn_readlane(wcur, wi);
+    win |= (u64)w << (32 - wb);
+    wb += 32;
+    if (++wi == 64) {
+      wi = 0;
+      base += 256;
+      wcur = wnext;
+      wnext = load_window(base + 256, lane);
+    }
+  }
+  __device__ __forceinline__ u32 get(u32 cnt, int lane) {  // cnt in 1..32
+    const u32 r = (u32)(win >> (64 - cnt));
+    win <<= cnt;
+    wb -= cnt;
+    if (wb <= 32) refill(lane);
+    return r;
+  }
+};
 struct AcDecArgs {
   const u8 *in;          // framed stream
   const u64 *blk_off;    // byte offset of each block's payload (after its size word)
@@ -1048,29 +1098,9 @@ __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
   if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
   if (p0 >= AC_D) p0 = AC_D - 1;  // corrupt stream: stay inside the tables
   if (p1 >= AC_D) p1 = AC_D - 1;
-  // bit reader: `win` holds the next `wb` bits of the stream, left aligned; refilled 32 bits at a time
-  u32 bytepos = 2;
-  auto word_at = [&](u32 pos) -> u32 {  // big-endian, zeros past the end of the block
-    u32 w = 0;
-    for (int k = 0; k < 4; k++) w = (w << 8) | (pos + k < insz ? (u32)in[pos + k] : 0u);
-    return w;
-  };
-  u64 win = ((u64)word_at(2) << 32) | word_at(6);
-  u32 wb = 64;
-  bytepos = 10;
-  u32 nextw = word_at(10);
-  auto getbits = [&](u32 cnt) -> u32 {  // cnt in 1..32
-    const u32 r = (u32)(win >> (64 - cnt));
-    win <<= cnt;
-    wb -= cnt;
-    if (wb <= 32) {
-      win |= (u64)nextw << (32 - wb);
-      wb += 32;
-      bytepos += 4;
-      nextw = word_at(bytepos);
-    }
-    return r;
-  };
+  AcBitReader br;
+  br.start(in, insz, 2, lane);
+  auto getbits = [&](u32 cnt) -> u32 { return br.get(cnt, lane); };
   u32 lo = 0, hi = 0xFFFFFFFFu, code = getbits(32);
   // lane j keeps symbol (i & 63) == j until 64 are gathered; the two raw symbols sit in lanes 0 and 1
   u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
@@ -1120,6 +1150,136 @@ __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
     p1 = sidx;
   }
   // tail of the last partial group
+  const u32 done = n & ~63u;
+  if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
+}
+
+// ---- decoder with the hot contexts' rows in LDS ------------------------------------------------------------
+// ac_decode_k's symbol costs one dependent 1280-byte row fetch from L2 (~0.4 us).  Two things shorten it:
+//  * compact rows: the decoder only needs the UPPER bound g(hi) of every symbol (the lower bound is the neighbour's),
+//    and only for the symbols that occur -- `rows[ctx]` holds S1 <= 64 entries of 8 bytes for the symbols
+//    smin - 1 .. smax (entry 0 is the bound below the span).  A code value outside the span (a symbol whose scaled count
+//    is 1 everywhere: possible, rare) goes through the full row exactly as ac_decode_k does;
+//  * the rows of the W x W most frequent contexts (the W symbols with the largest totals) sit in LDS (128 KB, two
+//    blocks per workgroup share them), addressed by the symbols' ranks, no map in between;
+// and the next row is requested as soon as the symbol is known, before the renormalisation and the bit refill.
+constexpr u32 AC_DEC_CACHE_ENTRIES = 16384;  // x 8 bytes = 128 KB of LDS
+struct AcDecCachedArgs {
+  AcDecArgs d;
+  const uint2 *rows;   // [6400][S1]
+  u32 smin, S1, W, nblk;
+  u8 hot[32];          // the W cached symbols, by rank
+  u8 rank[80];         // rank of a symbol, 0xFF = not cached
+};
+__global__ __launch_bounds__(256) void ac_dec_rows_k(const uint4 *tab, u32 smin, u32 S1, uint2 *rows) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 6400u * S1) return;
+  const u32 ctx = i / S1, j = i % S1;
+  uint2 v = make_uint2(0, 0);  // smin = 0: nothing lies below the span, the bound is 0
+  if (smin + j >= 1) { const uint4 e = tab[(u64)ctx * AC_D + (smin + j - 1)]; v = make_uint2(e.z, e.w); }
+  rows[i] = v;
+}
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void ac_decode_cached_k(AcDecCachedArgs a) {
+  __shared__ uint2 cache[AC_DEC_CACHE_ENTRIES];
+  const u32 W = a.W, S1 = a.S1;
+  for (u32 i = threadIdx.x; i < W * W * S1; i += blockDim.x) {
+    const u32 slot = i / S1, j = i % S1;
+    const u32 ctx = (u32)a.hot[slot / W] * AC_D + a.hot[slot % W];
+    cache[i] = a.rows[(u64)ctx * S1 + j];
+  }
+  __syncthreads();
+  const u32 blk = blockIdx.x * WPB + wave_id();
+  if (blk >= a.nblk) return;
+  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
+  const u32 n = (u32)((a.d.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.d.nsym - boff) : (u64)AC_BLOCK_SYMS);
+  const u8 *in = a.d.in + a.d.blk_off[blk];
+  const u32 insz = a.d.blk_size[blk];
+  u8 *out = a.d.out + boff;
+  const int lane = lane_id();
+  u32 p0 = insz > 0 ? in[0] : 0, p1 = insz > 1 ? in[1] : 0;
+  if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
+  if (p0 >= AC_D) p0 = AC_D - 1;
+  if (p1 >= AC_D) p1 = AC_D - 1;
+  const u32 rk0 = a.rank[lane], rk1 = lane < 16 ? a.rank[64 + lane] : 0xFFu;
+  auto rank_of = [&](u32 sy) -> u32 {  // sy wave-uniform
+    return sy < 64 ? __builtin_amdgcn_readlane(rk0, sy) : __builtin_amdgcn_readlane(rk1, sy - 64);
+  };
+  auto fetch = [&](u32 c0, u32 c1, u32 q0, u32 q1) -> uint2 {
+    uint2 e = make_uint2(0, 0);
+    if ((u32)lane < S1) {
+      if (q0 < W && q1 < W) e = cache[(q0 * W + q1) * S1 + lane];
+      else e = a.rows[(u64)(c0 * AC_D + c1) * S1 + lane];
+    }
+    return e;
+  };
+  AcBitReader br;
+  br.start(in, insz, 2, lane);
+  auto getbits = [&](u32 cnt) -> u32 { return br.get(cnt, lane); };
+  u32 lo = 0, hi = 0xFFFFFFFFu, code = getbits(32);
+  u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
+  u32 r0 = rank_of(p0), r1 = rank_of(p1);
+  uint2 e = fetch(p0, p1, r0, r1);
+  for (u32 i = 2; i < n; i++) {
+    const u32 R = hi - lo, v = code - lo;
+    const bool last = (e.x & e.y) == 0xFFFFFFFFu;  // g(hi) = 2^64 - 1 marks the context's last symbol
+    const u32 U = mulfrac(R, e.x, e.y);
+    const u64 m = __ballot((u32)lane < S1 && (last || v < U));
+    const u32 j = m ? (u32)__ffsll((long long)m) - 1 : S1;
+    u32 sidx, A, B;
+    bool is_last;
+    if (j == 0 || j >= S1) {
+      // below or above the symbols the compact rows hold: the full row, as ac_decode_k
+      const uint4 *row = a.d.tab + (u64)(p0 * AC_D + p1) * AC_D;
+      const uint4 f0 = row[lane];
+      const uint4 f1 = lane < 16 ? row[64 + lane] : make_uint4(0, 0, 0, 0);
+      const bool last0 = f0.w == 0xFFFFFFFFu, last1 = f1.w == 0xFFFFFFFFu;
+      const u32 U0 = mulfrac(R, f0.z, f0.w), U1 = mulfrac(R, f1.z, f1.w);
+      const u64 m0 = __ballot(last0 || v < U0);
+      const u64 m1 = __ballot(lane < 16 && (last1 || v < U1));
+      if (m0) {
+        sidx = (u32)__ffsll((long long)m0) - 1;
+        A = __builtin_amdgcn_readlane(U0, sidx);
+        is_last = __builtin_amdgcn_readlane((u32)last0, sidx) != 0;
+        B = sidx ? __builtin_amdgcn_readlane(U0, sidx - 1) : 0u;
+      } else {
+        const u32 t = m1 ? (u32)__ffsll((long long)m1) - 1 : 15u;  // corrupt stream: last symbol
+        sidx = 64 + t;
+        A = __builtin_amdgcn_readlane(U1, t);
+        is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
+        B = t ? __builtin_amdgcn_readlane(U1, t - 1) : __builtin_amdgcn_readlane(U0, 63);
+      }
+    } else {
+      sidx = a.smin - 1 + j;
+      A = __builtin_amdgcn_readlane(U, j);
+      B = __builtin_amdgcn_readlane(U, j - 1);
+      is_last = __builtin_amdgcn_readlane((u32)last, j) != 0;
+    }
+    // the next context is known: ask for its row before anything else
+    p0 = p1;
+    p1 = sidx;
+    r0 = r1;
+    r1 = rank_of(sidx);
+    const uint2 e_next = fetch(p0, p1, r0, r1);
+    const u32 nhi = is_last ? hi : lo + A - 1;
+    const u32 nlo = lo + B;
+    const u32 x = nlo ^ nhi;
+    const u32 k = x ? (u32)__clz(x) : 32u;
+    u32 l1, h1;
+    if (k == 32) { l1 = 0; h1 = 0xFFFFFFFFu; code = getbits(32); }
+    else if (k) { l1 = nlo << k; h1 = (nhi << k) | ((1u << k) - 1); code = (code << k) | getbits(k); }
+    else { l1 = nlo; h1 = nhi; }
+    const u32 y = (l1 & ~h1) << 1;
+    const u32 u = (u32)__clz(~y);
+    if (u) {
+      lo = (l1 << u) & 0x7FFFFFFFu;
+      hi = (h1 << u) | ((1u << u) - 1) | 0x80000000u;
+      code = ((code << u) ^ 0x80000000u) | getbits(u);
+    } else { lo = l1; hi = h1; }
+    outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
+    if ((i & 63) == 63) out[(i & ~63u) + lane] = (u8)outacc;
+    e = e_next;
+  }
   const u32 done = n & ~63u;
   if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
 }

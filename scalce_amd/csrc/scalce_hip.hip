@@ -1302,8 +1302,42 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
   LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, d_table, d_tab, d_cum, (u32 *)nullptr);
   AcDecArgs a;
   a.in = d_blocks; a.blk_off = d_off; a.blk_size = d_sz; a.nsym = nsym; a.tab = d_tab; a.out = d_out;
-  LAUNCH(ac_decode_k, nblk, 64, 0, s, a);
+  // span of the symbols that occur (scaled count > 1 in some context) and their totals: what the compact rows hold and
+  // which contexts go to LDS.  (A symbol outside the span can still be coded -- one occurrence scales down to the
+  // floor count 1 -- and takes the full-row path in the kernel.)
+  u32 smin = AC_D, smax = 0;
+  std::vector<u64> tot(AC_D, 0);
+  for (u32 ctx = 0; ctx < 6400; ctx++)
+    for (u32 sy = 0; sy < AC_D; sy++) {
+      const u32 v = table_host[(size_t)ctx * AC_D + sy];
+      if (v > 1) { smin = std::min(smin, sy); smax = std::max(smax, sy); tot[sy] += v; }
+    }
+  uint2 *d_rows = nullptr;
+  const bool cached = smin <= smax && smax - smin + 2 <= 64 && !getenv("SCALCE_AC_DECODE_PLAIN");
+  if (cached) {
+    AcDecCachedArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.d = a;
+    ca.smin = smin;
+    ca.S1 = smax - smin + 2;
+    ca.nblk = nblk;
+    std::vector<u32> order;
+    for (u32 sy = smin; sy <= smax; sy++) if (tot[sy]) order.push_back(sy);
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return tot[x] > tot[y]; });
+    u32 W = 1;
+    while (W < 32 && W < order.size() && (u64)(W + 1) * (W + 1) * ca.S1 <= AC_DEC_CACHE_ENTRIES) W++;
+    ca.W = W;
+    memset(ca.rank, 0xFF, sizeof ca.rank);
+    for (u32 r = 0; r < W; r++) { ca.hot[r] = (u8)order[r]; ca.rank[order[r]] = (u8)r; }
+    HIP_TRY(c, hipMalloc(&d_rows, sizeof(uint2) * 6400 * ca.S1));
+    LAUNCH(ac_dec_rows_k, cdiv(6400u * ca.S1, 256), 256, 0, s, d_tab, smin, ca.S1, d_rows);
+    ca.rows = d_rows;
+    LAUNCH(ac_decode_cached_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+  } else {
+    LAUNCH(ac_decode_k, nblk, 64, 0, s, a);
+  }
   HIP_TRY(c, hipStreamSynchronize(s));
   hipFree(d_table); hipFree(d_cum); hipFree(d_tab); hipFree(d_off); hipFree(d_sz);
+  if (d_rows) hipFree(d_rows);
   return SCALCE_OK;
 }

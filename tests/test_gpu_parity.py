@@ -438,3 +438,48 @@ def test_rows_coder_redo_path(blocks_per_wave, ctx, oracle_trie, monkeypatch):
     monkeypatch.setenv("SCALCE_AC_TEST_POISON", "3")
     bases, quals = synth.reads_and_quals(150_000, 100, seed=77)   # two blocks, the second one short
     check_against_oracle(ctx, oracle_trie, bases, quals, label="poison" + blocks_per_wave)
+
+
+@pytest.mark.parametrize("case", ["narrow", "rare_outside", "wide", "top_symbol", "plain_kernel"])
+def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
+    """scalce_ac_decode keeps compact rows (upper bounds of the symbols that occur) and the hot contexts' rows in LDS.
+    Crafted tables drive every path: a narrow alphabet (all contexts cached), symbols whose count is 1 everywhere but
+    which still occur (full-row path), an alphabet wider than one pass (the plain kernel), symbol 79 (the context's
+    last interval).  Encoder and decoder are both checked against the oracle's coder with the same table."""
+    import torch
+    rng = np.random.default_rng(77 + len(case))
+    nsym = 2 * 10 * 1024 * 1024 + 12345  # three blocks, the last one short
+    if case in ("narrow", "plain_kernel"):
+        alphabet, weights = np.array([2, 11, 25, 37]), np.array([0.1, 0.2, 0.3, 0.4])
+    elif case == "rare_outside":
+        alphabet, weights = np.arange(20, 42), None
+    elif case == "wide":
+        alphabet, weights = np.arange(0, 80), None
+    else:
+        alphabet, weights = np.array([30, 31, 40, 78, 79]), None
+    sym = rng.choice(alphabet, size=nsym, p=weights).astype(np.uint8)
+    table = np.ones((6400, 80), dtype=np.uint32)
+    ctxs = rng.integers(0, 6400, size=200_000)
+    np.add.at(table, (ctxs, rng.choice(alphabet, size=ctxs.size, p=weights)), rng.integers(1, 50, size=ctxs.size).astype(np.uint32))
+    table[:, alphabet] += 3
+    if case == "rare_outside":  # symbols 5 and 70 keep the floor count everywhere, and occur
+        at = rng.integers(2, nsym, size=4000)
+        sym[at] = rng.choice(np.array([5, 70, 19, 42], dtype=np.uint8), size=at.size)
+        sym[100:103] = (5, 5, 70)
+    table = table.reshape(-1)
+    if case == "plain_kernel":
+        monkeypatch.setenv("SCALCE_AC_DECODE_PLAIN", "1")
+    want = O.AcStat(table).encode_stream(sym)
+    b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
+    d_sym = torch.from_numpy(sym).to("cuda:0")
+    d_tab = torch.from_numpy(table.view(np.int32)).to("cuda:0")
+    b.entropy_stream(0, d_tab.data_ptr(), d_sym.data_ptr(), nsym)
+    b.finish()
+    enc = b.output(host.OUT_QUAL, 0)
+    assert len(enc) == len(want) and (enc == want).all(), f"{case}: coder bytes differ from the oracle's"
+    out = torch.zeros(nsym, dtype=torch.uint8, device="cuda:0")
+    p, nbytes = b.output_ptr(host.OUT_QUAL, 0)
+    ctx.ac_decode(table, p, nbytes, nsym, out.data_ptr())
+    got = out.cpu().numpy()
+    bad = np.flatnonzero(got != sym)
+    assert len(bad) == 0, f"{case}: decoded stream differs first at {bad[:5]}: {got[bad[:5]]} vs {sym[bad[:5]]}"
