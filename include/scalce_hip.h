@@ -199,6 +199,25 @@ int scalce_selftest_ac(scalce_ctx *ctx, uint64_t ncases, uint32_t seed, int gene
 int scalce_ac_decode(scalce_ctx *ctx, const uint32_t *table_host, const uint8_t *d_blocks, uint64_t nbytes,
                      uint64_t nsymbols, uint8_t *d_symbols_out, void *stream);
 
+/* Records back to FASTQ text on the device: the per-record body of decompress.cpp:240-366 -- bucket directory
+ * (:262-270), un-rotation of the 2-bit bases around the core (:331-345), N where the quality is 0 (:350-351), name
+ * line (:290-299; library mode "@<library>.<index>" :300-304), '+' line, qualities + phred offset.
+ *   reads_host   .scalcer payload behind its header (magic, no_ac, read length), host memory: the directory walk
+ *                is serial; has_buckets = 1 for mate 1 (bucket headers, end metadata), 0 for mate 2 (bare records,
+ *                no core -- the reference's stale `corlen` of decompress.cpp:250,332 is NOT reproduced);
+ *   d_qual       nrecords * read_len quality symbols in archive order (scalce_ac_decode's output, or the raw
+ *                bytes of a -A archive), device memory;
+ *   names_host   .scalcen payload behind magic and use_names byte, or NULL for library mode (`library` used);
+ *   mate_digit   0, or '1' / '2' for paired archives: a name ending in "/x" gets this digit (:296-298);
+ *   d_out        device buffer of out_cap >= scalce_fastq_text_bytes(...) bytes;
+ *   record_offsets_host  optional, nrecords + 1 entries: where each record starts in the text (-S splitting).
+ * Returns when the text is complete. */
+uint64_t scalce_fastq_text_bytes(int read_len, uint64_t nrecords, uint64_t names_bytes, const char *library /* NULL: names */);
+int scalce_fastq_records(scalce_ctx *ctx, int read_len, int has_buckets, const uint8_t *reads_host, uint64_t reads_bytes,
+                         uint64_t nrecords, const uint8_t *d_qual, int64_t phred_offset, const uint8_t *names_host,
+                         uint64_t names_bytes, const char *library, int mate_digit, uint8_t *d_out, uint64_t out_cap,
+                         uint64_t *out_bytes, uint64_t *record_offsets_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -367,30 +367,47 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
         library.assign((const char *)Nn[m].v.data() + Nn[m].pos, Nn[m].v.size() - Nn[m].pos);
       }
   }
-  const int sz_meta = len[0] > 255 ? 2 : 1;
-  // mate 1's bucket directory gives the order and the core of every record; kept for mate 2 (whose stream has no
-  // headers).  The reference lets `corlen` of the LAST mate-1 bucket leak into the mate-2 pass (decompress.cpp:250,
-  // 269,332); mate-2 records carry no core, so the length used here is always 0.
   for (int m = 0; m < nm; m++) {
     const int L = len[m];
-    std::vector<uint8_t> qs;
+    // qualities: arithmetic decoder on the device, or the raw q - offset bytes of a -A archive
+    void *d_q = nullptr;
+    uint64_t total = 0;
     if (!no_ac) {  // table + total + blocks -> GPU decoder
       std::vector<uint32_t> table(512000);
       if (Q[m].read(table.data(), 512000 * 4) != 512000 * 4) FAIL("truncated quality table\n");
-      uint64_t total = 0;
       Q[m].read(&total, 8);
-      qs.resize((size_t)total);
       const size_t nb = Q[m].v.size() - Q[m].pos;
-      void *d_in = nullptr, *d_out = nullptr;
+      void *d_in = nullptr;
       HIPOK(hipMalloc(&d_in, nb + 64));
-      HIPOK(hipMalloc(&d_out, total + 64));
+      HIPOK(hipMalloc(&d_q, total + 64));
       HIPOK(hipMemcpy(d_in, Q[m].v.data() + Q[m].pos, nb, hipMemcpyHostToDevice));
-      SCOK(ctx, scalce_ac_decode(ctx, table.data(), (const uint8_t *)d_in, nb, total, (uint8_t *)d_out, nullptr));
-      HIPOK(hipMemcpy(qs.data(), d_out, total, hipMemcpyDeviceToHost));
-      hipFree(d_in); hipFree(d_out);
+      SCOK(ctx, scalce_ac_decode(ctx, table.data(), (const uint8_t *)d_in, nb, total, (uint8_t *)d_q, nullptr));
+      hipFree(d_in);
     } else {
-      qs.assign(Q[m].v.begin() + (long)Q[m].pos, Q[m].v.end());
+      total = Q[m].v.size() - Q[m].pos;
+      HIPOK(hipMalloc(&d_q, total + 64));
+      HIPOK(hipMemcpy(d_q, Q[m].v.data() + Q[m].pos, total, hipMemcpyHostToDevice));
     }
+    const uint64_t nrec = L ? total / (uint64_t)L : 0;
+    // records -> FASTQ text on the device (decompress.cpp:240-366).  Mate 1's bucket directory gives the core of every
+    // record; mate-2 records carry no core (the reference lets `corlen` of the LAST mate-1 bucket leak into the mate-2
+    // pass, decompress.cpp:250,269,332 -- not reproduced).
+    const uint8_t *npay = names ? Nn[m].v.data() + Nn[m].pos : nullptr;
+    const uint64_t nbytes_names = names ? Nn[m].v.size() - Nn[m].pos : 0;
+    if (names && nbytes_names < nrec) FAIL("truncated name stream\n");
+    const uint64_t cap = scalce_fastq_text_bytes(L, nrec, nbytes_names, names ? nullptr : library.c_str());
+    void *d_text = nullptr;
+    HIPOK(hipMalloc(&d_text, cap + 64));
+    uint64_t text_bytes = 0;
+    std::vector<uint64_t> roff;
+    if (o.split) roff.resize((size_t)nrec + 1);
+    SCOK(ctx, scalce_fastq_records(ctx, L, m == 0, R[m].v.data() + R[m].pos, R[m].v.size() - R[m].pos, nrec, (const uint8_t *)d_q,
+                                   phred[m], npay, nbytes_names, library.c_str(), o.paired ? '1' + m : 0, (uint8_t *)d_text, cap,
+                                   &text_bytes, o.split ? roff.data() : nullptr, nullptr));
+    hipFree(d_q);
+    std::vector<char> text((size_t)text_bytes);
+    HIPOK(hipMemcpy(text.data(), d_text, text_bytes, hipMemcpyDeviceToHost));
+    hipFree(d_text);
     char fn[4096];
     int part = 1;
     auto part_name = [&](int F) {
@@ -398,93 +415,18 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
       else if (o.split) snprintf(fn, sizeof fn, "%s.%d_%d.fastq", o.out.c_str(), part, F + 1);
       else snprintf(fn, sizeof fn, "%s_%d.fastq", o.out.c_str(), F + 1);
     };
-    OutFile fo;
-    part_name(m);
-    fo.open(fn, false);
-    std::string outbuf;
-    outbuf.reserve(64 << 20);
-    size_t qpos = 0, rpos = R[m].pos, npos = Nn[m].pos;
-    const uint8_t *rv = R[m].v.data();
-    const size_t rsz = R[m].v.size();
-    int64_t K = 0, next_info = 0, in_part = 0, nameidx = 0;
-    int32_t core = 0;
-    int corlen = 0;
-    uint64_t total_reads = L ? qs.size() / (uint64_t)L : 0;
-    std::vector<char> line((size_t)L + 2);
-    for (;; K++) {
-      if (m == 0) {
-        if (K == next_info) {  // bucket header, decompress.cpp:262-270
-          if (rpos + 12 > rsz) break;
-          uint64_t cnt;
-          memcpy(&core, rv + rpos, 4);
-          memcpy(&cnt, rv + rpos + 4, 8);
-          rpos += 12;
-          next_info += (int64_t)cnt;
-          if (core == SCALCE_ROOT_CORE) corlen = 0;
-          else {
-            corlen = scalce_pattern_length(ctx, core);
-            if (corlen < 0) FAIL("archive refers to core %d which the core table does not have\n", core);
-          }
-          if (cnt == 0) { K--; continue; }
-        }
-      } else {
-        corlen = 0;
-        if ((uint64_t)K >= total_reads) break;
-      }
-      if (o.split && in_part == o.split) {  // decompress.cpp:276-287
-        fo.write(outbuf.data(), outbuf.size()); outbuf.clear();
-        fo.close();
-        part++; in_part = 0;
-        part_name(m);
-        fo.open(fn, false);
-      }
-      if (names) {  // decompress.cpp:290-299
-        const Reader &nr = Nn[m];
-        if (npos >= nr.v.size()) FAIL("truncated name stream\n");
-        const uint8_t n = nr.v[npos++];
-        outbuf.push_back('@');
-        const size_t at = outbuf.size();
-        outbuf.append((const char *)nr.v.data() + npos, n);
-        npos += n;
-        if (o.paired && n > 1 && outbuf[at + n - 2] == '/') outbuf[at + n - 1] = (char)('1' + m);
-        outbuf.push_back('\n');
-      } else {
-        char nb[4096];
-        int k = snprintf(nb, sizeof nb, "@%s.%lld\n", library.c_str(), (long long)nameidx);
-        outbuf.append(nb, (size_t)k);
-      }
-      const int nbytes = (L - corlen + 3) / 4;
-      if (rpos + (size_t)nbytes + (m == 0 ? sz_meta : 0) > rsz) FAIL("truncated read stream\n");
-      const uint8_t *ob = rv + rpos;
-      rpos += (size_t)nbytes;
-      int end = 0;
-      int lc = 0;
-      if (m == 0) {
-        end = rv[rpos] | (sz_meta == 2 ? (rv[rpos + 1] << 8) : 0);
-        rpos += (size_t)sz_meta;
-        if (end) {  // prefix, then the core itself, then the suffix (decompress.cpp:337-345)
-          for (int i = L - end; i < L - corlen; i++) line[lc++] = "ACGT"[(ob[i >> 2] >> ((~i & 3) << 1)) & 3];
-          const char *cs = scalce_pattern_string(ctx, core);
-          for (int i = 0; i < corlen; i++) line[lc++] = cs[i];
-        }
-      }
-      for (int i = 0; i < L - end; i++) line[lc++] = "ACGT"[(ob[i >> 2] >> ((~i & 3) << 1)) & 3];
-      if (qpos + (size_t)L > qs.size()) FAIL("truncated quality stream\n");
-      const size_t qat = outbuf.size() + (size_t)L + 3;
-      for (int i = 0; i < L; i++)
-        if (!qs[qpos + i]) line[i] = 'N';  // decompress.cpp:350-351
-      outbuf.append(line.data(), (size_t)L);
-      outbuf.append("\n+\n", 3);
-      outbuf.resize(qat + (size_t)L + 1);
-      for (int i = 0; i < L; i++) outbuf[qat + i] = (char)(qs[qpos + i] + phred[m]);
-      outbuf[qat + L] = '\n';
-      qpos += (size_t)L;
-      nameidx++; in_part++;
-      if (outbuf.size() > (48u << 20)) { fo.write(outbuf.data(), outbuf.size()); outbuf.clear(); }
+    const uint64_t per = o.split ? (uint64_t)o.split : (nrec ? nrec : 1);
+    for (uint64_t k0 = 0; k0 < nrec || k0 == 0; k0 += per, part++) {  // decompress.cpp:276-287: a new file every -S reads
+      const uint64_t k1 = std::min<uint64_t>(nrec, k0 + per);
+      const uint64_t b0 = o.split ? roff[(size_t)k0] : 0, b1 = o.split ? roff[(size_t)k1] : text_bytes;
+      OutFile fo;
+      part_name(m);
+      fo.open(fn, false);
+      fo.write(text.data() + b0, (size_t)(b1 - b0));
+      fo.close();
+      LOG("Created %s with %lld reads\n", fn, (long long)(k1 - k0));
+      if (!nrec) break;
     }
-    fo.write(outbuf.data(), outbuf.size());
-    fo.close();
-    LOG("Created %s with %lld reads\n", fn, (long long)K);
   }
   LOG("\tTime elapsed: %.2f s\n", now() - t0);
   return 0;

@@ -14,6 +14,7 @@
 #include "../../include/scalce_hip.h"
 #include "automaton.hpp"
 #include "kernels_ac.hpp"
+#include "kernels_fastq.hpp"
 
 using namespace scalce;
 
@@ -1339,5 +1340,118 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
   HIP_TRY(c, hipStreamSynchronize(s));
   hipFree(d_table); hipFree(d_cum); hipFree(d_tab); hipFree(d_off); hipFree(d_sz);
   if (d_rows) hipFree(d_rows);
+  return SCALCE_OK;
+}
+
+// ---- decode side, records -> FASTQ text (decompress.cpp:240-366) -----------------------------------
+extern "C" uint64_t scalce_fastq_text_bytes(int read_len, uint64_t nrecords, uint64_t names_bytes, const char *library) {
+  const u64 L = (u64)read_len, N = nrecords;
+  if (!library) return names_bytes - N + N * (2 * L + 6);  // names_bytes = sum of (1 + n)
+  u64 digits = N, p = 10;  // digits of 0 .. N-1
+  for (int t = 2; t <= 20 && N > p; t++, p *= 10) digits += N - p;
+  return N * (strlen(library) + 2 * L + 7) + digits;
+}
+
+extern "C" int scalce_fastq_records(scalce_ctx *c, int read_len, int has_buckets, const uint8_t *reads_host, uint64_t reads_bytes,
+                                    uint64_t nrecords, const uint8_t *d_qual, int64_t phred_offset, const uint8_t *names_host,
+                                    uint64_t names_bytes, const char *library, int mate_digit, uint8_t *d_out, uint64_t out_cap,
+                                    uint64_t *out_bytes, uint64_t *record_offsets_host, void *stream) {
+  if (!c || read_len <= 0 || !reads_host || (!names_host && !library) || !d_out || (nrecords && !d_qual)) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const u32 L = (u32)read_len;
+  const u32 sz_meta = has_buckets ? (L > 255 ? 2u : 1u) : 0u;
+  // 1. the bucket directory (decompress.cpp:262-270): headers sit between the buckets' records, so the walk is serial
+  std::vector<FqBucket> dir;
+  if (has_buckets) {
+    u64 pos = 0, k = 0;
+    while (pos + 12 <= reads_bytes) {
+      int32_t core;
+      u64 cnt;
+      memcpy(&core, reads_host + pos, 4);
+      memcpy(&cnt, reads_host + pos + 4, 8);
+      pos += 12;
+      FqBucket b;
+      memset(&b, 0, sizeof b);
+      if (core != SCALCE_ROOT_CORE) {
+        if (core < 0 || core >= (int)c->A.patterns.size()) {
+          set_err(c, "(ERROR) archive refers to core %d which the core table does not have", core);
+          return SCALCE_ERR_FORMAT;
+        }
+        const std::string &cs = c->A.patterns[core];
+        if (cs.size() > sizeof b.core || cs.size() > L) { set_err(c, "(ERROR) core %d does not fit the reads", core); return SCALCE_ERR_FORMAT; }
+        b.core_len = (u32)cs.size();
+        memcpy(b.core, cs.data(), cs.size());
+      }
+      b.first = k;
+      b.off = pos;
+      b.rec_bytes = (L - b.core_len + 3) / 4 + sz_meta;
+      if (cnt > (reads_bytes - pos) / b.rec_bytes) { set_err(c, "(ERROR) truncated read stream"); return SCALCE_ERR_FORMAT; }
+      pos += cnt * b.rec_bytes;
+      k += cnt;
+      if (cnt) dir.push_back(b);
+    }
+    if (k != nrecords) {
+      set_err(c, "(ERROR) the read stream holds %llu records, the quality stream %llu", (unsigned long long)k, (unsigned long long)nrecords);
+      return SCALCE_ERR_FORMAT;
+    }
+  } else {
+    FqBucket b;
+    memset(&b, 0, sizeof b);
+    b.rec_bytes = (L + 3) / 4;
+    if (nrecords > reads_bytes / b.rec_bytes) { set_err(c, "(ERROR) truncated read stream"); return SCALCE_ERR_FORMAT; }
+    dir.push_back(b);
+  }
+  // 2. where every name starts (each length byte says where the next one is: serial as well)
+  std::vector<u64> name_off;
+  if (names_host) {
+    name_off.resize(nrecords + 1);
+    u64 pos = 0;
+    for (u64 k = 0; k < nrecords; k++) {
+      if (pos >= names_bytes) { set_err(c, "(ERROR) truncated name stream"); return SCALCE_ERR_FORMAT; }
+      name_off[k] = pos;
+      pos += 1 + (u64)names_host[pos];
+    }
+    if (pos > names_bytes) { set_err(c, "(ERROR) truncated name stream"); return SCALCE_ERR_FORMAT; }
+    name_off[nrecords] = pos;
+    names_bytes = pos;
+  }
+  const u64 total = scalce_fastq_text_bytes(read_len, nrecords, names_bytes, names_host ? nullptr : library);
+  if (out_bytes) *out_bytes = total;
+  if (total > out_cap) { set_err(c, "output buffer of %llu bytes, the text needs %llu", (unsigned long long)out_cap, (unsigned long long)total); return SCALCE_ERR_CAPACITY; }
+  if (!nrecords) return SCALCE_OK;
+  FqArgs a;
+  memset(&a, 0, sizeof a);
+  u8 *d_reads = nullptr, *d_names = nullptr;
+  FqBucket *d_dir = nullptr;
+  u64 *d_noff = nullptr, *d_roff = nullptr;
+  auto release = [&]() { hipFree(d_reads); hipFree(d_names); hipFree(d_dir); hipFree(d_noff); hipFree(d_roff); };
+#define FQ_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { release(); set_err(c, "%s failed: %s", #expr, hipGetErrorString(e_)); return SCALCE_ERR_HIP; } } while (0)
+  FQ_TRY(hipMalloc(&d_reads, reads_bytes + 64));
+  FQ_TRY(hipMalloc(&d_dir, sizeof(FqBucket) * dir.size()));
+  FQ_TRY(hipMemcpyAsync(d_reads, reads_host, reads_bytes, hipMemcpyHostToDevice, s));
+  FQ_TRY(hipMemcpyAsync(d_dir, dir.data(), sizeof(FqBucket) * dir.size(), hipMemcpyHostToDevice, s));
+  if (names_host) {
+    FQ_TRY(hipMalloc(&d_names, names_bytes + 64));
+    FQ_TRY(hipMalloc(&d_noff, sizeof(u64) * (nrecords + 1)));
+    FQ_TRY(hipMemcpyAsync(d_names, names_host, names_bytes, hipMemcpyHostToDevice, s));
+    FQ_TRY(hipMemcpyAsync(d_noff, name_off.data(), sizeof(u64) * (nrecords + 1), hipMemcpyHostToDevice, s));
+  } else {
+    a.lib_len = (u32)std::min<size_t>(strlen(library), sizeof a.lib - 1);
+    if (strlen(library) >= sizeof a.lib) { release(); set_err(c, "library name longer than %zu characters", sizeof a.lib - 1); return SCALCE_ERR_ARG; }
+    memcpy(a.lib, library, a.lib_len);
+  }
+  if (record_offsets_host) FQ_TRY(hipMalloc(&d_roff, sizeof(u64) * (nrecords + 1)));
+  a.reads = d_reads; a.dir = d_dir; a.nbuckets = (u32)dir.size(); a.nrecords = nrecords; a.L = L; a.sz_meta = sz_meta;
+  a.qual = d_qual; a.phred = (u32)phred_offset; a.names = d_names; a.name_off = d_noff;
+  a.mate_digit = (u32)mate_digit; a.out = d_out; a.rec_off = d_roff;
+  const u64 waves = (nrecords + FQ_RECORDS_PER_WAVE - 1) / FQ_RECORDS_PER_WAVE;
+  LAUNCH(fastq_records_k, cdiv(waves, 4), 256, 0, s, a);
+  if (record_offsets_host)
+    FQ_TRY(hipMemcpyAsync(record_offsets_host, d_roff, sizeof(u64) * (nrecords + 1), hipMemcpyDeviceToHost, s));
+  FQ_TRY(hipStreamSynchronize(s));
+  FQ_TRY(hipGetLastError());
+#undef FQ_TRY
+  release();
   return SCALCE_OK;
 }

@@ -107,6 +107,10 @@ def lib():
                                                 C.POINTER(C.c_int32)]
     L.scalce_selftest_ac.argtypes = [vp, u64, C.c_uint32, i32, C.POINTER(C.c_uint32)]
     L.scalce_ac_decode.argtypes = [vp, vp, vp, u64, u64, vp, vp]
+    L.scalce_fastq_text_bytes.restype = u64
+    L.scalce_fastq_text_bytes.argtypes = [i32, u64, u64, C.c_char_p]
+    L.scalce_fastq_records.argtypes = [vp, i32, i32, vp, u64, u64, vp, C.c_int64, vp, u64, C.c_char_p, i32, vp, u64,
+                                       C.POINTER(u64), vp, vp]
     _LIB = L
     return L
 
@@ -178,6 +182,22 @@ class Context:
 
     def copy_d2d(self, dst, src, nbytes, stream=0):
         self._check(self.L.scalce_memcpy_d2d(self.h, dst, src, int(nbytes), stream))
+
+    def fastq_records(self, read_len, reads_payload, nrecords, d_qual, phred, names_payload=None, library=None, has_buckets=True,
+                      mate_digit=0, stream=0):
+        """Records back to FASTQ text on the device (scalce_fastq_records); returns the text as bytes."""
+        import torch
+        reads = np.frombuffer(reads_payload, dtype=np.uint8)
+        names = None if names_payload is None else np.frombuffer(names_payload, dtype=np.uint8)
+        lib = None if library is None else library.encode()
+        cap = self.L.scalce_fastq_text_bytes(read_len, nrecords, 0 if names is None else len(names), None if names is not None else lib)
+        out = torch.empty(cap + 64, dtype=torch.uint8, device=f"cuda:{self.device}")
+        nb = C.c_uint64(0)
+        self._check(self.L.scalce_fastq_records(self.h, read_len, int(has_buckets), reads.ctypes.data, len(reads), nrecords, d_qual,
+                                                int(phred), None if names is None else names.ctypes.data,
+                                                0 if names is None else len(names), lib or b"", mate_digit, out.data_ptr(), cap,
+                                                C.byref(nb), None, stream))
+        return out[: nb.value].cpu().numpy().tobytes()
 
     def ac_decode(self, table_u32, d_blocks, nbytes, nsym, d_out, stream=0):
         t = np.ascontiguousarray(table_u32, dtype=np.uint32)

@@ -62,3 +62,40 @@ def test_cli_errors_like_the_reference(tmp_path):
     r = subprocess.run([CLI, "-o", str(tmp_path / "o"), str(tmp_path / "bad_1.fq"), "--patterns-bin", PBIN],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "(ERROR)" in r.stderr
+
+
+def test_cli_split_output_and_device_records(tmp_path):
+    """-S: the device-built text is cut at record boundaries (decompress.cpp:276-287); and the C entry behind the CLI's
+    decompressor, scalce_fastq_records, rebuilds the oracle's FASTQ from the archive streams when called directly."""
+    import numpy as np
+    import struct
+    import torch
+    from scalce_amd import host
+    n, L = 5000, 100
+    synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=41, n_frac=0.004, dup_frac=0.1)
+    run_cli("-c", "no", "-o", tmp_path / "a", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    run_cli("-d", "-o", tmp_path / "whole", tmp_path / "a_1.scalcen", "--patterns-bin", PBIN)
+    run_cli("-d", "-S", "1500", "-o", tmp_path / "part", tmp_path / "a_1.scalcen", "--patterns-bin", PBIN)
+    whole = open(tmp_path / "whole_1.fastq", "rb").read()
+    parts = [open(tmp_path / f"part.{k}_1.fastq", "rb").read() for k in (1, 2, 3, 4)]
+    assert [p.count(b"\n") // 4 for p in parts] == [1500, 1500, 1500, 500]
+    assert b"".join(parts) == whole
+    O.orc_cli("decompress", PBIN, tmp_path / "a_1.scalcen", tmp_path / "oback")
+    assert whole == open(tmp_path / "oback_1.fastq", "rb").read()
+    # the C entry directly: streams of the archive in, text out
+    ctx = host.Context(0, patterns_bin=open(PBIN, "rb").read())
+    r = open(tmp_path / "a_1.scalcer", "rb").read()
+    q = open(tmp_path / "a_1.scalceq", "rb").read()
+    nm = open(tmp_path / "a_1.scalcen", "rb").read()
+    assert r[:8] == b"scalce22" and struct.unpack("<ii", r[8:16]) == (0, L)
+    phred = struct.unpack("<q", q[8:16])[0]
+    table = np.frombuffer(q[16:16 + 2048000], dtype=np.uint32)
+    total = struct.unpack("<Q", q[16 + 2048000:24 + 2048000])[0]
+    blocks = torch.frombuffer(bytearray(q[24 + 2048000:]), dtype=torch.uint8).to("cuda:0")
+    sym = torch.zeros(total, dtype=torch.uint8, device="cuda:0")
+    ctx.ac_decode(table, blocks.data_ptr(), blocks.numel(), total, sym.data_ptr())
+    text = ctx.fastq_records(L, r[16:], total // L, sym.data_ptr(), phred, names_payload=nm[9:])
+    assert text == whole
+    lib = ctx.fastq_records(L, r[16:], total // L, sym.data_ptr(), phred, library="run7")
+    recs = lib.split(b"\n")
+    assert recs[0] == b"@run7.0" and recs[4 * 4999] == b"@run7.4999" and recs[1] == whole.split(b"\n")[1]
