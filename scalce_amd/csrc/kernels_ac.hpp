@@ -1063,7 +1063,7 @@ struct AcBitReader {
     const u32 w = __builtin_amdgcn_readlane(wcur, wi);
     win |= (u64)w << (32 - wb);
     wb += 32;
-    if (++wi == 64) {
+    if (__builtin_expect(++wi == 64, 0)) {
       wi = 0;
       base += 256;
       wcur = wnext;
@@ -1077,7 +1077,35 @@ struct AcBitReader {
     if (wb <= 32) refill(lane);
     return r;
   }
+  __device__ __forceinline__ u32 get0(u32 cnt, int lane) {  // cnt in 0..32
+    const u32 r = (u32)((win >> 1) >> (63 - cnt));
+    win <<= cnt;
+    wb -= cnt;
+    if (__builtin_expect(wb <= 32, 0)) refill(lane);
+    return r;
+  }
 };
+// Renormalisation of the decoder (arithmetic.cpp:225-239) without its loop and without a branch in the usual case:
+// k agreed leading bits leave, then u underflow steps; lo, hi and the code register move by k + u bits at once.
+__device__ __forceinline__ void ac_dec_renorm(u32 &lo, u32 &hi, u32 &code, u32 nlo, u32 nhi, AcBitReader &br, int lane) {
+  const u32 x = nlo ^ nhi;
+  const u32 k = x ? (u32)__clz(x) : 32u;
+  const u32 l1 = (u32)((u64)nlo << k);
+  const u32 h1 = (u32)(((u64)nhi << k) | ((1ull << k) - 1));
+  const u32 y = (l1 & ~h1) << 1;
+  const u32 u = (u32)__clz(~y);  // positions from bit 30 down where lo has 1 and hi has 0; bit 0 of ~y is set
+  const u32 t = k + u;
+  const u32 top = u ? 0x80000000u : 0u;
+  lo = (u32)((u64)l1 << u) & ~top;
+  hi = (u32)(((u64)h1 << u) | ((1ull << u) - 1)) | top;
+  if (__builtin_expect(t <= 32, 1)) {
+    const u32 bits = br.get0(t, lane);
+    code = ((u32)((u64)code << t) | bits) ^ top;  // u steps of code = ((code ^ 0x40000000) << 1) | bit flip what ends up in bit 31
+  } else {  // more than 32 bits at once: rare
+    code = (u32)((u64)code << k) | br.get(k, lane);
+    code = ((code << u) ^ 0x80000000u) | br.get(u, lane);
+  }
+}
 struct AcDecArgs {
   const u8 *in;          // framed stream
   const u64 *blk_off;    // byte offset of each block's payload (after its size word)
@@ -1128,22 +1156,7 @@ __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
       is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
       B = t ? __builtin_amdgcn_readlane(U1, t - 1) : __builtin_amdgcn_readlane(U0, 63);
     }
-    const u32 nhi = is_last ? hi : lo + A - 1;
-    const u32 nlo = lo + B;
-    // renormalisation exactly as the encoder's general closed form; the code register follows (:225-239)
-    const u32 x = nlo ^ nhi;
-    const u32 k = x ? (u32)__clz(x) : 32u;
-    u32 l1, h1;
-    if (k == 32) { l1 = 0; h1 = 0xFFFFFFFFu; code = getbits(32); }
-    else if (k) { l1 = nlo << k; h1 = (nhi << k) | ((1u << k) - 1); code = (code << k) | getbits(k); }
-    else { l1 = nlo; h1 = nhi; }
-    const u32 y = (l1 & ~h1) << 1;
-    const u32 u = (u32)__clz(~y);
-    if (u) {
-      lo = (l1 << u) & 0x7FFFFFFFu;
-      hi = (h1 << u) | ((1u << u) - 1) | 0x80000000u;
-      code = ((code << u) ^ 0x80000000u) | getbits(u);  // u steps of code = ((code ^ 0x40000000) << 1) | bit
-    } else { lo = l1; hi = h1; }
+    ac_dec_renorm(lo, hi, code, lo + B, is_last ? hi : lo + A - 1, br, lane);
     outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
     if ((i & 63) == 63) out[(i & ~63u) + lane] = (u8)outacc;  // 64 symbols per store
     p0 = p1;
@@ -1203,12 +1216,13 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_cached_k(AcDecCachedArgs a
   if (p1 >= AC_D) p1 = AC_D - 1;
   const u32 rk0 = a.rank[lane], rk1 = lane < 16 ? a.rank[64 + lane] : 0xFFu;
   auto rank_of = [&](u32 sy) -> u32 {  // sy wave-uniform
-    return sy < 64 ? __builtin_amdgcn_readlane(rk0, sy) : __builtin_amdgcn_readlane(rk1, sy - 64);
+    const u32 x0 = __builtin_amdgcn_readlane(rk0, sy & 63), x1 = __builtin_amdgcn_readlane(rk1, sy & 15);
+    return sy < 64 ? x0 : x1;
   };
   auto fetch = [&](u32 c0, u32 c1, u32 q0, u32 q1) -> uint2 {
     uint2 e = make_uint2(0, 0);
     if ((u32)lane < S1) {
-      if (q0 < W && q1 < W) e = cache[(q0 * W + q1) * S1 + lane];
+      if (__builtin_expect(q0 < W && q1 < W, 1)) e = cache[(q0 * W + q1) * S1 + lane];
       else e = a.rows[(u64)(c0 * AC_D + c1) * S1 + lane];
     }
     return e;
@@ -1219,16 +1233,16 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_cached_k(AcDecCachedArgs a
   u32 lo = 0, hi = 0xFFFFFFFFu, code = getbits(32);
   u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
   u32 r0 = rank_of(p0), r1 = rank_of(p1);
-  uint2 e = fetch(p0, p1, r0, r1);
+  uint2 e = fetch(p0, p1, r0, r1);  // zeros in the lanes beyond S1: their bound is 0, never above the code value
   for (u32 i = 2; i < n; i++) {
     const u32 R = hi - lo, v = code - lo;
-    const bool last = (e.x & e.y) == 0xFFFFFFFFu;  // g(hi) = 2^64 - 1 marks the context's last symbol
-    const u32 U = mulfrac(R, e.x, e.y);
-    const u64 m = __ballot((u32)lane < S1 && (last || v < U));
+    const u64 lastm = __ballot((e.x & e.y) == 0xFFFFFFFFu);  // g(hi) = 2^64 - 1 marks the context's last symbol
+    const u32 U = mulfrac_m(R + 1, R == 0xFFFFFFFFu, e.x, e.y);
+    const u64 m = __ballot(v < U) | lastm;
     const u32 j = m ? (u32)__ffsll((long long)m) - 1 : S1;
     u32 sidx, A, B;
     bool is_last;
-    if (j == 0 || j >= S1) {
+    if (__builtin_expect(j == 0 || j >= S1, 0)) {
       // below or above the symbols the compact rows hold: the full row, as ac_decode_k
       const uint4 *row = a.d.tab + (u64)(p0 * AC_D + p1) * AC_D;
       const uint4 f0 = row[lane];
@@ -1253,7 +1267,7 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_cached_k(AcDecCachedArgs a
       sidx = a.smin - 1 + j;
       A = __builtin_amdgcn_readlane(U, j);
       B = __builtin_amdgcn_readlane(U, j - 1);
-      is_last = __builtin_amdgcn_readlane((u32)last, j) != 0;
+      is_last = ((lastm >> j) & 1) != 0;
     }
     // the next context is known: ask for its row before anything else
     p0 = p1;
@@ -1261,23 +1275,9 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_cached_k(AcDecCachedArgs a
     r0 = r1;
     r1 = rank_of(sidx);
     const uint2 e_next = fetch(p0, p1, r0, r1);
-    const u32 nhi = is_last ? hi : lo + A - 1;
-    const u32 nlo = lo + B;
-    const u32 x = nlo ^ nhi;
-    const u32 k = x ? (u32)__clz(x) : 32u;
-    u32 l1, h1;
-    if (k == 32) { l1 = 0; h1 = 0xFFFFFFFFu; code = getbits(32); }
-    else if (k) { l1 = nlo << k; h1 = (nhi << k) | ((1u << k) - 1); code = (code << k) | getbits(k); }
-    else { l1 = nlo; h1 = nhi; }
-    const u32 y = (l1 & ~h1) << 1;
-    const u32 u = (u32)__clz(~y);
-    if (u) {
-      lo = (l1 << u) & 0x7FFFFFFFu;
-      hi = (h1 << u) | ((1u << u) - 1) | 0x80000000u;
-      code = ((code << u) ^ 0x80000000u) | getbits(u);
-    } else { lo = l1; hi = h1; }
+    ac_dec_renorm(lo, hi, code, lo + B, is_last ? hi : lo + A - 1, br, lane);
     outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
-    if ((i & 63) == 63) out[(i & ~63u) + lane] = (u8)outacc;
+    if (__builtin_expect((i & 63) == 63, 0)) out[(i & ~63u) + lane] = (u8)outacc;
     e = e_next;
   }
   const u32 done = n & ~63u;
