@@ -210,6 +210,8 @@ __device__ __forceinline__ u32 ac_step_plain(u32 &lo, u32 &M, const uint4 g, u32
 struct SysState {
   u32 kM[4], nl[4];  // per lane: range received / lo + B computed in the lane's own step (set = lane & 3)
   u32 ones;          // 0xFFFFFFFF
+  u32 zero;          // 0, just as opaque: a literal 0 as the high word of B's addend is re-created in the result's
+                     // register pair before every multiply-add (one v_mov per step)
 };
 // Renormalisation count without the (k, u) pair.  The loop of arithmetic.cpp:133-152 drops t = k + u leading bits,
 // and t is the largest number of halvings after which [nlo, nhi] still lies inside ONE window of the form
@@ -234,7 +236,7 @@ __device__ __forceinline__ void sys_step(SysState &st, u32 &tlo, u32 &tM, const 
   // A - 1 comes for free: the high word of the 64-bit addend is 2^32 - 1 (st.ones: opaque to the compiler, which
   // would otherwise pull the constant out of the multiply-add and spend an instruction on it)
   const u32 A1 = (u32)(((u64)M * ops.w + (((u64)st.ones << 32) | __umulhi(M, ops.z))) >> 32);
-  const u32 B = (u32)(((u64)M * ops.y + __umulhi(M, ops.x)) >> 32);
+  const u32 B = (u32)(((u64)M * ops.y + (((u64)st.zero << 32) | __umulhi(M, ops.x))) >> 32);
   const u32 D = A1 - B;  // new range - 1 = nhi - nlo
   // nl = lo(from lane l-1) + B in one instruction; tlo was written many instructions ago (DPP read hazard)
   asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:%3 bank_mask:%4"
@@ -263,6 +265,7 @@ __device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const ui
   // step 0: every lane starts from the round's state (lane 0 is the one that matters); the state after the round is
   // what lane 63 leaves in (tlo, tM)
   asm("v_mov_b32 %0, -1" : "=v"(st.ones));
+    asm("v_mov_b32 %0, 0" : "=v"(st.zero));
   {
     st.kM[0] = M0;
     st.kM[1] = st.kM[2] = st.kM[3] = 0;
@@ -688,23 +691,24 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
 //   R = 16: DPP row_ror:1 in every step -- lane 0 of a row takes what lane 15 left, rounds follow each other without
 //           any hand-over.  Per 64 symbols of four blocks the chain wave spends ~5000 cycles instead of 4 x 4400:
 //           0.57 x the SIMD time per block at 1.13 x its latency.
-//   R = 8:  no DPP mode rotates inside 8 lanes, so a round starts with one row_ror:9 of the state (lane 0 <- lane 7,
-//           lane 8 <- lane 15), step 0 reads its own lane, steps 1..7 shift by one.  ~0.35 x the SIMD time per block.
+//   R = 8:  no DPP mode rotates inside 8 lanes: step 0 of a round reads the state through row_ror:9 (lane 0 <- lane 7,
+//           lane 8 <- lane 15: the last lane of the group, where the previous round left it), steps 1..7 through
+//           row_shr:1.  ~0.35 x the SIMD time per block.
 template <int R, int S>
 __device__ __forceinline__ void sys_step_rows(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
   constexpr int Q = S & 3;
   // write enable: the quad of lane S of every group (R = 8: two groups per 16-lane row)
   constexpr int BM = R == 16 ? (1 << (S >> 2)) : ((1 << (S >> 2)) | (1 << ((S >> 2) + 2)));
-  constexpr int CTRL = R == 16 ? 0x121 /* row_ror:1 */ : (S == 0 ? 0xE4 /* quad_perm:[0,1,2,3] */ : 0x111 /* row_shr:1 */);
+  constexpr int CTRL = R == 16 ? 0x121 /* row_ror:1 */ : (S == 0 ? 0x129 /* row_ror:9 */ : 0x111 /* row_shr:1 */);
   st.kM[Q] = __builtin_amdgcn_update_dpp(st.kM[Q], tM, CTRL, 0xF, BM, false);
   const u32 M = st.kM[Q];
   const u32 A1 = (u32)(((u64)M * ops.w + (((u64)st.ones << 32) | __umulhi(M, ops.z))) >> 32);
-  const u32 B = (u32)(((u64)M * ops.y + __umulhi(M, ops.x)) >> 32);
+  const u32 B = (u32)(((u64)M * ops.y + (((u64)st.zero << 32) | __umulhi(M, ops.x))) >> 32);
   const u32 D = A1 - B;
   if constexpr (R == 16)
     asm("v_add_u32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
   else if constexpr (S == 0)
-    asm("v_add_u32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
+    asm("v_add_u32_dpp %0, %1, %2 row_ror:9 row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
   else
     asm("v_add_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:%3" : "+v"(st.nl[Q]) : "v"(tlo), "v"(B), "n"(BM));
   __builtin_amdgcn_sched_barrier(0);
@@ -727,10 +731,6 @@ struct SysLoopRows<R, E, E> {
 // one round of R symbols for every group of the wave
 template <int R>
 __device__ __forceinline__ void sys_round_rows(SysState &st, u32 &tlo, u32 &tM, const uint4 &ops) {
-  if constexpr (R == 8) {  // the state of a group sits in its last lane: bring it to its first one
-    tlo = __builtin_amdgcn_update_dpp(tlo, tlo, 0x129 /* row_ror:9 */, 0xF, 0xF, false);
-    tM = __builtin_amdgcn_update_dpp(tM, tM, 0x129, 0xF, 0xF, false);
-  }
   SysLoopRows<R, 0, R>::run(st, tlo, tM, ops);
 }
 
@@ -914,6 +914,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     const u32 nsr_row = (n_row + 63) >> 6;
     SysState st;
     asm("v_mov_b32 %0, -1" : "=v"(st.ones));
+    asm("v_mov_b32 %0, 0" : "=v"(st.zero));
     st.kM[0] = st.kM[1] = st.kM[2] = st.kM[3] = 0;
     st.nl[0] = st.nl[1] = st.nl[2] = st.nl[3] = 0;
     // the travelling state; between rounds the one that matters sits in the last lane of the group.  M = 0 stands for 2^32.

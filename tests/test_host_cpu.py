@@ -152,3 +152,19 @@ def test_renorm_count_formula_matches_the_literal_loop():
         assert t == k + u or full, (hex(a), hex(b), k, u, t)
         checked += 1
     assert checked > 50000
+
+
+def test_fastq_text_bytes_matches_the_text_it_sizes():
+    """scalce_fastq_text_bytes sizes the device buffer scalce_fastq_records fills: with names it is the name stream
+    minus the length bytes plus 2L + 6 per record ('@', two newlines around the bases, "+\\n", the final newline); in
+    library mode the decimal index of every record is counted in closed form (decompress.cpp:290-304)."""
+    L = host.lib()
+    rng = np.random.default_rng(5)
+    for n, rl in ((0, 100), (1, 36), (9, 100), (10, 100), (11, 75), (1234, 151), (100001, 50)):
+        lens = rng.integers(1, 40, size=n)
+        names_bytes = int((lens + 1).sum())
+        want = sum(1 + int(k) + 1 + rl + 3 + rl + 1 for k in lens)
+        assert L.scalce_fastq_text_bytes(rl, n, names_bytes, None) == want
+        lib = b"run_7"
+        want = sum(len(b"@%s.%d\n" % (lib, i)) + rl + 3 + rl + 1 for i in range(n))
+        assert L.scalce_fastq_text_bytes(rl, n, 0, lib) == want
