@@ -99,3 +99,18 @@ def test_cli_split_output_and_device_records(tmp_path):
     lib = ctx.fastq_records(L, r[16:], total // L, sym.data_ptr(), phred, library="run7")
     recs = lib.split(b"\n")
     assert recs[0] == b"@run7.0" and recs[4 * 4999] == b"@run7.4999" and recs[1] == whole.split(b"\n")[1]
+
+
+def test_cli_decompress_rejects_truncated_streams(tmp_path):
+    """A cut read or name stream ends the reference with '(ERROR) ...' and exit(1) (const.h:77-81); the device path keeps
+    that contract -- the directory and name walks on the host see the cut before any kernel runs."""
+    n, L = 2000, 100
+    synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=43)
+    run_cli("-c", "no", "-o", tmp_path / "a", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    for ext, cut in (("r", 11), ("n", 7)):
+        for e in "nrq":
+            data = open(tmp_path / f"a_1.scalce{e}", "rb").read()
+            open(tmp_path / f"bad_1.scalce{e}", "wb").write(data[:-cut] if e == ext else data)
+        r = subprocess.run([CLI, "-d", "-o", str(tmp_path / "x"), str(tmp_path / "bad_1.scalcen"), "--patterns-bin", PBIN],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "(ERROR)" in r.stderr and "truncated" in r.stderr, (ext, r.stderr[-300:])
