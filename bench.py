@@ -72,17 +72,30 @@ def main():
     from scalce_amd import format as fmt
     off, vals, Ls = fmt.sample_qmap(head)
     assert Ls == L
-    # shards per coder launch / shards in flight.  One GPU: 3 / 6 (199 GB of the 288 GB HBM at 50 M reads per shard).  A
+    # shards per coder launch / shards in flight: 3 / 6 (199 GB of the 288 GB HBM at 50 M reads per shard on one GPU).  A
     # sharded run also holds every in-flight shard's block range of the run-wide quality stream and the all-to-all
-    # buffers (measured with the 2-rank rehearsal: ~1.7 GB per million reads of a shard on top), so it keeps 2 / 4.
-    G = max(1, args.group if args.group is not None else (3 if world == 1 else 2))
+    # buffers.  Measured with the 2-rank rehearsal (tools/mem_probe.sh; 20 M and 28 M reads, 4 and 6 in flight), per rank:
+    # 8 GB + 0.4 GB per million reads + 0.73 GB per million reads and shard in flight (x L / 100) = 246 GB at 50 M reads
+    # and six in flight.  A rank keeps 3 / 6 when that estimate plus a margin fits what is free now, else 2 / 4 (174 GB).
+    comm = sdist.TorchComm() if world > 1 else None
+
+    def sharded_need_gb(inflight):
+        nm = n / 1e6 * L / 100.0
+        return 8 + 0.4 * nm + 0.7275 * nm * inflight
+    G = args.group
+    if G is None:
+        G = 3
+        if world > 1:
+            free_gb = torch.cuda.mem_get_info()[0] / 1e9 + nbytes / 1e9  # the shard's text is already there
+            fits = sharded_need_gb(6) * 1.06 + 8 <= free_gb
+            G = 3 if comm.all_reduce_max(0 if fits else 1) == 0 else 2  # every rank takes the same decision
+    G = max(1, G)
     D = max(1, args.inflight) if args.inflight is not None else 2 * G
     if G > 1:
         D = max(D, 2 * G)
     batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)]) for _ in range(D)]
     batch = batches[0]
     state = {}
-    comm = sdist.TorchComm() if world > 1 else None
 
     def barrier():
         torch.cuda.synchronize()
