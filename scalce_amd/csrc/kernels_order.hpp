@@ -63,6 +63,26 @@ __global__ __launch_bounds__(256) void run_heads_k(RunArgs a, u8 *head) {
   if (i >= a.n) return;
   head[i] = (i == 0) ? 1 : (same_phase1_key(a, a.perm[i - 1], a.perm[i]) ? 0 : 1);
 }
+// Phase 1 on (key, read) pairs: the key is what phase 1 sorts by, most significant first --
+// bucket | chunk | first PREFIX_DIGITS digits -- built once from the rows in input order (sequential reads)
+__global__ __launch_bounds__(256) void order_keys_k(u32 n, const u32 *bucket, const u32 *chunk /* or null */, u32 chunk_bits,
+                                                   const u8 *packed, const u16 *end, int L, int stride, int ndig1, u64 *keys) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 prefix = 0;
+  for (int d = 0; d < PREFIX_DIGITS; d++) {
+    KeyDigit kd{packed, end, L, stride, d};
+    prefix = (prefix << 8) | (d < ndig1 ? kd(i) : 0u);
+  }
+  u64 hi = bucket[i];
+  if (chunk) hi = (hi << chunk_bits) | chunk[i];
+  keys[i] = (hi << 32) | prefix;
+}
+__global__ __launch_bounds__(256) void run_heads_keys_k(u32 n, const u64 *sorted_keys, u8 *head) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  head[i] = (i == 0 || sorted_keys[i] != sorted_keys[i - 1]) ? 1 : 0;
+}
 struct RunMember {  // position i belongs to a run of length > 1
   const u8 *head;
   u32 n;

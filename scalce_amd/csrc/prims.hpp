@@ -221,6 +221,88 @@ inline void radix_pass(const u32 *in, u32 *out, u32 n, D digit, u32 *hist_ws, u3
   hipLaunchKernelGGL((radix_scatter_k<D>), dim3(ntiles), dim3(RS_THREADS), 0, st, in, out, n, digit, hist_ws, ntiles);
 }
 
+// ---------------------------------------------------------------------------------------------
+// the same pass over (64-bit key, u32 payload) pairs: the digit is byte `shift / 8` of the key that
+// travels with the payload, so every read is sequential (radix_pass's functor gathers through the
+// payload: 8 GB of sector fetches per pass for 50 M two-byte digits)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_key_k(const u64 *keys, u32 n, u32 shift, u32 *hist, u32 ntiles) {
+  __shared__ u32 h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 base = blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; i++) {
+    const u32 idx = base + i * RS_THREADS + threadIdx.x;
+    if (idx < n) atomicAdd(&h[(u32)(keys[idx] >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  hist[(u64)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_k(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out,
+                                                                u32 n, u32 shift, const u32 *offs, u32 ntiles) {
+  __shared__ u32 wh[4][256];
+  for (int i = threadIdx.x; i < 4 * 256; i += RS_THREADS) (&wh[0][0])[i] = 0;
+  __syncthreads();
+  const int w = wave_id(), lane = lane_id();
+  const u64 lt = (1ull << lane) - 1;
+  const u32 base = blockIdx.x * RS_TILE + w * (64 * RS_ITEMS);
+  u64 key[RS_ITEMS];
+  u32 val[RS_ITEMS], pos[RS_ITEMS];
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++) {
+    const u32 idx = base + r * 64 + lane;
+    const bool valid = idx < n;
+    key[r] = valid ? keys_in[idx] : 0ull;
+    val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
+    const u32 d = (u32)(key[r] >> shift) & 0xFFu;
+    u64 peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1;
+      const u64 bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const u32 rank = __popcll(peers & lt);
+    u32 pre = 0;
+    if (valid && rank == 0) {
+      pre = wh[w][d];
+      wh[w][d] = pre + (u32)__popcll(peers);
+    }
+    const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+    pre = __shfl(pre, leader, 64);
+    pos[r] = valid ? ((d << 16) | (pre + rank)) : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  {
+    const u32 d = threadIdx.x;
+    const u32 c0 = wh[0][d], c1 = wh[1][d], c2 = wh[2][d];
+    const u32 g = offs[(u64)d * ntiles + blockIdx.x];
+    wh[0][d] = g;
+    wh[1][d] = g + c0;
+    wh[2][d] = g + c0 + c1;
+    wh[3][d] = g + c0 + c1 + c2;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_ITEMS; r++)
+    if (pos[r] != 0xFFFFFFFFu) {
+      const u32 at = wh[w][pos[r] >> 16] + (pos[r] & 0xFFFFu);
+      keys_out[at] = key[r];
+      vals_out[at] = val[r];
+    }
+}
+// vals_in == nullptr means the identity permutation
+inline void radix_pass_kv(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out, u32 n, u32 shift, u32 *hist_ws,
+                          u32 *tile_ws, hipStream_t st) {
+  if (!n) return;
+  const u32 ntiles = (n + RS_TILE - 1) / RS_TILE;
+  hipLaunchKernelGGL(radix_hist_key_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
+  exclusive_scan<u32>(LoadAs<u32, u32>{hist_ws}, (u64)256 * ntiles, StoreTo<u32>{hist_ws}, tile_ws, (u32 *)nullptr, st);
+  hipLaunchKernelGGL(radix_scatter_kv_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+                     hist_ws, ntiles);
+}
+
 inline u64 scan_ws_elems(u64 n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 1; }
 inline u64 radix_hist_elems(u64 n) { return 256 * ((n + RS_TILE - 1) / RS_TILE) + 256; }
 

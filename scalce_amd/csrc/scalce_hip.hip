@@ -186,7 +186,7 @@ struct scalce_batch {
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
-  DBuf perm_a, perm_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
+  DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, name_off, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
   std::vector<AcBlockDesc> ac_desc_host;  // block descriptors of the last coder launch this shard led
@@ -238,7 +238,7 @@ static void free_all(scalce_batch *b) {
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
                  &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
                  &b->chosen, &b->G, &b->seg, &b->dirty, &b->cand_place, &b->Gseg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
-                 &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->hist, &b->scan_ws, &b->S, &b->run_head, &b->run_hcount, &b->run_rank, &b->runid,
+                 &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->key_a, &b->key_b, &b->hist, &b->scan_ws, &b->S, &b->run_head, &b->run_hcount, &b->run_rank, &b->runid,
                  &b->run_items_a, &b->run_items_b, &b->run_pos,
                  &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab[0], &b->ac_cum[0],
                  &b->ac_blocks[0], &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1],
@@ -674,23 +674,45 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   const int ndig = (b->L[0] + 3) / 4;
   const bool two_phase = getenv("SCALCE_ORDER_SINGLE_PHASE") == nullptr;  // test hook: all digits in one go
   const int ndig1 = two_phase ? (ndig < PREFIX_DIGITS ? ndig : PREFIX_DIGITS) : ndig;
-  // phase 1: first ndig1 key digits (least significant first), then chunk, then bucket
-  for (int d = ndig1 - 1; d >= 0; d--) {
-    radix_pass(src, dst, (u32)N, KeyDigit{b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], d}, b->hist.as<u32>(),
-               ws32, s);
-    flip();
-  }
   const u32 *chunk_or_null = b->nchunks > 1 ? b->chunk.as<u32>() : nullptr;
-  if (b->nchunks > 1)
-    for (int sh = 0; (1u << sh) < b->nchunks; sh += 8) {
-      radix_pass(src, dst, (u32)N, DigitOfArray{b->chunk.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
-      flip();
-    }
   int bits = 1;
   while ((1u << bits) < nb1 && bits < 31) bits++;
-  for (int sh = 0; sh < bits; sh += 8) {
-    radix_pass(src, dst, (u32)N, DigitOfArray{b->bucket.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
-    flip();
+  int cbits = 0;
+  while (b->nchunks > 1 && (1u << cbits) < b->nchunks) cbits++;
+  // phase 1 on (key, read) pairs when bucket | chunk | 32 prefix bits fit 64 bits (always, short of millions of cores
+  // together with thousands of chunks): every pass then reads and writes sequentially.  The index-only passes below
+  // gather a digit through the index in every pass: 8 GB of sector fetches per pass at 50 M reads, and the scattered
+  // accesses are what slows a coder launch running beside the order stage most (tools/coder_beside.py).
+  const bool by_pairs = two_phase && 32 + cbits + bits <= 64 && !getenv("SCALCE_ORDER_INDEX_ONLY");
+  const u64 *sorted_keys = nullptr;
+  if (by_pairs) {
+    ENSURE(b, b->key_a, sizeof(u64) * (N + 2));
+    ENSURE(b, b->key_b, sizeof(u64) * (N + 2));
+    u64 *ka = b->key_a.as<u64>(), *kb = b->key_b.as<u64>();
+    LAUNCH(order_keys_k, cdiv(N, 256), 256, 0, s, (u32)N, b->bucket.as<u32>(), chunk_or_null, (u32)cbits, b->packed[0].as<u8>(),
+           b->endv.as<u16>(), b->L[0], b->stride[0], ndig1, ka);
+    for (int sh = 0; sh < 32 + cbits + bits; sh += 8) {
+      radix_pass_kv(ka, src, kb, dst, (u32)N, (u32)sh, b->hist.as<u32>(), ws32, s);
+      flip();
+      u64 *t = ka; ka = kb; kb = t;
+    }
+    sorted_keys = ka;
+  } else {
+    // phase 1: first ndig1 key digits (least significant first), then chunk, then bucket
+    for (int d = ndig1 - 1; d >= 0; d--) {
+      radix_pass(src, dst, (u32)N, KeyDigit{b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], d}, b->hist.as<u32>(),
+                 ws32, s);
+      flip();
+    }
+    if (b->nchunks > 1)
+      for (int sh = 0; (1u << sh) < b->nchunks; sh += 8) {
+        radix_pass(src, dst, (u32)N, DigitOfArray{b->chunk.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+        flip();
+      }
+    for (int sh = 0; sh < bits; sh += 8) {
+      radix_pass(src, dst, (u32)N, DigitOfArray{b->bucket.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+      flip();
+    }
   }
   u32 *perm1 = const_cast<u32 *>(src);
   b->order_run_members = 0;
@@ -702,7 +724,8 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
     ENSURE(b, b->runid, sizeof(u32) * (N + 2));
     RunArgs ra{(u32)N, perm1, b->bucket.as<u32>(), chunk_or_null, b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], ndig1};
     u8 *head = b->run_head.as<u8>();
-    LAUNCH(run_heads_k, cdiv(N, 256), 256, 0, s, ra, head);
+    if (sorted_keys) LAUNCH(run_heads_keys_k, cdiv(N, 256), 256, 0, s, (u32)N, sorted_keys, head);
+    else LAUNCH(run_heads_k, cdiv(N, 256), 256, 0, s, ra, head);
     exclusive_scan<u32>(LoadAs<u8, u32>{head}, N, StoreTo<u32>{b->run_hcount.as<u32>()}, ws32, (u32 *)nullptr, s);
     exclusive_scan<u32>(RunMember{head, (u32)N}, N, StoreTo<u32>{b->run_rank.as<u32>()}, ws32, b->d_small + 9, s);
     u32 M = 0;
