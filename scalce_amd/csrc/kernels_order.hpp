@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void run_heads_k(RunArgs a, u8 *head) {
 // Phase 1 on (key, read) pairs: the key is what phase 1 sorts by, most significant first --
 // bucket | chunk | first PREFIX_DIGITS digits -- built once from the rows in input order (sequential reads)
 __global__ __launch_bounds__(256) void order_keys_k(u32 n, const u32 *bucket, const u32 *chunk /* or null */, u32 chunk_bits,
-                                                   const u8 *packed, const u16 *end, int L, int stride, int ndig1, u64 *keys) {
+                                                   const u8 *packed, const u16 *end, int L, int stride, int ndig1, u32 end_bits,
+                                                   u64 *keys) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   u32 prefix = 0;
@@ -76,12 +77,14 @@ __global__ __launch_bounds__(256) void order_keys_k(u32 n, const u32 *bucket, co
   }
   u64 hi = bucket[i];
   if (chunk) hi = (hi << chunk_bits) | chunk[i];
-  keys[i] = (hi << 32) | prefix;
+  // where 16 bits are left below the sorted part, the record's `end` rides along: the emit stage then finds bucket and
+  // end of the k-th record in the k-th key instead of gathering them through the permutation
+  keys[i] = (((hi << 32) | prefix) << end_bits) | (end_bits ? (u64)end[i] : 0ull);
 }
-__global__ __launch_bounds__(256) void run_heads_keys_k(u32 n, const u64 *sorted_keys, u8 *head) {
+__global__ __launch_bounds__(256) void run_heads_keys_k(u32 n, const u64 *sorted_keys, u32 end_bits, u8 *head) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  head[i] = (i == 0 || sorted_keys[i] != sorted_keys[i - 1]) ? 1 : 0;
+  head[i] = (i == 0 || (sorted_keys[i] >> end_bits) != (sorted_keys[i - 1] >> end_bits)) ? 1 : 0;
 }
 struct RunMember {  // position i belongs to a run of length > 1
   const u8 *head;
@@ -101,9 +104,14 @@ __global__ __launch_bounds__(256) void run_compact_k(u32 n, const u8 *head, cons
   pos_list[m] = i;
   runid_of_read[r] = head_count[i] + head[i];  // heads at positions <= i: constant inside a run, increasing across runs
 }
-__global__ __launch_bounds__(256) void run_scatter_k(u32 m, const u32 *sorted, const u32 *pos_list, u32 *perm) {
+__global__ __launch_bounds__(256) void run_scatter_k(u32 m, const u32 *sorted, const u32 *pos_list, u32 *perm, u64 *keys /* or null */,
+                                                    u32 end_bits, const u16 *end) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) perm[pos_list[i]] = sorted[i];
+  if (i >= m) return;
+  const u32 p = pos_list[i], r = sorted[i];
+  perm[p] = r;
+  // the members of a run share the sorted part of the key; the `end` riding below it follows the record
+  if (keys && end_bits) keys[p] = ((keys[p] >> end_bits) << end_bits) | (u64)end[r];
 }
 
 // spill chunks (compress.cpp:702-715): running size of the records since the last dump; when it
@@ -179,14 +187,17 @@ struct EmitArgs {
   const u64 *bucket_off;    // exclusive scan of BucketBytes
   const u64 *counts;
   u8 *out;
+  const u64 *keys;          // sorted phase-1 keys (position k <-> record perm[k]) or null
+  u32 key_bucket_shift, key_bucket_mask, key_end_bits;
 };
 __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
   const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= a.nrec) return;
   const u32 r = a.perm[k];
-  const u32 b = a.bucket[r];
+  const u64 key = a.keys ? a.keys[k] : 0ull;
+  const u32 b = a.keys ? ((u32)(key >> a.key_bucket_shift) & a.key_bucket_mask) : a.bucket[r];
   const int lv = (int)a.bucket_level[b];
-  const int e = a.end[r];
+  const int e = (a.keys && a.key_end_bits) ? (int)(key & 0xFFFFu) : (int)a.end[r];
   const int recsz = ((a.L - lv + 3) >> 2) + a.sz_meta;
   const u64 first = a.bucket_first[b];
   u8 *dst = a.out + a.bucket_off[b];

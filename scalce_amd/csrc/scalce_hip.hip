@@ -186,6 +186,8 @@ struct scalce_batch {
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
+  const u64 *sorted_keys = nullptr;  // phase-1 keys in output order (order stage), consumed by the emit stage
+  u32 key_end_bits = 0, key_bucket_shift = 0, key_bucket_mask = 0;
   DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, name_off, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
@@ -639,6 +641,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   ENSURE(b, b->hist, sizeof(u32) * radix_hist_elems(N));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(radix_hist_elems(N)) + scan_ws_elems(N + 1) + 1024));
   b->perm = b->perm_a.as<u32>();
+  b->sorted_keys = nullptr;
   b->nchunks = 1;
   if (!N) return SCALCE_OK;
   u32 *ws32 = b->scan_ws.as<u32>();
@@ -684,19 +687,24 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   // gather a digit through the index in every pass: 8 GB of sector fetches per pass at 50 M reads, and the scattered
   // accesses are what slows a coder launch running beside the order stage most (tools/coder_beside.py).
   const bool by_pairs = two_phase && 32 + cbits + bits <= 64 && !getenv("SCALCE_ORDER_INDEX_ONLY");
-  const u64 *sorted_keys = nullptr;
+  u64 *sorted_keys = nullptr;
+  const u32 end_bits = (48 + cbits + bits <= 64) ? 16u : 0u;
   if (by_pairs) {
     ENSURE(b, b->key_a, sizeof(u64) * (N + 2));
     ENSURE(b, b->key_b, sizeof(u64) * (N + 2));
     u64 *ka = b->key_a.as<u64>(), *kb = b->key_b.as<u64>();
     LAUNCH(order_keys_k, cdiv(N, 256), 256, 0, s, (u32)N, b->bucket.as<u32>(), chunk_or_null, (u32)cbits, b->packed[0].as<u8>(),
-           b->endv.as<u16>(), b->L[0], b->stride[0], ndig1, ka);
-    for (int sh = 0; sh < 32 + cbits + bits; sh += 8) {
+           b->endv.as<u16>(), b->L[0], b->stride[0], ndig1, end_bits, ka);
+    for (int sh = (int)end_bits; sh < (int)end_bits + 32 + cbits + bits; sh += 8) {
       radix_pass_kv(ka, src, kb, dst, (u32)N, (u32)sh, b->hist.as<u32>(), ws32, s);
       flip();
       u64 *t = ka; ka = kb; kb = t;
     }
     sorted_keys = ka;
+    b->sorted_keys = ka;
+    b->key_end_bits = end_bits;
+    b->key_bucket_shift = end_bits + 32 + (u32)cbits;
+    b->key_bucket_mask = (1u << bits) - 1;
   } else {
     // phase 1: first ndig1 key digits (least significant first), then chunk, then bucket
     for (int d = ndig1 - 1; d >= 0; d--) {
@@ -724,7 +732,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
     ENSURE(b, b->runid, sizeof(u32) * (N + 2));
     RunArgs ra{(u32)N, perm1, b->bucket.as<u32>(), chunk_or_null, b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], ndig1};
     u8 *head = b->run_head.as<u8>();
-    if (sorted_keys) LAUNCH(run_heads_keys_k, cdiv(N, 256), 256, 0, s, (u32)N, sorted_keys, head);
+    if (sorted_keys) LAUNCH(run_heads_keys_k, cdiv(N, 256), 256, 0, s, (u32)N, sorted_keys, end_bits, head);
     else LAUNCH(run_heads_k, cdiv(N, 256), 256, 0, s, ra, head);
     exclusive_scan<u32>(LoadAs<u8, u32>{head}, N, StoreTo<u32>{b->run_hcount.as<u32>()}, ws32, (u32 *)nullptr, s);
     exclusive_scan<u32>(RunMember{head, (u32)N}, N, StoreTo<u32>{b->run_rank.as<u32>()}, ws32, b->d_small + 9, s);
@@ -750,7 +758,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
         radix_pass(rs, rd, M, DigitOfArray{b->runid.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
         rflip();
       }
-      LAUNCH(run_scatter_k, cdiv(M, 256), 256, 0, s, M, rs, b->run_pos.as<u32>(), perm1);
+      LAUNCH(run_scatter_k, cdiv(M, 256), 256, 0, s, M, rs, b->run_pos.as<u32>(), perm1, sorted_keys, end_bits, b->endv.as<u16>());
     }
   }
   b->perm = perm1;
@@ -790,6 +798,8 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.L = b->L[0]; a.stride = b->stride[0]; a.sz_meta = b->sz_meta; a.bucket_level = c->d_bucket_level;
     a.bucket_pattern = c->d_bucket_pattern; a.bucket_first = b->bucket_first.as<u64>(); a.bucket_off = b->bucket_off.as<u64>();
     a.counts = counts; a.out = b->out_reads[0].as<u8>();
+    a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
+    a.key_end_bits = b->key_end_bits;
     LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
     if (b->p.use_names)
       LAUNCH(emit_names_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->line_end[0].as<u64>(), b->d_text[0],
