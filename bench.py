@@ -81,7 +81,7 @@ def main():
 
     def sharded_need_gb(inflight):
         nm = n / 1e6 * L / 100.0
-        return 8 + 0.4 * nm + 0.7435 * nm * inflight  # (+ 16 bytes per read and slot: the order stage sorts (key, read) pairs)
+        return 8 + 0.4 * nm + 0.76 * nm * inflight  # (+ 33 bytes per read and slot since the rehearsal: (key, read) pairs of the order stage, name cells)
     G = args.group
     if G is None:
         G = 3

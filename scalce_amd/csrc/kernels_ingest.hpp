@@ -100,6 +100,7 @@ struct UnpackArgs {
   u8 *packed;     // nrec * stride, zero padded rows, base 4j..4j+3 in byte j, first base in bits 7-6
   u8 *q;          // nrec * L
   u8 *namelen;    // nrec (mate 0 only)
+  u8 *namecell;   // nrec x 16 (mate 0, names on): [length][first 15 characters] -- one gather for the emit stage
   const u8 *qlut;  // 128 bytes: (values[c] - offset) & 255
   DevErr *err;
 };
@@ -204,6 +205,11 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
       const u64 l = i - (ns + 1);
       if (l > 255 || p0 <= ns) dev_fail(a.err, E_NAMELEN, r);
       len = (u32)(l & 255);
+      if (a.namecell) {
+        u32 w[4] = {len, 0, 0, 0};
+        for (u32 k = 0; k < 15 && k < len; k++) w[(k + 1) >> 2] |= (u32)byte_at(ns + 1 + k) << (8 * ((k + 1) & 3));
+        *reinterpret_cast<uint4 *>(a.namecell + 16 * r) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
     }
     a.namelen[r] = (u8)len;
   }

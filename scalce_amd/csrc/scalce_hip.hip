@@ -182,7 +182,7 @@ struct scalce_batch {
   u32 *d_small = nullptr;    // scratch counters: [0..15]
   u64 *d_small64 = nullptr;
   u8 *d_qlut[2] = {nullptr, nullptr};
-  DBuf line_end[2], packed[2], q[2], namelen, freq4[2], table[2], qs[2];
+  DBuf line_end[2], packed[2], q[2], namelen, namecell, outlen, freq4[2], table[2], qs[2];
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
@@ -235,7 +235,7 @@ static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
 #define ENSURE(b, buf, bytes) do { int rc_ = ensure(b, buf, bytes); if (rc_) return rc_; } while (0)
 
 static void free_all(scalce_batch *b) {
-  DBuf *all[] = {&b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen,
+  DBuf *all[] = {&b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen, &b->namecell, &b->outlen,
                  &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
                  &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
@@ -300,6 +300,10 @@ extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64
     ENSURE(b, b->table[m], sizeof(u32) * 512000);
   }
   ENSURE(b, b->namelen, max_reads + 64);
+  if (b->p.use_names) {
+    ENSURE(b, b->namecell, 16 * (max_reads + 8));
+    ENSURE(b, b->outlen, max_reads + 64);
+  }
   ENSURE(b, b->scan_ws, sizeof(u64) * (max_text / IDX_TILE + scan_ws_elems(4 * max_reads + 1024) + 4096));
   return SCALCE_OK;
 }
@@ -400,6 +404,7 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
     a.text = d_text; a.nbytes = nbytes; a.line_end = b->line_end[mate].as<u64>(); a.nrec = nrec;
     a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
     a.packed = b->packed[mate].as<u8>(); a.q = b->q[mate].as<u8>(); a.namelen = b->namelen.as<u8>();
+    a.namecell = (mate == 0 && b->p.use_names) ? b->namecell.as<u8>() : nullptr;
     a.qlut = b->d_qlut[mate]; a.err = b->d_err;
     if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
       LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
@@ -784,7 +789,8 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
                       b->d_small64 + 2, s);
   if (b->p.use_names) {
     ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
-    exclusive_scan<u64>(NameLenOut{b->perm, b->namelen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
+    if (N) LAUNCH(name_outlen_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->outlen.as<u8>());
+    exclusive_scan<u64>(NameLenSeq{b->outlen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
   }
   u64 h[4] = {0, 0, 0, 0};
   { int rc = read_u64(b, b->d_small64, h, 4, s); if (rc) return rc; }
@@ -803,7 +809,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
     if (b->p.use_names)
       LAUNCH(emit_names_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->line_end[0].as<u64>(), b->d_text[0],
-             b->name_off.as<u64>(), b->out_names.as<u8>());
+             b->name_off.as<u64>(), b->namecell.as<u8>(), b->out_names.as<u8>());
     for (int m = 0; m < b->nm; m++) {
       const u32 w = (u32)b->L[m];
       const u64 items = ((w & 3) == 0) ? N * (w / 4) : N * w;

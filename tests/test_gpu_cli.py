@@ -114,3 +114,27 @@ def test_cli_decompress_rejects_truncated_streams(tmp_path):
         r = subprocess.run([CLI, "-d", "-o", str(tmp_path / "x"), str(tmp_path / "bad_1.scalcen"), "--patterns-bin", PBIN],
                            capture_output=True, text=True)
         assert r.returncode == 1 and "(ERROR)" in r.stderr and "truncated" in r.stderr, (ext, r.stderr[-300:])
+
+
+def test_cli_names_of_every_length(tmp_path):
+    """Names from 1 to 60 characters, with and without a comment behind a space (output_name, names.cpp:48-62, stops at
+    the first space): the ingest stage keeps names of up to 15 characters in 16-byte cells for the emit stage and goes
+    back to the text for longer ones -- both sides of that boundary against the oracle's .scalcen, and back."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    n, L = 6000, 100
+    bases, quals = synth.reads_and_quals(n, L, seed=45)
+    alphabet = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789_.:/-", dtype=np.uint8)
+    with open(tmp_path / "in_1.fq", "wb") as f:
+        for i in range(n):
+            ln = 1 + (i % 60) if i < 600 else int(rng.integers(1, 40))
+            name = alphabet[rng.integers(0, len(alphabet), size=ln)].tobytes()
+            comment = b" length=%d extra" % L if i % 3 == 0 else b""
+            f.write(b"@" + name + comment + b"\n" + bases[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
+    run_cli("-c", "no", "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc")
+    for ext in "nrq":
+        assert open(tmp_path / f"hip_1.scalce{ext}", "rb").read() == open(tmp_path / f"orc_1.scalce{ext}", "rb").read(), ext
+    run_cli("-d", "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
+    O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback")
+    assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()
