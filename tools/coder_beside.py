@@ -25,6 +25,9 @@ stages = {
     "ingest": lambda: B.ingest(0, text.data_ptr(), nbytes, s2.cuda_stream),
     "quality": lambda: B.quality(s2.cuda_stream),
     "tokenize": lambda: B.tokenize(None, s2.cuda_stream),
+    "tok begin": lambda: B.tokenize_begin(s2.cuda_stream),   # DFA walk, tie candidates, events sorted by bucket
+    "tok sweeps": lambda: [B.tokenize_sweep(None, s2.cuda_stream) for _ in range(10)],  # ten tie-break sweeps
+
     "order": lambda: B.order(s2.cuda_stream),
     "emit": lambda: B.emit(s2.cuda_stream),
 }
@@ -43,4 +46,4 @@ for name, f in stages.items():
     dt = (time.perf_counter() - t0) * 1e3
     for b in grp:
         b.finish(s2.cuda_stream)
-    print(f"coder beside {name:9s}: {dt:6.0f} ms  ({reps} runs of the stage meanwhile)", flush=True)
+    print(f"coder beside {name:10s}: {dt:6.0f} ms  ({reps} runs of the stage meanwhile)", flush=True)
