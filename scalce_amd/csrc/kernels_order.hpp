@@ -190,55 +190,91 @@ struct EmitArgs {
   const u64 *keys;          // sorted phase-1 keys (position k <-> record perm[k]) or null
   u32 key_bucket_shift, key_bucket_mask, key_end_bits;
 };
+// The records of a workgroup's 256 positions are contiguous in the output (bucket headers included), 27 bytes each at
+// L = 100 and not aligned to anything: written by their own threads byte by byte they cost 4.6 bytes of HBM writes per
+// byte (PMC WRITE_SIZE).  They are assembled in LDS instead and leave as one coalesced block.
+constexpr int EMIT_STAGE_BYTES = 256 * 64;
 __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
+  __shared__ __attribute__((aligned(16))) u8 stage[EMIT_STAGE_BYTES];
+  __shared__ u64 wg_begin, wg_end;
   const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= a.nrec) return;
-  const u32 r = a.perm[k];
-  const u64 key = a.keys ? a.keys[k] : 0ull;
-  const u32 b = a.keys ? ((u32)(key >> a.key_bucket_shift) & a.key_bucket_mask) : a.bucket[r];
-  const int lv = (int)a.bucket_level[b];
-  const int e = (a.keys && a.key_end_bits) ? (int)(key & 0xFFFFu) : (int)a.end[r];
-  const int recsz = ((a.L - lv + 3) >> 2) + a.sz_meta;
-  const u64 first = a.bucket_first[b];
-  u8 *dst = a.out + a.bucket_off[b];
-  if (k == first) {  // [int32 core][int64 count], compress.cpp:365-378
-    const u32 core = (u32)a.bucket_pattern[b];
-    const u64 cnt = a.counts[b];
-    for (int i = 0; i < 4; i++) dst[i] = (u8)(core >> (8 * i));
-    for (int i = 0; i < 8; i++) dst[4 + i] = (u8)(cnt >> (8 * i));
+  const bool live = k < a.nrec;
+  u64 my_begin = 0, my_end = 0, rec_at = 0;
+  u32 r = 0, b = 0;
+  int lv = 0, e = 0, recsz = 0;
+  u64 first = 0;
+  if (live) {
+    r = a.perm[k];
+    const u64 key = a.keys ? a.keys[k] : 0ull;
+    b = a.keys ? ((u32)(key >> a.key_bucket_shift) & a.key_bucket_mask) : a.bucket[r];
+    lv = (int)a.bucket_level[b];
+    e = (a.keys && a.key_end_bits) ? (int)(key & 0xFFFFu) : (int)a.end[r];
+    recsz = ((a.L - lv + 3) >> 2) + a.sz_meta;
+    first = a.bucket_first[b];
+    rec_at = a.bucket_off[b] + 12 + (k - first) * (u64)recsz;
+    my_begin = (k == first) ? a.bucket_off[b] : rec_at;
+    my_end = rec_at + (u64)recsz;
   }
-  dst += 12 + (k - first) * (u64)recsz;
-  // output_read(line, dest, n = e - lv, l = lv): bases [e, L) then [0, e - lv).  Done on 32-bit big-endian
-  // words of the packed row: output word j = up to two bit-field fetches (funnel shifts) instead of 16
-  // single-base extractions.
-  const u32 *roww = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
-  const int nwords = a.stride >> 2;
-  auto S = [&](int i) -> u32 { return i < nwords ? __builtin_bswap32(roww[i]) : 0u; };
-  auto bits32 = [&](int pos) -> u32 {  // 32 source bits starting at bit `pos` (MSB first)
-    const int w = pos >> 5, sh = pos & 31;
-    const u32 w0 = S(w);
-    if (!sh) return w0;
-    return (w0 << sh) | (S(w + 1) >> (32 - sh));
-  };
-  const int n = e ? e - lv : 0;
-  const int A = 2 * (a.L - e);        // bits of the part after the core
-  const int T = A + 2 * n;            // bits of the record (2 * (L - lv) with a core, 2 * L without)
-  const int nbytes = (T + 7) >> 3;
-  int j = 0;
-  for (int p0 = 0; p0 < T; p0 += 32) {
-    int n1 = A - p0;
-    n1 = n1 < 0 ? 0 : (n1 > 32 ? 32 : n1);
-    u32 word = 0;
-    if (n1) word = bits32(2 * e + p0) & (0xFFFFFFFFu << (32 - n1));
-    if (n1 < 32) word |= bits32(p0 + n1 - A) >> n1;
-    const int left = T - p0;          // record bits from this word on
-    if (left < 32) word &= 0xFFFFFFFFu << (32 - left);
+  if (threadIdx.x == 0) wg_begin = my_begin;
+  if (live && (threadIdx.x == blockDim.x - 1 || k + 1 == a.nrec)) wg_end = my_end;
+  __syncthreads();
+  const bool staged = wg_end - wg_begin <= (u64)EMIT_STAGE_BYTES;  // always, short of reads of more than ~200 bases
+  u8 *dst = staged ? stage + (rec_at - wg_begin) : a.out + rec_at;
+  if (live) {
+    if (k == first) {  // [int32 core][int64 count], compress.cpp:365-378
+      u8 *h = dst - 12;
+      const u32 core = (u32)a.bucket_pattern[b];
+      const u64 cnt = a.counts[b];
+      for (int i = 0; i < 4; i++) h[i] = (u8)(core >> (8 * i));
+      for (int i = 0; i < 8; i++) h[4 + i] = (u8)(cnt >> (8 * i));
+    }
+    // output_read(line, dest, n = e - lv, l = lv): bases [e, L) then [0, e - lv).  Done on 32-bit big-endian
+    // words of the packed row: output word j = up to two bit-field fetches (funnel shifts) instead of 16
+    // single-base extractions.
+    const u32 *roww = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
+    const int nwords = a.stride >> 2;
+    auto S = [&](int i) -> u32 { return i < nwords ? __builtin_bswap32(roww[i]) : 0u; };
+    auto bits32 = [&](int pos) -> u32 {  // 32 source bits starting at bit `pos` (MSB first)
+      const int w = pos >> 5, sh = pos & 31;
+      const u32 w0 = S(w);
+      if (!sh) return w0;
+      return (w0 << sh) | (S(w + 1) >> (32 - sh));
+    };
+    const int n = e ? e - lv : 0;
+    const int A = 2 * (a.L - e);        // bits of the part after the core
+    const int T = A + 2 * n;            // bits of the record (2 * (L - lv) with a core, 2 * L without)
+    const int nbytes = (T + 7) >> 3;
+    int j = 0;
+    for (int p0 = 0; p0 < T; p0 += 32) {
+      int n1 = A - p0;
+      n1 = n1 < 0 ? 0 : (n1 > 32 ? 32 : n1);
+      u32 word = 0;
+      if (n1) word = bits32(2 * e + p0) & (0xFFFFFFFFu << (32 - n1));
+      if (n1 < 32) word |= bits32(p0 + n1 - A) >> n1;
+      const int left = T - p0;          // record bits from this word on
+      if (left < 32) word &= 0xFFFFFFFFu << (32 - left);
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-      if (j < nbytes) dst[j++] = (u8)(word >> (24 - 8 * t));
+      for (int t = 0; t < 4; t++)
+        if (j < nbytes) dst[j++] = (u8)(word >> (24 - 8 * t));
+    }
+    dst[j] = (u8)e;  // end marker, reads.cpp:130
+    if (a.sz_meta == 2) dst[j + 1] = (u8)(e >> 8);
   }
-  dst[j] = (u8)e;  // end marker, reads.cpp:130
-  if (a.sz_meta == 2) dst[j + 1] = (u8)(e >> 8);
+  if (!staged) return;
+  __syncthreads();
+  // the block leaves: bytes up to the first 4-byte boundary of the output, whole words, the tail
+  u8 *out = a.out + wg_begin;
+  const u32 span = (u32)(wg_end - wg_begin);
+  const u32 head = (u32)((4 - ((u64)out & 3)) & 3) < span ? (u32)((4 - ((u64)out & 3)) & 3) : span;
+  if (threadIdx.x < head) out[threadIdx.x] = stage[threadIdx.x];
+  const u32 nwords_out = (span - head) >> 2;
+  for (u32 w = threadIdx.x; w < nwords_out; w += blockDim.x) {
+    const u8 *sp = stage + head + 4 * w;
+    const u32 v = (u32)sp[0] | ((u32)sp[1] << 8) | ((u32)sp[2] << 16) | ((u32)sp[3] << 24);
+    *reinterpret_cast<u32 *>(out + head + 4 * w) = v;
+  }
+  const u32 done = head + 4 * nwords_out;
+  if (threadIdx.x < span - done) out[done + threadIdx.x] = stage[done + threadIdx.x];
 }
 
 struct NameLenOut {  // bytes of the k-th emitted name record
