@@ -560,8 +560,33 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   return SCALCE_OK;
 }
 
-// One Jacobi sweep over the tie reads with the given cross-shard prior counts, then new prefix sums and
-// per-bucket counts (SCALCE_OUT_BUCKET_COUNTS).  *changed = 1 if any decision of THIS shard moved.
+// One Jacobi sweep, enqueued only: decisions of the tie reads against the current counts, then new prefix sums and
+// per-bucket counts for the buckets whose flags moved (seg_rescan_k looks at the dirty marks itself: nothing moved,
+// nothing to do).  flag[0] becomes 1 if any decision of this shard moved.
+static int tokenize_sweep_enqueue(scalce_batch *b, const uint64_t *d_prior, u32 *flag, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie;
+  u32 *d0 = b->dirty.as<u32>(), *d1 = d0 + nb1 + 64;
+  u32 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
+  u64 *prior_seen = reinterpret_cast<u64 *>(d0 + 2 * (size_t)(nb1 + 64));
+  if (d_prior) LAUNCH(prior_dirty_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), prior_seen, dirty_in);
+  HIP_TRY(c, hipMemsetAsync(flag, 0, sizeof(u32), s));
+  u32 *G = b->G.as<u32>();
+  JacobiArgs a;
+  a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
+  a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_place = b->cand_place.as<u32>(); a.G = G;
+  a.Gseg = b->Gseg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
+  a.changed = flag;
+  a.dirty_in = dirty_in; a.dirty_out = dirty_out;
+  HIP_TRY(c, hipMemsetAsync(dirty_out, 0xFF, sizeof(u32) * nb1, s));
+  LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
+  b->dirty_cur ^= 1;
+  LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, b->seg.as<u32>(), dirty_out, b->chosen.as<u8>(), G, b->Gseg.as<u32>(), b->counts.as<u64>());
+  return SCALCE_OK;
+}
+
+// One sweep with the given cross-shard prior counts (SCALCE_OUT_BUCKET_COUNTS is current when it returns).
+// *changed = 1 if any decision of THIS shard moved.
 extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior, int *changed, void *stream) {
   if (!b || !b->tok_open || !changed) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -569,30 +594,12 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   *changed = 0;
-  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie;
-  if (!b->N || !ntie) return SCALCE_OK;
-  u32 *d0 = b->dirty.as<u32>(), *d1 = d0 + nb1 + 64;
-  u32 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
-  u64 *prior_seen = reinterpret_cast<u64 *>(d0 + 2 * (size_t)(nb1 + 64));
-  if (d_prior) LAUNCH(prior_dirty_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), prior_seen, dirty_in);
-  static const u32 init[2] = {0u, 0xFFFFFFFFu};
-  HIP_TRY(c, hipMemcpyAsync(b->d_small + 4, init, sizeof init, hipMemcpyHostToDevice, s));
-  u32 *G = b->G.as<u32>();
-  JacobiArgs a;
-  a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
-  a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_place = b->cand_place.as<u32>(); a.G = G;
-  a.Gseg = b->Gseg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
-  a.changed = b->d_small + 4;
-  a.dirty_in = dirty_in; a.dirty_out = dirty_out;
-  HIP_TRY(c, hipMemsetAsync(dirty_out, 0xFF, sizeof(u32) * nb1, s));
-  LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
-  b->dirty_cur ^= 1;
-  u32 ch[2];
-  { int rc = read_u32(b, b->d_small + 4, ch, 2, s); if (rc) return rc; }
+  if (!b->N || !b->ntie) return SCALCE_OK;
+  { int rc = tokenize_sweep_enqueue(b, d_prior, b->d_small + 4, s); if (rc) return rc; }
+  u32 ch = 0;
+  { int rc = read_u32(b, b->d_small + 4, &ch, 1, s); if (rc) return rc; }
   b->jacobi_iters++;
-  *changed = ch[0] ? 1 : 0;
-  if (ch[0])  // new prefix sums and counts for the buckets whose flags moved in this sweep
-    LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, b->seg.as<u32>(), dirty_out, b->chosen.as<u8>(), G, b->Gseg.as<u32>(), b->counts.as<u64>());
+  *changed = ch ? 1 : 0;
   return SCALCE_OK;
 }
 
@@ -617,11 +624,22 @@ extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
 extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, void *stream) {
   int rc = scalce_batch_tokenize_begin(b, stream);
   if (rc) return rc;
-  for (;;) {
-    int changed = 0;
-    if ((rc = scalce_batch_tokenize_sweep(b, d_prior, &changed, stream))) return rc;
-    if (!changed) break;
-    if (b->jacobi_iters > b->ntie + 1) { set_err(b->ctx, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
+  // Sweeps go out four at a time and the host looks at their flags once per batch: a sweep after the fixed point changes
+  // nothing (and costs next to nothing), while a round trip per sweep left the stream idle 47 times per shard.
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int SWEEPS_PER_LOOK = 4;
+  for (bool done = !(b->N && b->ntie); !done;) {
+    StageTimer tm(b, ST_TOKENIZE, s);
+    u32 *flags = b->d_small + 32;
+    for (int i = 0; i < SWEEPS_PER_LOOK; i++)
+      if ((rc = tokenize_sweep_enqueue(b, d_prior, flags + i, s))) return rc;
+    u32 ch[SWEEPS_PER_LOOK];
+    if ((rc = read_u32(b, flags, ch, SWEEPS_PER_LOOK, s))) return rc;
+    for (int i = 0; i < SWEEPS_PER_LOOK && !done; i++) {
+      b->jacobi_iters++;  // sweeps up to and including the first one that moved nothing, as one at a time would count
+      if (!ch[i]) done = true;
+    }
+    if (b->jacobi_iters > b->ntie + 1 + SWEEPS_PER_LOOK) { set_err(b->ctx, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
   }
   return scalce_batch_tokenize_end(b, stream);
 }
