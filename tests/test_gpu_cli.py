@@ -138,3 +138,19 @@ def test_cli_names_of_every_length(tmp_path):
     run_cli("-d", "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
     O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback")
     assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()
+
+
+@pytest.mark.parametrize("L", [36, 250, 300])
+def test_cli_short_and_long_reads(L, tmp_path):
+    """Reads of 250 / 300 bases leave the tiled ingest kernel and the LDS-staged record writer and, from 256 on, carry a
+    two-byte `end` (reads.cpp:106-108,130); 36-base reads have barely more key digits than the sort prefix.  Files
+    against the oracle's, both ways."""
+    n = 3000
+    synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=60 + L, n_frac=0.002, dup_frac=0.2)
+    run_cli("-c", "no", "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc")
+    for ext in "nrq":
+        assert open(tmp_path / f"hip_1.scalce{ext}", "rb").read() == open(tmp_path / f"orc_1.scalce{ext}", "rb").read(), ext
+    run_cli("-d", "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
+    O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback")
+    assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()

@@ -483,3 +483,4 @@ def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
     got = out.cpu().numpy()
     bad = np.flatnonzero(got != sym)
     assert len(bad) == 0, f"{case}: decoded stream differs first at {bad[:5]}: {got[bad[:5]]} vs {sym[bad[:5]]}"
+
