@@ -310,7 +310,7 @@ __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos)
 // k agreed leading bits, u underflow steps -- and appends the bits arithmetic.cpp:133-147 would have written one at a
 // time.  All 64 lanes of the calling wave take part; `buf` is AC_BUF_WORDS words of LDS owned by that wave.
 struct AcSink {
-  u32 *dst = nullptr;  // the block's output words
+  SCALCE_GLOBAL u32 *dst = nullptr;  // the block's output words
   u32 wcap = 0;        // words the block may write
   u32 gw = 0;          // words already stored
   u32 c0 = 16;         // bits pending in `carry` (left aligned); a block starts with its two raw symbols
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
   else __builtin_amdgcn_s_setprio(2);
   // ---- helper-wave state (bit sink) ----
   AcSink sink;
-  sink.dst = reinterpret_cast<u32 *>(a.out + (u64)blk * a.out_stride);
+  sink.dst = (SCALCE_GLOBAL u32 *)(a.out + (u64)blk * a.out_stride);
   sink.wcap = a.out_cap / 4;
   // ---- chain-wave state ----
   u32 lo = 0, hi = 0xFFFFFFFFu;
@@ -783,20 +783,31 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     const int h = wv - 1;
     u32 *buf0 = bufs[h][0], *buf1 = bufs[h][1];
     AcSink sink[2];
-    const u8 *sp[2];
-    const uint4 *tabp[2];
-    u32 nb[2], sy_a[2], sy_b[2];  // sy_a, sy_b: symbols of super-rounds r + 2 and r + 3
-    uint4 o_pend[2];              // operands of super-round r + 2, in flight since the last iteration
-    auto sym_at = [&](int e, u32 i) -> u32 { return i < nb[e] ? (u32)sp[e][i] : 0u; };
-    auto lookup = [&](int e, u32 sy_prev, u32 sy, u32 base) -> uint4 {
-      const u32 e63 = __builtin_amdgcn_readlane(sy_prev, 63), e62 = __builtin_amdgcn_readlane(sy_prev, 62);
-      const u32 p1 = __builtin_amdgcn_update_dpp(e63, sy, 0x138, 0xF, 0xF, false);
-      const u32 p0 = __builtin_amdgcn_update_dpp(e62, p1, 0x138, 0xF, 0xF, false);
+    const SCALCE_GLOBAL u8 *sp[2];        // (global, not generic: see SCALCE_GLOBAL)
+    const SCALCE_GLOBAL u32x4 *tabp[2];
+    u32 nb[2];
+    // Operands and symbols in flight, in two register sets that alternate by name (the loop below runs two super-rounds
+    // per iteration): what is requested at the top of one super-round is first touched in the next one, and the
+    // barrier between them waits for LDS only.  Before, every super-round ended with the loads it had just issued
+    // (copied at its end; __syncthreads() drains vmcnt anyway), so beside other shards' front stages -- when a fetch
+    // takes a few microseconds -- the chain wave stood at the barrier for 18-25 % of its time.
+    uint4 oA[2], oB[2];   // operands of super-round r + 2 (in use) / r + 3 (being fetched)
+    u32 sA[2], sB[2];     // symbols of super-round r + 3 (in use) / r + 4 (being fetched)
+    u32 e62[2], e63[2];   // the two symbols in front of the next super-round to be addressed
+    auto sym_at = [&](int e, u32 i) -> u32 {  // unconditional load (a load behind a branch cannot be counted by s_waitcnt)
+      const u32 v = sp[e][i < nb[e] ? i : 0u];
+      return i < nb[e] ? v : 0u;
+    };
+    auto lookup = [&](int e, u32 sy, u32 base) -> uint4 {
+      const u32 p1 = __builtin_amdgcn_update_dpp(e63[e], sy, 0x138, 0xF, 0xF, false);
+      const u32 p0 = __builtin_amdgcn_update_dpp(e62[e], p1, 0x138, 0xF, 0xF, false);
+      e63[e] = __builtin_amdgcn_readlane(sy, 63);
+      e62[e] = __builtin_amdgcn_readlane(sy, 62);
       const u32 D1 = AC_D - 1;
       const u32 c = sy < D1 ? sy : D1, q1 = p1 < D1 ? p1 : D1, q0 = p0 < D1 ? p0 : D1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (base + lane < nb[e]) v = tabp[e][(q0 * AC_D + q1) * AC_D + c];
-      return v;
+      const u32x4 t = tabp[e][(q0 * AC_D + q1) * AC_D + c];
+      const bool live = base + lane < nb[e];
+      return make_uint4(live ? t.x : 0u, live ? t.y : 0u, live ? t.z : 0u, live ? t.w : 0u);
     };
     // outcome of a symbol from what its lane latched in the chain wave (the "parallel recomputation" of ac_encode_k,
     // done here where there is slack): hi before the shift, k agreed bits, u underflow steps
@@ -821,18 +832,15 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const u32 b = blk0 + 2 * h + e;
       nb[e] = block_len(b);
       const AcBlockDesc dsc = nb[e] ? a.desc[b] : a.desc[0];
-      sp[e] = dsc.sym;
-      tabp[e] = dsc.tab;
-      sink[e].dst = dsc.dst;
+      sp[e] = (const SCALCE_GLOBAL u8 *)dsc.sym;
+      tabp[e] = (const SCALCE_GLOBAL u32x4 *)dsc.tab;
+      sink[e].dst = (SCALCE_GLOBAL u32 *)dsc.dst;
       sink[e].wcap = a.out_cap / 4;
       if (nb[e]) sink[e].carry = ((u32)sp[e][0] << 24) | ((nb[e] > 1 ? (u32)sp[e][1] : 0u) << 16);
-      // table rows are fetched two super-rounds before the chain wave needs them and the symbols they are addressed
-      // with a super-round before that: beside other shards' front stages a fetch can take longer than a super-round
-      const u32 sy0 = sym_at(e, lane), sy1 = sym_at(e, 64 + lane);
-      sy_a[e] = sym_at(e, 128 + lane);
-      sy_b[e] = sym_at(e, 192 + lane);
-      const uint4 o0 = lookup(e, 0u, sy0, 0), o1 = lookup(e, sy0, sy1, 64);
-      o_pend[e] = lookup(e, sy1, sy_a[e], 128);
+      e62[e] = e63[e] = 0;
+      const uint4 o0 = lookup(e, sym_at(e, lane), 0), o1 = lookup(e, sym_at(e, 64 + lane), 64);
+      oA[e] = lookup(e, sym_at(e, 128 + lane), 128);
+      sA[e] = sym_at(e, 192 + lane);
       opsb[0][2 * h + e][lane] = o0;
       opsb[1][2 * h + e][lane] = o1;
       hist[e][0] = make_uint4(0, 0, 0, 0);
@@ -844,14 +852,11 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     __syncthreads();
     u64 hprof_wait = 0;
     const u64 hprof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
-    for (u32 r = 0; r < nsr; r++) {
-      uint4 o2[2], o3[2];
-      u32 sy_c[2];
+    auto super_round = [&](const u32 r, uint4 (&o_use)[2], u32 (&s_use)[2], uint4 (&o_load)[2], u32 (&s_load)[2]) {
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        o2[e] = o_pend[e];
-        o3[e] = lookup(e, sy_a[e], sy_b[e], (r + 3) << 6);
-        sy_c[e] = sym_at(e, ((r + 4) << 6) + lane);
+        o_load[e] = lookup(e, s_use[e], (r + 3) << 6);
+        s_load[e] = sym_at(e, ((r + 4) << 6) + lane);
       }
       if (r > 0) {
         u32 rH[2], rK[2];
@@ -866,23 +871,24 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       }
 #pragma unroll
       for (int e = 0; e < 2; e++) {
-        opsb[r & 1][2 * h + e][lane] = o2[e];
-        const u32 ok2 = plain_ok(e, o2[e], r + 2);
+        opsb[r & 1][2 * h + e][lane] = o_use[e];
+        const u32 ok2 = plain_ok(e, o_use[e], r + 2);
         if (lane == 0) oflag[r & 1][2 * h + e] = ok2;
-        sy_a[e] = sy_b[e];
-        sy_b[e] = sy_c[e];
-        o_pend[e] = o3[e];
         hist[e][0] = hist[e][1];
         hist[e][1] = hist[e][2];
-        hist[e][2] = o2[e];
+        hist[e][2] = o_use[e];
       }
       if (a.prof && h == 0) {
         const u64 w0 = __builtin_amdgcn_s_memtime();
-        __syncthreads();
+        barrier_lds_only();
         hprof_wait += __builtin_amdgcn_s_memtime() - w0;
       } else {
-        __syncthreads();
+        barrier_lds_only();
       }
+    };
+    for (u32 r = 0; r < nsr; r += 2) {
+      super_round(r, oA, sA, oB, sB);
+      if (r + 1 < nsr) super_round(r + 1, oB, sB, oA, sA);
     }
     if (a.prof && h == 0 && lane == 0) {
       a.prof[blockIdx.x * 5 + 3] = hprof_wait;

@@ -12,6 +12,17 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 typedef unsigned short u16;
 typedef unsigned char u8;
+// Pointers that a kernel loads from memory (descriptor tables) are generic to the compiler: it then emits flat_*
+// instructions, which count on BOTH vmcnt and lgkmcnt, so that every LDS wait also waits for the global loads in
+// flight.  Such pointers are cast to the global address space by hand.
+#define SCALCE_GLOBAL __attribute__((address_space(1)))
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+// Workgroup barrier for waves that only exchange data through LDS: __syncthreads() is a fence as well and drains the
+// global loads and stores in flight (s_waitcnt vmcnt(0)) in front of every barrier -- no prefetch survives it.
+__device__ __forceinline__ void barrier_lds_only() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt and expcnt left alone
+  __builtin_amdgcn_s_barrier();
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
