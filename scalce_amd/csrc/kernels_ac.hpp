@@ -14,6 +14,7 @@
 //   * the serial part then walks the 64 staged operands from LDS (broadcast reads) with the
 //     renormalisation loop of :133-152 in closed form (count-leading-zeros instead of bit steps).
 #pragma once
+#include <type_traits>
 #include "kernels_order.hpp"
 
 namespace scalce {
@@ -447,6 +448,9 @@ __device__ __forceinline__ void ac_pack2(AcSink *sk, u32 *buf0, u32 *buf1, int l
   if (slow) {  // an underflow run longer than 32 bits (about once per 2^32 symbols): the serial walk, block by block
     sk[0].pack(buf0, lane, slow_threshold, rH[0], rK[0]);
     sk[1].pack(buf1, lane, slow_threshold, rH[1], rK[1]);
+    // (two stores on this path as well, to the dump words: the caller's waits count the stores behind its loads)
+    sk[0].dst[sk[0].wcap + lane] = 0;
+    sk[1].dst[sk[1].wcap + lane] = 0;
     return;
   }
 #pragma unroll
@@ -476,10 +480,21 @@ __device__ __forceinline__ void ac_pack2(AcSink *sk, u32 *buf0, u32 *buf1, int l
   for (int e = 0; e < 2; e++) {
     const u32 endbits = sk[e].c0 + total[e];
     const u32 nfull = endbits >> 5;
-    for (u32 w = lane; w < nfull; w += 64) {
-      if (sk[e].gw + w < sk[e].wcap) sk[e].dst[sk[e].gw + w] = __builtin_bswap32(bufs[e][w]);
-      else sk[e].over = true;
+    {
+      // ONE store instruction per block and round, issued whatever the lanes have to write (a lane without a word
+      // writes to the dump words behind the block's output): a store behind a branch cannot be counted, and the wait
+      // for the next loads then drains every store in flight as well (s_waitcnt vmcnt(0))
+      const u32 w = (u32)lane;
+      const bool has = w < nfull, fits = sk[e].gw + w < sk[e].wcap;
+      if (has && !fits) sk[e].over = true;
+      const u32 at = (has && fits) ? sk[e].gw + w : sk[e].wcap + w;
+      sk[e].dst[at] = __builtin_bswap32(bufs[e][w]);
     }
+    if (nfull > 64)  // more than 2048 bits from 64 symbols: rare
+      for (u32 w = lane + 64; w < nfull; w += 64) {
+        if (sk[e].gw + w < sk[e].wcap) sk[e].dst[sk[e].gw + w] = __builtin_bswap32(bufs[e][w]);
+        else sk[e].over = true;
+      }
     sk[e].carry = bufs[e][nfull];
     sk[e].c0 = endbits & 31;
     sk[e].gw += nfull;
@@ -835,7 +850,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sp[e] = (const SCALCE_GLOBAL u8 *)dsc.sym;
       tabp[e] = (const SCALCE_GLOBAL u32x4 *)dsc.tab;
       sink[e].dst = (SCALCE_GLOBAL u32 *)dsc.dst;
-      sink[e].wcap = a.out_cap / 4;
+      sink[e].wcap = a.out_cap / 4 - 64;  // the last 64 words of the block's buffer are the dump words of ac_pack2
       if (nb[e]) sink[e].carry = ((u32)sp[e][0] << 24) | ((nb[e] > 1 ? (u32)sp[e][1] : 0u) << 16);
       e62[e] = e63[e] = 0;
       const uint4 o0 = lookup(e, sym_at(e, lane), 0), o1 = lookup(e, sym_at(e, 64 + lane), 64);
@@ -852,13 +867,14 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     __syncthreads();
     u64 hprof_wait = 0;
     const u64 hprof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
-    auto super_round = [&](const u32 r, uint4 (&o_use)[2], u32 (&s_use)[2], uint4 (&o_load)[2], u32 (&s_load)[2]) {
+    auto super_round = [&](auto first, const u32 r, uint4 (&o_use)[2], u32 (&s_use)[2], uint4 (&o_load)[2], u32 (&s_load)[2]) {
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         o_load[e] = lookup(e, s_use[e], (r + 3) << 6);
         s_load[e] = sym_at(e, ((r + 4) << 6) + lane);
       }
-      if (r > 0) {
+      if constexpr (!decltype(first)::value) {  // (super-round 0 has nothing to pack: peeled, so that every pass of the
+                                                //  loop issues its stores -- see ac_pack2)
         u32 rH[2], rK[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
@@ -886,9 +902,10 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
         barrier_lds_only();
       }
     };
-    for (u32 r = 0; r < nsr; r += 2) {
-      super_round(r, oA, sA, oB, sB);
-      if (r + 1 < nsr) super_round(r + 1, oB, sB, oA, sA);
+    if (nsr) super_round(std::true_type{}, 0u, oA, sA, oB, sB);
+    for (u32 r = 1; r < nsr; r += 2) {
+      super_round(std::false_type{}, r, oB, sB, oA, sA);
+      if (r + 1 < nsr) super_round(std::false_type{}, r + 1, oA, sA, oB, sB);
     }
     if (a.prof && h == 0 && lane == 0) {
       a.prof[blockIdx.x * 5 + 3] = hprof_wait;
