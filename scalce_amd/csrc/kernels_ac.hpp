@@ -298,7 +298,8 @@ __device__ __forceinline__ void sys_round(SysState &st, u32 lo, u32 M0, const ui
 //                               sum gives every symbol its bit offset, the bits are OR-ed into an LDS
 //                               word buffer and the finished words leave with one coalesced store.
 // The two waves meet at one barrier per round, so gather and pack are off the chain's critical path.
-constexpr int AC_BUF_WORDS = 136;  // 31 carried bits + 64 symbols x 64 bits
+constexpr int AC_BUF_WORDS = 200;  // up to 2047 buffered bits (ac_pack2) + 64 symbols x 64 bits, rounded up
+constexpr int AC_ROUND_WORDS = 136;  // one round on its own (AcSink::pack): 31 carried bits + 64 symbols x 64 bits
 
 __device__ __forceinline__ void lds_place(u32 *buf, u32 bits, u32 n, u32 bitpos) {  // n in 1..32
   const u32 s = bitpos & 31, w = bitpos >> 5;
@@ -318,6 +319,27 @@ struct AcSink {
   u32 carry = 0;
   u32 pend = 0;        // underflow steps not yet materialised as bits
   bool over = false;
+  u32 fill = 0;        // ac_pack2 only: bits waiting in the wave's LDS buffer (stored 2048 at a time)
+
+  // ac_pack2 <-> the one-round-at-a-time form: everything buffered goes out except the last partial word, which becomes
+  // `carry` / `c0` again (to_plain), or the partial word goes back to the front of the buffer (to_buffered)
+  __device__ __forceinline__ void to_buffered(u32 *buf, int lane) {
+    if (lane == 0) buf[0] = carry;
+    fill = c0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void to_plain(u32 *buf, int lane) {
+    const u32 nfull = fill >> 5;
+    for (u32 w = lane; w < nfull; w += 64) {
+      if (gw + w < wcap) dst[gw + w] = __builtin_bswap32(buf[w]);
+      else over = true;
+    }
+    carry = (fill & 31) ? buf[nfull] : 0u;
+    c0 = fill & 31;
+    gw += nfull;
+    fill = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
 
   // uniform append of nb <= 32 bits (every lane passes the same values): rare slow path and final flush
   __device__ __forceinline__ void emit_u(u32 *buf, int lane, u32 v, u32 nb) {
@@ -377,7 +399,7 @@ struct AcSink {
     const u32 incl = wave_inclusive_sum(nbits);
     const u32 total = __builtin_amdgcn_readlane(incl, 63);
     const u32 o = c0 + incl - nbits;
-    for (int w = lane; w < AC_BUF_WORDS; w += 64) buf[w] = (w == 0) ? carry : 0u;
+    for (int w = lane; w < AC_ROUND_WORDS; w += 64) buf[w] = (w == 0) ? carry : 0u;
     __builtin_amdgcn_wave_barrier();
     if (flag) {
       const u32 run = (msb || P == 0) ? 0u : (P == 32 ? 0xFFFFFFFFu : ((1u << P) - 1));
@@ -446,20 +468,26 @@ __device__ __forceinline__ void ac_pack2(AcSink *sk, u32 *buf0, u32 *buf1, int l
     slow = slow || __any(flag[e] && P[e] > slow_threshold);
   }
   if (slow) {  // an underflow run longer than 32 bits (about once per 2^32 symbols): the serial walk, block by block
-    sk[0].pack(buf0, lane, slow_threshold, rH[0], rK[0]);
-    sk[1].pack(buf1, lane, slow_threshold, rH[1], rK[1]);
-    // (two stores on this path as well, to the dump words: the caller's waits count the stores behind its loads)
-    sk[0].dst[sk[0].wcap + lane] = 0;
-    sk[1].dst[sk[1].wcap + lane] = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      sk[e].to_plain(bufs[e], lane);
+      sk[e].pack(bufs[e], lane, slow_threshold, rH[e], rK[e]);
+      sk[e].to_buffered(bufs[e], lane);
+    }
     return;
   }
+  // The bits of a round are appended to what the buffer already holds and leave 64 words (one coalesced 256-byte
+  // store) at a time, every 7-14 rounds: a store per round and block was ~24 bytes wide, and with stores in flight
+  // behind every load the waits for the next operands had to drain them too.
 #pragma unroll
   for (int e = 0; e < 2; e++) {
     nbits[e] = flag[e] ? k[e] + P[e] : 0u;
     const u32 incl = wave_inclusive_sum(nbits[e]);
     total[e] = __builtin_amdgcn_readlane(incl, 63);
-    o[e] = sk[e].c0 + incl - nbits[e];
-    for (int w = lane; w < AC_BUF_WORDS; w += 64) bufs[e][w] = (w == 0) ? sk[e].carry : 0u;
+    o[e] = sk[e].fill + incl - nbits[e];
+    // zero the words this round reaches for the first time (the partial word at the end of the buffer keeps its bits)
+    const u32 w0 = (sk[e].fill + 31) >> 5, w1 = (sk[e].fill + total[e] + 31) >> 5;
+    for (u32 w = w0 + lane; w < w1; w += 64) bufs[e][w] = 0u;
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -478,29 +506,24 @@ __device__ __forceinline__ void ac_pack2(AcSink *sk, u32 *buf0, u32 *buf1, int l
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int e = 0; e < 2; e++) {
-    const u32 endbits = sk[e].c0 + total[e];
-    const u32 nfull = endbits >> 5;
-    {
-      // ONE store instruction per block and round, issued whatever the lanes have to write (a lane without a word
-      // writes to the dump words behind the block's output): a store behind a branch cannot be counted, and the wait
-      // for the next loads then drains every store in flight as well (s_waitcnt vmcnt(0))
-      const u32 w = (u32)lane;
-      const bool has = w < nfull, fits = sk[e].gw + w < sk[e].wcap;
-      if (has && !fits) sk[e].over = true;
-      const u32 at = (has && fits) ? sk[e].gw + w : sk[e].wcap + w;
-      sk[e].dst[at] = __builtin_bswap32(bufs[e][w]);
-    }
-    if (nfull > 64)  // more than 2048 bits from 64 symbols: rare
-      for (u32 w = lane + 64; w < nfull; w += 64) {
-        if (sk[e].gw + w < sk[e].wcap) sk[e].dst[sk[e].gw + w] = __builtin_bswap32(bufs[e][w]);
-        else sk[e].over = true;
-      }
-    sk[e].carry = bufs[e][nfull];
-    sk[e].c0 = endbits & 31;
-    sk[e].gw += nfull;
+    sk[e].fill += total[e];
     sk[e].pend = pend_out[e];
+    while (sk[e].fill >= 2048) {  // 64 full words: out, and the rest moves to the front
+      if (sk[e].gw + lane < sk[e].wcap) sk[e].dst[sk[e].gw + lane] = __builtin_bswap32(bufs[e][lane]);
+      else sk[e].over = true;
+      const u32 rem = (sk[e].fill - 2048 + 31) >> 5;  // words behind the 64 (at most 130)
+      u32 t[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) t[j] = (lane + 64 * j < rem) ? bufs[e][64 + lane + 64 * j] : 0u;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        if (lane + 64 * j < rem) bufs[e][lane + 64 * j] = t[j];
+      __builtin_amdgcn_wave_barrier();
+      sk[e].fill -= 2048;
+      sk[e].gw += 64;
+    }
   }
-  __builtin_amdgcn_wave_barrier();
 }
 
 template <bool GENERAL>
@@ -850,7 +873,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sp[e] = (const SCALCE_GLOBAL u8 *)dsc.sym;
       tabp[e] = (const SCALCE_GLOBAL u32x4 *)dsc.tab;
       sink[e].dst = (SCALCE_GLOBAL u32 *)dsc.dst;
-      sink[e].wcap = a.out_cap / 4 - 64;  // the last 64 words of the block's buffer are the dump words of ac_pack2
+      sink[e].wcap = a.out_cap / 4;
       if (nb[e]) sink[e].carry = ((u32)sp[e][0] << 24) | ((nb[e] > 1 ? (u32)sp[e][1] : 0u) << 16);
       e62[e] = e63[e] = 0;
       const uint4 o0 = lookup(e, sym_at(e, lane), 0), o1 = lookup(e, sym_at(e, 64 + lane), 64);
@@ -863,6 +886,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       hist[e][2] = o1;
       const u32 ok1 = plain_ok(e, o1, 1);
       if (lane == 0) { oflag[0][2 * h + e] = 0; oflag[1][2 * h + e] = ok1; }
+      sink[e].to_buffered(e ? buf1 : buf0, lane);  // the two raw symbols of the block open its buffer
     }
     __syncthreads();
     u64 hprof_wait = 0;
@@ -918,6 +942,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const uint2 v = outcome(rec[r & 1][2 * h + e][lane], hist[e][0], recfmt[r & 1][2 * h + e]);
       const bool valid = ((r << 6) + lane < nb[e]) && !(r == 0 && lane < 2);
       u32 *buf = e ? buf1 : buf0;
+      sink[e].to_plain(buf, lane);
       sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       const u32 bytes = sink[e].finish(buf, lane, final_lo[2 * h + e]);
       const AcBlockDesc dsc = a.desc[blk0 + 2 * h + e];
