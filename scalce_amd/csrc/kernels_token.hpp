@@ -158,6 +158,7 @@ struct EventArgs {
   const u32 *ev_off;
   u32 *ev_bucket;
   u8 *ev_init;           // initial "chosen" flag: fixed reads 1, first candidate 1, others 0
+  u64 *ev_key;           // bucket << 1 | initial flag: what the sort by bucket carries along (or null)
 };
 __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
   const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,12 +167,16 @@ __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
   if (a.tok_pos[r] >> 31) {
     const u32 t = a.tie_index[r], off = a.tie_off[t], k = a.tie_ncand[t];
     for (u32 j = 0; j < k; j++) {
-      a.ev_bucket[e + j] = a.cand_bucket[off + j];
+      const u32 bk = a.cand_bucket[off + j];
+      a.ev_bucket[e + j] = bk;
       a.ev_init[e + j] = j == 0;
+      if (a.ev_key) a.ev_key[e + j] = ((u64)bk << 1) | (j == 0 ? 1u : 0u);
     }
   } else {
-    a.ev_bucket[e] = a.tok_bucket[r];
+    const u32 bk = a.tok_bucket[r];
+    a.ev_bucket[e] = bk;
     a.ev_init[e] = 1;
+    if (a.ev_key) a.ev_key[e] = ((u64)bk << 1) | 1u;
   }
 }
 
@@ -220,6 +225,25 @@ __global__ __launch_bounds__(256) void events_segments_k(u32 nev, const u32 *sor
   if (i > nev) return;
   const u32 cur = i < nev ? ev_bucket[sorted[i]] : nb;
   const u32 prev = i ? ev_bucket[sorted[i - 1]] : 0xFFFFFFFFu;
+  if (i == 0) {
+    for (u32 b = 0; b <= cur && b <= nb; b++) seg[b] = 0;
+  } else if (cur != prev) {
+    for (u32 b = prev + 1; b <= cur && b <= nb; b++) seg[b] = i;
+  }
+}
+
+// the same two from the sorted (bucket << 1 | initial flag) keys: sequential reads instead of gathers through `sorted`
+__global__ __launch_bounds__(256) void events_place_keys_k(u32 nev, const u32 *sorted, const u64 *keys, u32 *ev_place, u8 *chosen) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nev) return;
+  ev_place[sorted[i]] = i;
+  chosen[i] = (u8)(keys[i] & 1u);
+}
+__global__ __launch_bounds__(256) void events_segments_keys_k(u32 nev, const u64 *keys, u32 nb, u32 *seg) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nev) return;
+  const u32 cur = i < nev ? (u32)(keys[i] >> 1) : nb;
+  const u32 prev = i ? (u32)(keys[i - 1] >> 1) : 0xFFFFFFFFu;
   if (i == 0) {
     for (u32 b = 0; b <= cur && b <= nb; b++) seg[b] = 0;
   } else if (cur != prev) {

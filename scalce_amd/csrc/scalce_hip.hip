@@ -533,20 +533,27 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
     a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
     a.ev_off = b->ev_off.as<u32>(); a.ev_bucket = b->ev_bucket.as<u32>(); a.ev_init = b->ev_init.as<u8>();
+    // the events are sorted by bucket as (key, event) pairs, like the order stage's records (sequential passes; the
+    // index-only passes gathered the bucket through the index, and so did the two kernels behind them)
+    ENSURE(b, b->key_a, sizeof(u64) * ((size_t)nev + 2));
+    ENSURE(b, b->key_b, sizeof(u64) * ((size_t)nev + 2));
+    a.ev_key = b->key_a.as<u64>();
     LAUNCH(events_fill_k, cdiv(N, 256), 256, 0, s, a);
   }
   int bits = 1;
   while ((1u << bits) < nb1 && bits < 31) bits++;
   const u32 *src = nullptr;  // identity
   u32 *dst = b->ev_sorted.as<u32>(), *alt = b->ev_tmp.as<u32>();
-  for (int sh = 0; sh < bits; sh += 8) {
-    radix_pass(src, dst, nev, DigitOfArray{b->ev_bucket.as<u32>(), sh}, b->hist.as<u32>(), ws32, s);
+  u64 *ka = b->key_a.as<u64>(), *kb = b->key_b.as<u64>();
+  for (int sh = 1; sh < 1 + bits; sh += 8) {  // bit 0 is the initial flag riding along
+    radix_pass_kv(ka, src, kb, dst, nev, (u32)sh, b->hist.as<u32>(), ws32, s);
     src = dst;
     u32 *t = dst; dst = alt; alt = t;
+    u64 *tk = ka; ka = kb; kb = tk;
   }
   const u32 *sorted = src;
-  LAUNCH(events_place_k, cdiv(nev, 256), 256, 0, s, nev, sorted, b->ev_init.as<u8>(), b->ev_place.as<u32>(), b->chosen.as<u8>());
-  LAUNCH(events_segments_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, sorted, b->ev_bucket.as<u32>(), nb1, b->seg.as<u32>());
+  LAUNCH(events_place_keys_k, cdiv(nev, 256), 256, 0, s, nev, sorted, ka, b->ev_place.as<u32>(), b->chosen.as<u8>());
+  LAUNCH(events_segments_keys_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, ka, nb1, b->seg.as<u32>());
   if (ntie)
     LAUNCH(tie_place_k, cdiv(ntie, 256), 256, 0, s, ntie, b->tie_read.as<u32>(), b->tie_off.as<u32>(), b->tie_ncand.as<u32>(),
            b->ev_off.as<u32>(), b->ev_place.as<u32>(), b->cand_place.as<u32>());
