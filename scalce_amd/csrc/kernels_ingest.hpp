@@ -102,6 +102,7 @@ struct UnpackArgs {
   u8 *namelen;    // nrec (mate 0 only)
   u8 *namecell;   // nrec x 16 (mate 0, names on): [length][first 15 characters] -- one gather for the emit stage
   const u8 *qlut;  // 128 bytes: (values[c] - offset) & 255
+  int q_affine;    // >= 0: values[c] == c for every c, q' = (c & 127) - q_affine without the table
   DevErr *err;
 };
 
@@ -174,8 +175,15 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
     }
     // q' (qualities.cpp:183): exactly 'N' forces the offset, i.e. symbol 0
     const u32 isN = (zero_bytes(vb ^ 0x4E4E4E4Eu) >> 7) * 0xFFu;
-    u32 qq = (u32)lut[vq & 127] | ((u32)lut[(vq >> 8) & 127] << 8) | ((u32)lut[(vq >> 16) & 127] << 16) |
-             ((u32)lut[(vq >> 24) & 127] << 24);
+    u32 qq;
+    if (a.q_affine >= 0) {  // four subtractions in one word, no borrow across bytes: every byte of x is < 128, so with
+                            // bit 7 set it cannot go below zero (it returns to the result through the xor)
+      const u32 x = vq & 0x7F7F7F7Fu, y = (u32)a.q_affine * 0x01010101u;
+      qq = ((x | 0x80808080u) - y) ^ 0x80808080u;
+    } else {
+      qq = (u32)lut[vq & 127] | ((u32)lut[(vq >> 8) & 127] << 8) | ((u32)lut[(vq >> 16) & 127] << 16) |
+           ((u32)lut[(vq >> 24) & 127] << 24);
+    }
     qq &= ~isN;
     if (rem >= 4) {
       if (qrow_aligned)

@@ -182,6 +182,7 @@ struct scalce_batch {
   u32 *d_small = nullptr;    // scratch counters: [0..15]
   u64 *d_small64 = nullptr;
   u8 *d_qlut[2] = {nullptr, nullptr};
+  int q_affine[2] = {-1, -1};  // the quality map is q - offset for every character: no table lookups in the ingest kernel
   DBuf line_end[2], packed[2], q[2], namelen, namecell, outlen, freq4[2], table[2], qs[2];
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
@@ -289,7 +290,12 @@ extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64
   HIP_TRY(c, hipEventCreate(&b->ev1));
   for (int m = 0; m < b->nm; m++) {
     u8 lut[128];
-    for (int i = 0; i < 128; i++) lut[i] = (u8)((p->qmap[m].values[i] - p->qmap[m].offset) & 255);
+    bool identity = p->qmap[m].offset >= 0 && p->qmap[m].offset < 128;
+    for (int i = 0; i < 128; i++) {
+      lut[i] = (u8)((p->qmap[m].values[i] - p->qmap[m].offset) & 255);
+      identity = identity && p->qmap[m].values[i] == i;
+    }
+    b->q_affine[m] = identity ? (int)p->qmap[m].offset : -1;
     HIP_TRY(c, hipMalloc(&b->d_qlut[m], 128));
     HIP_TRY(c, hipMemcpy(b->d_qlut[m], lut, 128, hipMemcpyHostToDevice));
     ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (max_reads + 1));
@@ -406,6 +412,7 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
     a.packed = b->packed[mate].as<u8>(); a.q = b->q[mate].as<u8>(); a.namelen = b->namelen.as<u8>();
     a.namecell = (mate == 0 && b->p.use_names) ? b->namecell.as<u8>() : nullptr;
     a.qlut = b->d_qlut[mate]; a.err = b->d_err;
+    a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
     if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
       LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
     else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
