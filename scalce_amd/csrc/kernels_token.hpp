@@ -34,7 +34,11 @@ struct TokArgs {
   u32 root_bucket;      // bucket id of "no core" (== number of real buckets)
   u32 *tok_bucket;      // first longest core (bucket id), or root_bucket
   u32 *tok_pos;         // bits 0-15: index of the core's last base; bits 16-30: hits at max level; bit 31: tie
+  // k-mer tables (tokenize_kmer_k), 52 KB: t7[16384] u16 | bits8[2048] u32 | out8[2048] u32 | rank8[2048] u16
+  const u32 *kmer;
+  u32 id8_first;        // first state of depth 8 (= n_states when there is none): ids are BFS ranks, so depth >= 8 <=> id >= this
 };
+constexpr u32 KMER_T7_WORDS = 16384 / 2, KMER_BITS_WORDS = 2048, KMER_WORDS = KMER_T7_WORDS + 2 * KMER_BITS_WORDS + 2048 / 2;
 
 __device__ __forceinline__ u32 base_at(const u8 *row, int i) { return (row[i >> 2] >> (6 - 2 * (i & 3))) & 3u; }
 
@@ -69,6 +73,60 @@ __global__ __launch_bounds__(TOK_THREADS) void tokenize_k(TokArgs a) {
       if (t >> 31) {
         u32 info;
         if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state];
+        const u32 lv = info >> kLevelShiftD, b = info & kBucketMaskD;
+        if (lv > best_lv) {
+          best_lv = lv; best_b = b; best_pos = 16 * w + k; hits = 1; tie = 0;
+        } else if (lv == best_lv) {
+          hits++;
+          if (b != best_b) tie = 1;
+        }
+      }
+    }
+  }
+  a.tok_bucket[r] = best_b;
+  a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
+}
+
+// The same walk with most transitions replaced by lookups that do not depend on the previous state.  With thousands
+// of cores of 8 and more bases nearly every 7-mer is a trie node: the walk sits at depth 7-8 (tens of thousands of
+// states) and tokenize_k finds four of five transitions in L2 -- 260 GB of random sector reads per 50 M reads, which is
+// what bounds it.  But the state after a base is the longest suffix of the text that is a trie node, and when the state
+// BEFORE the base has depth <= 7 that suffix is at most 8 long: it is the node of the last 8 bases if they form one
+// (bits8 / rank8: states of one depth are numbered in lexicographic order) and otherwise the state the last 7 bases
+// lead to from the root (t7).  Only from states of depth >= 8 (a fifth of the positions) the transition itself is read.
+__global__ __launch_bounds__(TOK_THREADS) void tokenize_kmer_k(TokArgs a) {
+  __shared__ u32 tab[KMER_WORDS];
+  for (u32 i = threadIdx.x; i < KMER_WORDS; i += TOK_THREADS) tab[i] = a.kmer[i];
+  __syncthreads();
+  const u16 *t7 = reinterpret_cast<const u16 *>(tab);
+  const u32 *bits8 = tab + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
+  const u16 *rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+  const u64 r = (u64)blockIdx.x * TOK_THREADS + threadIdx.x;
+  if (r >= a.nrec) return;
+  const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
+  u32 state = 0, best_lv = 0, best_b = a.root_bucket, best_pos = 0, hits = 0, tie = 0, code = 0;
+  const int nw = (a.L + 15) >> 4;
+  for (int w = 0; w < nw; w++) {
+    const u32 word = row[w];
+    const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
+    for (int k = 0; k < cnt; k++) {
+      const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
+      code = ((code << 2) | c) & 0xFFFFu;  // the last 8 bases, the oldest one in the top bits
+      u32 t;
+      if (16 * w + k < 7 || state >= a.id8_first) {
+        t = reinterpret_cast<const u32 *>(a.next)[(u64)state * 4 + c];
+      } else {
+        const u32 wd = bits8[code >> 5], bit = code & 31;
+        if ((wd >> bit) & 1) {
+          t = (a.id8_first + rank8[code >> 5] + (u32)__popc(wd & ((1u << bit) - 1))) | (((out8[code >> 5] >> bit) & 1u) << 31);
+        } else {
+          const u32 e = t7[code & 0x3FFFu];
+          t = (e & 0x7FFFu) | ((e >> 15) << 31);
+        }
+      }
+      state = t & 0x7FFFFFFFu;
+      if (t >> 31) {
+        const u32 info = a.outinfo[state];
         const u32 lv = info >> kLevelShiftD, b = info & kBucketMaskD;
         if (lv > best_lv) {
           best_lv = lv; best_b = b; best_pos = 16 * w + k; hits = 1; tie = 0;

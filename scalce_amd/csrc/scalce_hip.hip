@@ -27,6 +27,8 @@ struct scalce_ctx {
   u32 *d_outinfo = nullptr;
   int32_t *d_bucket_pattern = nullptr;
   u32 *d_bucket_level = nullptr;
+  u32 *d_kmer = nullptr;      // k-mer tables of tokenize_kmer_k, or null when the core table does not qualify
+  u32 id8_first = 0;
   int tok_lds_states = 0;
   u32 *d_simd_load = nullptr;  // per (XCC, SE, SH, CU, SIMD): coder waves resident there (ac_encode_k's role choice)
 };
@@ -76,6 +78,8 @@ static void free_tables(scalce_ctx *c) {
   if (c->d_outinfo) hipFree(c->d_outinfo);
   if (c->d_bucket_pattern) hipFree(c->d_bucket_pattern);
   if (c->d_bucket_level) hipFree(c->d_bucket_level);
+  if (c->d_kmer) hipFree(c->d_kmer);
+  c->d_kmer = nullptr;
   c->d_next = nullptr; c->d_outinfo = nullptr; c->d_bucket_pattern = nullptr; c->d_bucket_level = nullptr;
 }
 
@@ -107,6 +111,62 @@ static int upload_tables(scalce_ctx *c) {
                        hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_bucket_level, A.bucket_level.data(), sizeof(u32) * A.bucket_level.size(),
                        hipMemcpyHostToDevice));
+  {
+    // k-mer tables for tokenize_kmer_k.  Depth of every state = its distance from the root (a transition raises the
+    // depth by at most one and the trie path does); the string of a state of depth 8 follows its first discovery.
+    const u32 ns = (u32)A.n_states;
+    std::vector<int> depth(ns, -1);
+    std::vector<u32> code(ns, 0), order;
+    order.reserve(ns);
+    depth[0] = 0;
+    order.push_back(0);
+    for (size_t h = 0; h < order.size(); h++) {
+      const u32 st = order[h];
+      for (u32 ch = 0; ch < 4; ch++) {
+        const u32 t = A.next[(size_t)st * 4 + ch];
+        if (depth[t] < 0) { depth[t] = depth[st] + 1; code[t] = (code[st] << 2) | ch; order.push_back(t); }
+      }
+    }
+    bool ok = order.size() == ns && !getenv("SCALCE_TOKENIZE_WALK");
+    u32 id8 = ns, n8 = 0;
+    for (u32 st = 0; st < ns && ok; st++) {  // ids are BFS ranks: depth must not decrease with the id
+      if (st && depth[st] < depth[st - 1]) ok = false;
+      if (depth[st] >= 8 && id8 == ns) id8 = st;
+      if (depth[st] == 8) n8++;
+    }
+    if (ok && id8 > 32768) ok = false;  // t7 keeps a state in 15 bits
+    std::vector<u32> tab(KMER_WORDS, 0);
+    if (ok) {
+      u16 *t7 = reinterpret_cast<u16 *>(tab.data());
+      u32 *bits8 = tab.data() + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
+      u16 *rank8 = reinterpret_cast<u16 *>(out8 + KMER_BITS_WORDS);
+      for (u32 x = 0; x < 16384 && ok; x++) {
+        u32 st = 0;
+        for (int j = 0; j < 7; j++) st = A.next[(size_t)st * 4 + ((x >> (12 - 2 * j)) & 3)];
+        if (st >= 32768 || st >= id8) ok = false;
+        t7[x] = (u16)(st | (A.outinfo[st] != kNoOutD ? 0x8000u : 0u));
+      }
+      u32 prev_code = 0;
+      for (u32 i = 0; i < n8 && ok; i++) {  // the depth-8 states: ids id8 .. id8 + n8 - 1 in the order of their 8-mers
+        const u32 st = id8 + i;
+        if (st >= ns || depth[st] != 8 || (i && code[st] <= prev_code)) { ok = false; break; }
+        prev_code = code[st];
+        bits8[code[st] >> 5] |= 1u << (code[st] & 31);
+        if (A.outinfo[st] != kNoOutD) out8[code[st] >> 5] |= 1u << (code[st] & 31);
+      }
+      u32 run = 0;
+      for (u32 wi = 0; wi < KMER_BITS_WORDS && ok; wi++) {
+        if (run > 0xFFFF) ok = false;
+        rank8[wi] = (u16)run;
+        run += (u32)__builtin_popcount(bits8[wi]);
+      }
+    }
+    if (ok) {
+      HIP_TRY(c, hipMalloc(&c->d_kmer, sizeof(u32) * KMER_WORDS));
+      HIP_TRY(c, hipMemcpy(c->d_kmer, tab.data(), sizeof(u32) * KMER_WORDS, hipMemcpyHostToDevice));
+      c->id8_first = id8;
+    }
+  }
   // stage as many leading (shallow) states as fit in 60 KiB of LDS: 2 workgroups per CU stay resident
   int cap = (60 * 1024) / 20;
   c->tok_lds_states = A.n_states < cap ? A.n_states : cap;
@@ -484,7 +544,9 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.packed = b->packed[0].as<u8>(); a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     const size_t sh = (size_t)a.lds_states * 20;
-    if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
+    a.kmer = c->d_kmer; a.id8_first = c->id8_first;
+    if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+    else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
   }
   // tie reads: compact, then size the candidate lists by their hit counts
