@@ -94,13 +94,34 @@ __global__ __launch_bounds__(TOK_THREADS) void tokenize_k(TokArgs a) {
 // BEFORE the base has depth <= 7 that suffix is at most 8 long: it is the node of the last 8 bases if they form one
 // (bits8 / rank8: states of one depth are numbered in lexicographic order) and otherwise the state the last 7 bases
 // lead to from the root (t7).  Only from states of depth >= 8 (a fifth of the positions) the transition itself is read.
+struct KmerTables {  // views of the 52 KB block in LDS
+  const u16 *t7;
+  const u32 *bits8, *out8;
+  const u16 *rank8;
+  u32 id8_first;
+  __device__ __forceinline__ void bind(const u32 *tab, u32 id8) {
+    t7 = reinterpret_cast<const u16 *>(tab);
+    bits8 = tab + KMER_T7_WORDS;
+    out8 = bits8 + KMER_BITS_WORDS;
+    rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+    id8_first = id8;
+  }
+  // transition word (state | has-output << 31) for base c at position pos; `code` = the last 8 bases including c
+  __device__ __forceinline__ u32 step(const u32 *next, u32 state, u32 c, u32 code, int pos) const {
+    if (pos < 7 || state >= id8_first) return next[(u64)state * 4 + c];
+    const u32 wd = bits8[code >> 5], bit = code & 31;
+    if ((wd >> bit) & 1)
+      return (id8_first + rank8[code >> 5] + (u32)__popc(wd & ((1u << bit) - 1))) | (((out8[code >> 5] >> bit) & 1u) << 31);
+    const u32 e = t7[code & 0x3FFFu];
+    return (e & 0x7FFFu) | ((e >> 15) << 31);
+  }
+};
 __global__ __launch_bounds__(TOK_THREADS) void tokenize_kmer_k(TokArgs a) {
   __shared__ u32 tab[KMER_WORDS];
   for (u32 i = threadIdx.x; i < KMER_WORDS; i += TOK_THREADS) tab[i] = a.kmer[i];
   __syncthreads();
-  const u16 *t7 = reinterpret_cast<const u16 *>(tab);
-  const u32 *bits8 = tab + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
-  const u16 *rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+  KmerTables km;
+  km.bind(tab, a.id8_first);
   const u64 r = (u64)blockIdx.x * TOK_THREADS + threadIdx.x;
   if (r >= a.nrec) return;
   const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
@@ -112,18 +133,7 @@ __global__ __launch_bounds__(TOK_THREADS) void tokenize_kmer_k(TokArgs a) {
     for (int k = 0; k < cnt; k++) {
       const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
       code = ((code << 2) | c) & 0xFFFFu;  // the last 8 bases, the oldest one in the top bits
-      u32 t;
-      if (16 * w + k < 7 || state >= a.id8_first) {
-        t = reinterpret_cast<const u32 *>(a.next)[(u64)state * 4 + c];
-      } else {
-        const u32 wd = bits8[code >> 5], bit = code & 31;
-        if ((wd >> bit) & 1) {
-          t = (a.id8_first + rank8[code >> 5] + (u32)__popc(wd & ((1u << bit) - 1))) | (((out8[code >> 5] >> bit) & 1u) << 31);
-        } else {
-          const u32 e = t7[code & 0x3FFFu];
-          t = (e & 0x7FFFu) | ((e >> 15) << 31);
-        }
-      }
+      const u32 t = km.step(reinterpret_cast<const u32 *>(a.next), state, c, code, 16 * w + k);
       state = t & 0x7FFFFFFFu;
       if (t >> 31) {
         const u32 info = a.outinfo[state];
@@ -155,16 +165,24 @@ struct TieArgs {
   u32 *cand_bucket, *cand_pos;
   u32 *tie_ncand;
   u32 lds_states;
+  const u32 *kmer;       // k-mer tables as in TokArgs (USE_KMER)
+  u32 id8_first;
 };
 
-template <bool USE_LDS>
+template <bool USE_LDS, bool USE_KMER = false>
 __global__ __launch_bounds__(TOK_THREADS) void tie_candidates_k(TieArgs a) {
   // same staging of the shallow (hot) states as tokenize_k: the second walk used to go to global memory for every
   // transition and took half as long as the first walk for a fifth of the reads
   extern __shared__ uint4 lds_dyn[];
   uint4 *l_next = lds_dyn;
   u32 *l_out = reinterpret_cast<u32 *>(lds_dyn + a.lds_states);
-  if (USE_LDS) {
+  KmerTables km;
+  if (USE_KMER) {  // the k-mer tables of tokenize_kmer_k instead of the staged states (53 KB of dynamic LDS)
+    u32 *tab = reinterpret_cast<u32 *>(lds_dyn);
+    for (u32 i = threadIdx.x; i < KMER_WORDS; i += TOK_THREADS) tab[i] = a.kmer[i];
+    __syncthreads();
+    km.bind(tab, a.id8_first);
+  } else if (USE_LDS) {
     for (u32 i = threadIdx.x; i < a.lds_states; i += TOK_THREADS) {
       l_next[i] = a.next[i];
       l_out[i] = a.outinfo[i];
@@ -177,19 +195,21 @@ __global__ __launch_bounds__(TOK_THREADS) void tie_candidates_k(TieArgs a) {
   const u32 off = a.tie_off[t];
   const u32 lvmax = a.bucket_level[a.tok_bucket[r]];
   const u32 *row = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
-  u32 state = 0, k = 0;
+  u32 state = 0, k = 0, code = 0;
   const int nw = (a.L + 15) >> 4;
   for (int w = 0; w < nw; w++) {
     const u32 word = row[w];
     const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
     for (int q = 0; q < cnt; q++) {
       const u32 c = (word >> (8 * (q >> 2) + 6 - 2 * (q & 3))) & 3u;
+      code = ((code << 2) | c) & 0xFFFFu;
       u32 tr;
-      if (USE_LDS && state < a.lds_states) tr = reinterpret_cast<const u32 *>(l_next)[state * 4 + c];
+      if (USE_KMER) tr = km.step(reinterpret_cast<const u32 *>(a.next), state, c, code, 16 * w + q);
+      else if (USE_LDS && state < a.lds_states) tr = reinterpret_cast<const u32 *>(l_next)[state * 4 + c];
       else tr = reinterpret_cast<const u32 *>(a.next)[(u64)state * 4 + c];
       state = tr & 0x7FFFFFFFu;
       u32 info = kNoOutD;
-      if (tr >> 31) { if (USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state]; }
+      if (tr >> 31) { if (!USE_KMER && USE_LDS && state < a.lds_states) info = l_out[state]; else info = a.outinfo[state]; }
       if (info != kNoOutD && (info >> kLevelShiftD) == lvmax) {
         const u32 bk = info & kBucketMaskD;
         bool seen = false;

@@ -577,7 +577,9 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.tok_bucket = b->tok_bucket.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_pos = b->cand_pos.as<u32>();
     a.tie_ncand = b->tie_ncand.as<u32>();
     a.lds_states = (u32)c->tok_lds_states;
-    if (a.lds_states) LAUNCH(tie_candidates_k<true>, cdiv(ntie, TOK_THREADS), TOK_THREADS, (size_t)a.lds_states * 20, s, a);
+    a.kmer = c->d_kmer; a.id8_first = c->id8_first;
+    if (c->d_kmer) LAUNCH((tie_candidates_k<false, true>), cdiv(ntie, TOK_THREADS), TOK_THREADS, sizeof(u32) * KMER_WORDS, s, a);
+    else if (a.lds_states) LAUNCH(tie_candidates_k<true>, cdiv(ntie, TOK_THREADS), TOK_THREADS, (size_t)a.lds_states * 20, s, a);
     else LAUNCH(tie_candidates_k<false>, cdiv(ntie, TOK_THREADS), TOK_THREADS, 0, s, a);
     HIP_TRY(c, hipMemsetAsync(b->choice.p, 0, sizeof(u32) * ntie, s));
   }
