@@ -274,6 +274,7 @@ struct scalce_batch {
   u64 *prof_ptr = nullptr;  // SCALCE_AC_PROF of the last rows-coder launch this shard led
   u32 prof_n = 0;
   u32 ent_pending[2] = {0, 0};
+  u32 frame_deferred[2] = {0, 0};  // blocks coded by a grouped launch and not framed yet (entropy_collect frames them)
   // symbol stream to code per mate: the shard's own reordered stream, or one the caller assembled (sharded runs)
   const u8 *ent_sym[2] = {nullptr, nullptr};
   u64 ent_nsym[2] = {0, 0};
@@ -1120,6 +1121,12 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
     b->prof_ptr = nullptr;
   }
   for (int m = 0; m < b->nm; m++) {
+    if (b->frame_deferred[m]) {
+      AcJob j{b, m, nullptr, 0, b->frame_deferred[m], false};
+      b->frame_deferred[m] = 0;
+      int rc = ac_frame(j, s);
+      if (rc) return rc;
+    }
     if (!b->ent_pending[m]) continue;
     u64 total = 0;
     { int rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s); if (rc) return rc; }
@@ -1217,7 +1224,10 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
   if (ac_blocks_per_wg() != 1) bpw = ac_blocks_per_wg();
   int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);
   if (rc) return rc;
-  for (auto &j : jobs) if ((rc = ac_frame(j, s))) return rc;
+  // The framing ([u32 size][bytes] per block: scan of the sizes + one copy kernel, ~5 ms per 50 M-read shard) is left to
+  // entropy_collect, i.e. to the stream the caller collects on: behind the coder on its own stream it lengthened every
+  // launch by the framing of all its shards, and the coder stream is the one the pipeline waits for.
+  for (auto &j : jobs) j.b->frame_deferred[j.m] = j.nblk;
   return SCALCE_OK;
 }
 
