@@ -625,6 +625,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       if (lane == 0) { oflag[0] = 0; oflag[1] = ok1; }
     }
     __syncthreads();
+    __syncthreads();  // the chain wave has read slot 0 (round 0 writes the operands of round 2 there)
     for (u32 r = 0; r < nrounds; r++) {
       const uint4 o2 = lookup(sy_a, sy_b, (r + 2) << 6);   // lands while the bits of round r - 1 are packed
       const u32 sy_c = sym_at(((r + 3) << 6) + lane);
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
     // ================= chain wave: nothing but the coder state =================
     __syncthreads();  // operands of rounds 0 and 1 are in LDS
     uint4 cur = opsb[0][lane];
+    __syncthreads();  // ... and slot 0 is in registers
     u32 cur_ok = 0;
     for (u32 r = 0; r < nrounds; r++) {
       const u32 base = r << 6;
@@ -792,6 +794,15 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
   // Roles.  The chain wave must have a SIMD to itself; the waves of a workgroup go to the CU's four SIMDs in turn, so
   // with five waves (R = 8) two of them share one.  The chain is the first wave whose SIMD no other wave of the
   // workgroup sits on, the others are helpers in wave order.
+#ifdef AC_DEBUG_ZERO_LDS
+  for (u32 i = threadIdx.x; i < sizeof(rec) / 4; i += blockDim.x) reinterpret_cast<u32 *>(rec)[i] = AC_DEBUG_ZERO_LDS;
+  for (u32 i = threadIdx.x; i < sizeof(opsb) / 4; i += blockDim.x) reinterpret_cast<u32 *>(opsb)[i] = AC_DEBUG_ZERO_LDS;
+  for (u32 i = threadIdx.x; i < sizeof(bufs) / 4; i += blockDim.x) reinterpret_cast<u32 *>(bufs)[i] = AC_DEBUG_ZERO_LDS;
+  for (u32 i = threadIdx.x; i < sizeof(recfmt) / 4; i += blockDim.x) reinterpret_cast<u32 *>(recfmt)[i] = AC_DEBUG_ZERO_LDS;
+  for (u32 i = threadIdx.x; i < sizeof(oflag) / 4; i += blockDim.x) reinterpret_cast<u32 *>(oflag)[i] = AC_DEBUG_ZERO_LDS;
+  for (u32 i = threadIdx.x; i < sizeof(final_lo) / 4; i += blockDim.x) reinterpret_cast<u32 *>(final_lo)[i] = AC_DEBUG_ZERO_LDS;
+  __syncthreads();
+#endif
   if (lane == 0) wave_simd[wave_id()] = simd_key() & 3u;
   __syncthreads();
   int chain_w = 0;
@@ -889,6 +900,10 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sink[e].to_buffered(e ? buf1 : buf0, lane);  // the two raw symbols of the block open its buffer
     }
     __syncthreads();
+    // ... and the chain wave has taken slot 0 into registers before super-round 0 puts the operands of super-round 2
+    // there.  (Every later slot is read a whole super-round before it is overwritten; this first hand-over was not, and
+    // once the helpers stopped waiting for their loads they could win the race: a block coded wrongly now and then.)
+    __syncthreads();
     u64 hprof_wait = 0;
     const u64 hprof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     auto super_round = [&](auto first, const u32 r, uint4 (&o_use)[2], u32 (&s_use)[2], uint4 (&o_load)[2], u32 (&s_load)[2]) {
@@ -971,6 +986,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     uint4 cur[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) cur[q] = opsb[0][row][q * R + col];
+    __syncthreads();  // slot 0 is in registers: the helpers may overwrite it (see their side)
     u32 cur_ok = 0;
     u64 prof_wait = 0;
     const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;

@@ -361,14 +361,19 @@ __global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, u32 prev0
 constexpr u32 TRI_TILE = 64 * 1024;
 __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 pass,
                                                              const u32 *range, u64 *freq4, unsigned long long *tile_counter) {
+  // Counters are 16-bit fields, two per word: twice the leading symbols per pass (a 39-symbol alphabet in ONE streaming
+  // pass, the full 80 in nine instead of twenty).  LDS has 32-bit atomics only, so a field must never carry into its
+  // neighbour: bit 15 is a guard -- the add that finds 0x7FFF takes 32768 off the field again and moves them to the
+  // global table.  A carry would need 32768 more adds to land on the same field between two consecutive
+  // instructions of that thread; tri_check_k compares the table's total with the number of symbols all the same.
   __shared__ u32 tab[TRI_CAP];
   const u32 lo = range[0], A = range[1];
   if (A == 0) return;
-  const u32 AA = A * A, width = TRI_CAP / AA;  // leading symbols per pass (>= 4)
+  const u32 AA = A * A, width = (2 * TRI_CAP) / AA;  // leading symbols per pass (>= 9)
   const u32 d0 = pass * width;
   if (d0 >= A) return;                          // the alphabet is done
   const u32 used = (A - d0 < width ? A - d0 : width) * AA;
-  for (u32 i = threadIdx.x; i < used; i += TRI_THREADS) tab[i] = 0;
+  for (u32 i = threadIdx.x; i < (used + 1) / 2; i += TRI_THREADS) tab[i] = 0;
   __syncthreads();
   const u32 first = lo + d0;                    // leading symbols [first, first + width) belong to this pass
   const int lane = lane_id();
@@ -396,7 +401,14 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
     for (int k = 0; k < 16; k++) {
       const u32 c = (w[k >> 2] >> (8 * (k & 3))) & 255u;
       const u32 d = a - first, bb = b - lo, cc = c - lo;  // unsigned: anything outside its range fails the test
-      if (k < cnt && d < width && bb < A && cc < A) atomicAdd(&tab[d * AA + bb * A + cc], 1u);
+      if (k < cnt && d < width && bb < A && cc < A) {
+        const u32 i = d * AA + bb * A + cc, sh = (i & 1u) * 16;
+        const u32 old = atomicAdd(&tab[i >> 1], 1u << sh);
+        if (((old >> sh) & 0xFFFFu) == 0x7FFFu) {  // the field just reached 2^15
+          atomicSub(&tab[i >> 1], 0x8000u << sh);
+          atomicAdd(&freq4[((u64)(first + d) * 80 + lo + bb) * 80 + lo + cc], 32768ull);
+        }
+      }
       a = b;
       b = c;
     }
@@ -404,10 +416,32 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
   }
   __syncthreads();
   for (u32 i = threadIdx.x; i < used; i += TRI_THREADS) {
-    const u32 v = tab[i];
+    const u32 v = (tab[i >> 1] >> ((i & 1u) * 16)) & 0xFFFFu;
     if (v) {
       const u32 d = i / AA, rem = i - d * AA, bb = rem / A, cc = rem - bb * A;
       atomicAdd(&freq4[((u64)(first + d) * 80 + lo + bb) * 80 + lo + cc], (u64)v);
+    }
+  }
+}
+
+// every symbol that has two predecessors was counted once: the sum of the table says so (see trigram_pass_k)
+__global__ __launch_bounds__(256) void tri_check_k(const u64 *freq4, u64 expected, u64 *acc /* zeroed */, u32 *done /* zeroed */,
+                                                  DevErr *err) {
+  __shared__ u64 part[256];
+  u64 sum = 0;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < 512000u; i += gridDim.x * blockDim.x) sum += freq4[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)part[0]);
+    __threadfence();
+    if (atomicAdd(done, 1u) == gridDim.x - 1) {
+      const u64 total = atomicAdd(reinterpret_cast<unsigned long long *>(acc), 0ull);
+      if (total != expected) dev_fail(err, E_INTERNAL, total, 16);
     }
   }
 }

@@ -19,9 +19,11 @@ typedef unsigned char u8;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 // Workgroup barrier for waves that only exchange data through LDS: __syncthreads() is a fence as well and drains the
 // global loads and stores in flight (s_waitcnt vmcnt(0)) in front of every barrier -- no prefetch survives it.
+// (One asm statement with a memory clobber: to the compiler the s_barrier builtin touches no memory, so on its own it
+// lets LDS reads of the next super-round be hoisted above the barrier -- a race that shows as a block coded wrongly
+// once in a few runs.)
 __device__ __forceinline__ void barrier_lds_only() {
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt and expcnt left alone
-  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

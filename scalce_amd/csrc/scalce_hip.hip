@@ -505,6 +505,14 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
       LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0], b->p.qprev[m][1], pass, range,
              b->freq4[m].as<u64>(), tiles);
+    {  // one count per symbol with two predecessors (the shard's first two have them only when the caller passed qprev)
+      const bool p0 = b->p.qprev[m][0] < 80, p1 = b->p.qprev[m][1] < 80;
+      const u64 skip = p1 ? (p0 ? 0 : 1) : 2;
+      const u64 expected = n > skip ? n - skip : 0;
+      u64 *acc = b->d_small64 + 400 + 2 * m;
+      HIP_TRY(c, hipMemsetAsync(acc, 0, 2 * sizeof(u64), s));
+      LAUNCH(tri_check_k, 64, 256, 0, s, b->freq4[m].as<u64>(), expected, acc, reinterpret_cast<u32 *>(acc + 1), b->d_err);
+    }
   }
   return SCALCE_OK;
 }
