@@ -171,7 +171,7 @@ def main():
 
     traffic, traffic_src = None, None
     kname = "ac_encode_rows_k" if G > 1 else "ac_encode_k"
-    pmc = os.path.join(ROOT, "profiles", "r01_v16_bench50m_pmc_fetch_write.json" if G > 1 else "r01_v9_bench50m_pmc_fetch_write.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_v17_bench50m_pmc_fetch_write.json" if G > 1 else "r01_v9_bench50m_pmc_fetch_write.json")
     if rank == 0 and n == 50_000_000 and L == 100 and os.path.exists(pmc):
         # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of
         # KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM")
