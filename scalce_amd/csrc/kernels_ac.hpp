@@ -794,15 +794,6 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
   // Roles.  The chain wave must have a SIMD to itself; the waves of a workgroup go to the CU's four SIMDs in turn, so
   // with five waves (R = 8) two of them share one.  The chain is the first wave whose SIMD no other wave of the
   // workgroup sits on, the others are helpers in wave order.
-#ifdef AC_DEBUG_ZERO_LDS
-  for (u32 i = threadIdx.x; i < sizeof(rec) / 4; i += blockDim.x) reinterpret_cast<u32 *>(rec)[i] = AC_DEBUG_ZERO_LDS;
-  for (u32 i = threadIdx.x; i < sizeof(opsb) / 4; i += blockDim.x) reinterpret_cast<u32 *>(opsb)[i] = AC_DEBUG_ZERO_LDS;
-  for (u32 i = threadIdx.x; i < sizeof(bufs) / 4; i += blockDim.x) reinterpret_cast<u32 *>(bufs)[i] = AC_DEBUG_ZERO_LDS;
-  for (u32 i = threadIdx.x; i < sizeof(recfmt) / 4; i += blockDim.x) reinterpret_cast<u32 *>(recfmt)[i] = AC_DEBUG_ZERO_LDS;
-  for (u32 i = threadIdx.x; i < sizeof(oflag) / 4; i += blockDim.x) reinterpret_cast<u32 *>(oflag)[i] = AC_DEBUG_ZERO_LDS;
-  for (u32 i = threadIdx.x; i < sizeof(final_lo) / 4; i += blockDim.x) reinterpret_cast<u32 *>(final_lo)[i] = AC_DEBUG_ZERO_LDS;
-  __syncthreads();
-#endif
   if (lane == 0) wave_simd[wave_id()] = simd_key() & 3u;
   __syncthreads();
   int chain_w = 0;
