@@ -484,3 +484,23 @@ def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
     bad = np.flatnonzero(got != sym)
     assert len(bad) == 0, f"{case}: decoded stream differs first at {bad[:5]}: {got[bad[:5]]} vs {sym[bad[:5]]}"
 
+
+
+@pytest.mark.gpu
+def test_rows_coder_repeated_launches(ctx, oracle_trie, monkeypatch):
+    """The same two-block shard through the four- and eight-blocks-per-wave coder a dozen times, every result against
+    the oracle's bytes: the hand-over of the first operand slot between helper and chain waves once raced (a block coded
+    wrongly in one launch out of a few), which a single launch per test rarely showed."""
+    from gpu_util import hip_compress, oracle_streams
+    bases, quals = synth.reads_and_quals(150_000, 100, seed=78)
+    fq = synth.fastq_bytes_fast(bases, quals)
+    ref = oracle_streams(oracle_trie, bases, quals, 33, None)
+    want = None
+    for rep in range(6):
+        for bpw in ("8", "4"):
+            monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", bpw)
+            b = hip_compress(ctx, fq, 100)
+            if want is None:
+                want = O.AcStat(b.output(host.OUT_TABLE, 0, np.uint32)).encode_stream(ref["qp"][ref["perm"]].reshape(-1))
+            enc = b.output(host.OUT_QUAL, 0)
+            assert len(enc) == len(want) and (enc == want).all(), f"launch {rep} with {bpw} blocks per wave differs"
