@@ -489,8 +489,10 @@ def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
 @pytest.mark.gpu
 def test_rows_coder_repeated_launches(ctx, oracle_trie, monkeypatch):
     """The same two-block shard through the four- and eight-blocks-per-wave coder a dozen times, every result against
-    the oracle's bytes: the hand-over of the first operand slot between helper and chain waves once raced (a block coded
-    wrongly in one launch out of a few), which a single launch per test rarely showed."""
+    the oracle's bytes.  (The hand-over of the first operand slot between helper and chain waves once raced: a block
+    coded wrongly in one launch out of a few.  It showed in test_rows_coder_redo_path[8] when it ran behind
+    test_grouped_coder_launch_equals_separate_launches -- keep those two in that order -- and not in this loop on its
+    own; repetition is cheap all the same.)"""
     from gpu_util import hip_compress, oracle_streams
     bases, quals = synth.reads_and_quals(150_000, 100, seed=78)
     fq = synth.fastq_bytes_fast(bases, quals)
