@@ -137,12 +137,15 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8 *t, u64 at, u64 n) {
 
 // One record: bases -> 2-bit row (global), qualities -> q' (through `qrow`, LDS or global), name length.
 // `word(at)` returns the aligned little-endian 32-bit word that contains text byte `at & ~3`.
-template <typename WordAt, typename ByteAt>
+// PART: 3 = the whole record; 1 = bases + name only, 2 = qualities only (unpack_tiled_k gives a record to two threads of
+// different waves: the work of a thread is a long chain of dependent instructions, and with the 40 KB tile per 128
+// records only two waves per SIMD were resident to hide it).
+template <int PART = 3, typename WordAt, typename ByteAt>
 __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const u8 *lut, WordAt word, ByteAt byte_at, u8 *qrow,
                                               bool qrow_aligned) {
   const u64 p0 = a.line_end[4 * r], p1 = a.line_end[4 * r + 1], p2 = a.line_end[4 * r + 2], p3 = a.line_end[4 * r + 3];
   if (p1 - p0 - 1 != (u64)a.L || p3 - p2 - 1 != (u64)a.L) {
-    dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
+    if (PART & 1) dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
     return;
   }
   const int L = a.L;
@@ -166,13 +169,16 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
       vb &= keep;
       vq &= keep;
     }
-    acc |= pack4(vb) << (8 * nacc);
-    if (++nacc == 4) {
-      *reinterpret_cast<u32 *>(prow + 4 * wout) = acc;
-      wout++;
-      acc = 0;
-      nacc = 0;
+    if (PART & 1) {
+      acc |= pack4(vb) << (8 * nacc);
+      if (++nacc == 4) {
+        *reinterpret_cast<u32 *>(prow + 4 * wout) = acc;
+        wout++;
+        acc = 0;
+        nacc = 0;
+      }
     }
+    if (!(PART & 2)) continue;
     // q' (qualities.cpp:183): exactly 'N' forces the offset, i.e. symbol 0
     const u32 isN = (zero_bytes(vb ^ 0x4E4E4E4Eu) >> 7) * 0xFFu;
     u32 qq;
@@ -197,12 +203,13 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
     }
     if (!a.no_ac && ((((qq & 0x7F7F7F7Fu) + 0x30303030u) | qq) & 0x80808080u)) bad = true;  // a byte >= 80
   }
+  if (bad) dev_fail(a.err, E_SYMBOL, r);
+  if (!(PART & 1)) return;
   // flush the partial word and zero the rest of the row
   for (int w = wout; w < a.stride / 4; w++) {
     *reinterpret_cast<u32 *>(prow + 4 * w) = acc;
     acc = 0;
   }
-  if (bad) dev_fail(a.err, E_SYMBOL, r);
   if (a.mate == 0) {
     // output_name, names.cpp:55-57: characters after '@' up to the first space or the newline
     const u64 ns = r ? a.line_end[4 * r - 1] + 1 : 0;
@@ -243,14 +250,14 @@ constexpr int UNP_RPB = 128;
 constexpr int UNP_Q_CAP = 20 * 1024;  // UNP_RPB * L must fit: L <= 160
 __host__ __device__ inline u32 unp_text_cap(int L) { return (u32)(((UNP_RPB * (2 * L + 20) + 64) + 15) & ~15); }
 __host__ __device__ inline u32 unp_q_cap(int L) { return (u32)((UNP_RPB * L + 15) & ~15); }
-__global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
+__global__ __launch_bounds__(2 * UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
   extern __shared__ __attribute__((aligned(16))) u8 unp_lds[];
   const u32 UNP_TEXT_CAP = unp_text_cap(a.L);
   u8 *tile = unp_lds;
   u8 *qt = unp_lds + UNP_TEXT_CAP + 32;
   __shared__ u8 lut[128];
   const int tid = threadIdx.x;
-  lut[tid] = a.qlut[tid];
+  if (tid < 128) lut[tid] = a.qlut[tid];
   const u64 r0 = (u64)blockIdx.x * UNP_RPB;
   const u64 r1 = r0 + UNP_RPB < a.nrec ? r0 + UNP_RPB : a.nrec;
   const u64 span0 = r0 ? a.line_end[4 * r0 - 1] + 1 : 0;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
   const u64 tbytes = span1 - a0;
   const bool in_lds = tbytes <= (u64)UNP_TEXT_CAP;  // uniform for the workgroup
   if (in_lds) {
-    for (u64 i = (u64)tid * 16; i < tbytes + 8; i += (u64)UNP_RPB * 16) {  // +8: the funnel fetch may touch the next word
+    for (u64 i = (u64)tid * 16; i < tbytes + 8; i += (u64)(2 * UNP_RPB) * 16) {  // +8: the funnel fetch may touch the next word
       uint4 v;
       if (a0 + i + 16 <= a.nbytes) v = *reinterpret_cast<const uint4 *>(a.text + a0 + i);
       else {
@@ -272,28 +279,36 @@ __global__ __launch_bounds__(UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
     }
   }
   __syncthreads();
-  const u64 r = r0 + tid;
+  // waves 0, 1: bases and name of record tid; waves 2, 3: the qualities of record tid - UNP_RPB
+  const int rec = tid & (UNP_RPB - 1);
+  const bool second = tid >= UNP_RPB;
+  const u64 r = r0 + rec;
   if (r < r1) {
-    u8 *qrow = qt + (size_t)tid * a.L;
+    u8 *qrow = qt + (size_t)rec * a.L;
     const bool al = ((a.L & 3) == 0);
-    if (in_lds)
-      unpack_record(a, r, lut, [&](u64 at) { return *reinterpret_cast<const u32 *>(tile + ((at & ~3ull) - a0)); },
-                    [&](u64 at) { return tile[at - a0]; }, qrow, al);
-    else
-      unpack_record(a, r, lut, [&](u64 at) { return load_word(a.text, at & ~3ull, a.nbytes); },
-                    [&](u64 at) { return a.text[at]; }, qrow, al);
+    auto w_lds = [&](u64 at) { return *reinterpret_cast<const u32 *>(tile + ((at & ~3ull) - a0)); };
+    auto b_lds = [&](u64 at) { return tile[at - a0]; };
+    auto w_glb = [&](u64 at) { return load_word(a.text, at & ~3ull, a.nbytes); };
+    auto b_glb = [&](u64 at) { return a.text[at]; };
+    if (in_lds) {
+      if (second) unpack_record<2>(a, r, lut, w_lds, b_lds, qrow, al);
+      else unpack_record<1>(a, r, lut, w_lds, b_lds, qrow, al);
+    } else {
+      if (second) unpack_record<2>(a, r, lut, w_glb, b_glb, qrow, al);
+      else unpack_record<1>(a, r, lut, w_glb, b_glb, qrow, al);
+    }
   }
   __syncthreads();
   // q' rows of this workgroup are one contiguous range of the output
   const u64 qbytes = (r1 - r0) * (u64)a.L;
   u8 *qdst = a.q + r0 * (u64)a.L;
   if ((((u64)qdst) & 15) == 0) {
-    for (u64 i = (u64)tid * 16; i < qbytes; i += (u64)UNP_RPB * 16) {
+    for (u64 i = (u64)tid * 16; i < qbytes; i += (u64)(2 * UNP_RPB) * 16) {
       if (i + 16 <= qbytes) *reinterpret_cast<uint4 *>(qdst + i) = *reinterpret_cast<const uint4 *>(qt + i);
       else for (u64 k = i; k < qbytes; k++) qdst[k] = qt[k];
     }
   } else {
-    for (u64 i = tid; i < qbytes; i += UNP_RPB) qdst[i] = qt[i];
+    for (u64 i = tid; i < qbytes; i += 2 * UNP_RPB) qdst[i] = qt[i];
   }
 }
 

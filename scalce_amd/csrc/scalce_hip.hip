@@ -475,7 +475,7 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
     a.qlut = b->d_qlut[mate]; a.err = b->d_err;
     a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
     if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
-      LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
+      LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
     else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
   }
   b->ingested[mate] = true;
