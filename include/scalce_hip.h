@@ -143,6 +143,10 @@ int scalce_batch_entropy_stream_begin(scalce_batch *b, int mate, const uint32_t 
 /* ... or only remembered, to be coded by the next scalce_batch_entropy_begin_group that includes this shard. */
 int scalce_batch_entropy_stream_prepare(scalce_batch *b, int mate, const uint32_t *d_table, const uint8_t *d_symbols,
                                         uint64_t nsym, void *stream);
+/* Table scaling on its own (compress.cpp:297-313): d_table[i] = max(1, (1 + d_counters[i]) / factor) for the 512000
+ * counters of one mate (SCALCE_OUT_FREQ4 layout: raw trigram counts; the reference's counters all start at 1,
+ * qualities.cpp:191-196).  factor = 1 + symbols / (2^32 - 1) over the RUN (:297-303). */
+int scalce_ac_scale(scalce_ctx *ctx, const uint64_t *d_counters, uint32_t factor, uint32_t *d_table, void *stream);
 /* Piecewise device copy: dst[piece_dst[p] + i] = src[piece_src[p] + i]; pieces contiguous in src, sorted. */
 int scalce_copy_pieces(scalce_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, const uint64_t *d_piece_src,
                        const uint64_t *d_piece_dst, uint32_t npieces, uint64_t total_bytes, void *stream);

@@ -13,9 +13,15 @@
  * framing, bin_dump, compress(), decompress().  Those call f_gets/f_read/f_write,
  * which stay unresolved in this binary and are never called.
  *
- * usage: ref_driver <fastq> <outdir> [-P patterns.txt] [-q qmap.txt] [-n] [-t]
+ * usage: ref_driver <fastq> <outdir> [-P patterns.txt] [-q qmap.txt] [-2 fastq2 [-q2 qmap2.txt]] [-f factor] [-n] [-t]
  *   -P  text core list (read_patterns_from_file) instead of the embedded patterns.bin
  *   -q  file with 129 integers: offset, values[0..127]  (default: offset 33, identity)
+ *   -2  second mate (-r): every record also goes through output_read(read2, .., 0, 0) and
+ *       output_quality(qual2, read2, qmap + 1, .., 1) exactly as thread() does (compress.cpp:692-699);
+ *       packed2.bin / qual2.bin / freq4_2.u64 / ac2.bin are the mate-2 streams (same record order)
+ *   -f  shrink factor of compress.cpp:297-313 applied to the counters before ac_stat is built
+ *       (p = p / factor, 0 -> 1: those three lines live in the final writer, which needs buffio and
+ *       is not linked, so they are repeated here); table.u32 / table2.u32 hold the scaled table
  *   -n  names off (-n lib)
  *   -t  timing mode (bench.py's cpu_baseline of kind "reference"): the compress path only -- no decoder check,
  *       nothing but ac.bin is written -- and the seconds spent in it go to stderr
@@ -68,33 +74,45 @@ static void dump(const std::string &path, const void *p, size_t n) {
 int main(int argc, char **argv) {
   if (argc < 3) { fprintf(stderr, "usage: ref_driver <fastq> <outdir> [-P txt] [-q qmap] [-n]\n"); return 2; }
   std::string fq = argv[1], out = argv[2];
-  const char *ptxt = 0, *qfile = 0;
-  int timing = 0;
+  const char *ptxt = 0, *qfile = 0, *qfile2 = 0, *fq2 = 0;
+  int timing = 0, factor = 1;
   for (int i = 3; i < argc; i++) {
     if (!strcmp(argv[i], "-P") && i + 1 < argc) ptxt = argv[++i];
     else if (!strcmp(argv[i], "-q") && i + 1 < argc) qfile = argv[++i];
+    else if (!strcmp(argv[i], "-q2") && i + 1 < argc) qfile2 = argv[++i];
+    else if (!strcmp(argv[i], "-2") && i + 1 < argc) { fq2 = argv[++i]; _use_second_file = 1; }
+    else if (!strcmp(argv[i], "-f") && i + 1 < argc) factor = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-n")) _use_names = 0;
     else if (!strcmp(argv[i], "-t")) timing = 1;
   }
   struct timespec ts0;
   clock_gettime(CLOCK_MONOTONIC, &ts0);
-  quality_mapping qm;
-  qm.offset = 33;
-  for (int i = 0; i < 128; i++) qm.values[i] = i;
-  if (qfile) {
-    FILE *f = fopen(qfile, "r");
-    if (!f || fscanf(f, "%d", &qm.offset) != 1) { fprintf(stderr, "bad qmap\n"); return 2; }
-    for (int i = 0; i < 128; i++) if (fscanf(f, "%d", &qm.values[i]) != 1) { fprintf(stderr, "bad qmap\n"); return 2; }
-    fclose(f);
+  quality_mapping qmaps[2];
+  const char *qfiles[2] = {qfile, qfile2};
+  for (int m = 0; m < 2; m++) {
+    quality_mapping &q = qmaps[m];
+    q.offset = 33;
+    for (int i = 0; i < 128; i++) q.values[i] = i;
+    if (qfiles[m]) {
+      FILE *f = fopen(qfiles[m], "r");
+      if (!f || fscanf(f, "%d", &q.offset) != 1) { fprintf(stderr, "bad qmap\n"); return 2; }
+      for (int i = 0; i < 128; i++) if (fscanf(f, "%d", &q.values[i]) != 1) { fprintf(stderr, "bad qmap\n"); return 2; }
+      fclose(f);
+    }
   }
+  quality_mapping &qm = qmaps[0];
 
   aho_trie *trie = ptxt ? read_patterns_from_file(ptxt) : read_patterns();
 
   FILE *f = fopen(fq.c_str(), "r");
   if (!f) { perror(fq.c_str()); return 2; }
+  FILE *f2 = fq2 ? fopen(fq2, "r") : 0;
+  if (fq2 && !f2) { perror(fq2); return 2; }
   static char name[MAXLINE], read[MAXLINE], plus[MAXLINE], qual[MAXLINE];
+  static char name2[MAXLINE], read2[MAXLINE], plus2[MAXLINE], qual2[MAXLINE];
   std::vector<int32_t> tok;
-  std::vector<uint8_t> packed, names, quals;
+  std::vector<uint8_t> packed, names, quals, packed2, quals2;
+  int L2 = 0;
   std::vector<bin_node *> nodes_in_order;
   uint8_t outbuf[MAXLINE * 5];
   int64_t N = 0;
@@ -121,6 +139,19 @@ int main(int argc, char **argv) {
     rd.sz += output_quality(qual, read, &qm, rd.data + rd.sz, 0);
     quals.insert(quals.end(), rd.data + before, rd.data + rd.sz);
     rd.of = rd.sz;
+    if (f2) { /* compress.cpp:692-699: the mate is never searched for a core */
+      if (!(fgets(name2, MAXLINE, f2) && fgets(read2, MAXLINE, f2) && fgets(plus2, MAXLINE, f2) && fgets(qual2, MAXLINE, f2))) {
+        fprintf(stderr, "mate 2 is shorter than mate 1\n");
+        return 2;
+      }
+      if (!L2) { L2 = strlen(read2) - 1; read_length[1] = L2; }
+      before = rd.sz;
+      rd.sz += output_read(read2, rd.data + rd.sz, 0, 0);
+      packed2.insert(packed2.end(), rd.data + before, rd.data + rd.sz);
+      before = rd.sz;
+      rd.sz += output_quality(qual2, read2, &qmaps[1], rd.data + rd.sz, 1);
+      quals2.insert(quals2.end(), rd.data + before, rd.data + rd.sz);
+    }
     rd.read_length = (int32_t)N; /* unused outside PACBIO builds: carries the input index */
     bin_node *bn = aho_trie_bucket(bucket, &rd);
     memcpy(bn->data.data, rd.data, rd.sz);
@@ -137,7 +168,13 @@ int main(int argc, char **argv) {
     dump(out + "/names.bin", names.data(), names.size());
     dump(out + "/qual.bin", quals.data(), quals.size());
     dump(out + "/freq4.u64", ac_freq4[0], sizeof(uint64_t) * AC_DEPTH * AC_DEPTH * AC_DEPTH);
+    if (f2) {
+      dump(out + "/packed2.bin", packed2.data(), packed2.size());
+      dump(out + "/qual2.bin", quals2.data(), quals2.size());
+      dump(out + "/freq4_2.u64", ac_freq4[1], sizeof(uint64_t) * AC_DEPTH * AC_DEPTH * AC_DEPTH);
+    }
   }
+  if (f2) fclose(f2);
 
   /* pattern -> BFS id (reads.cpp:296): walk each core through the automaton */
   int np = 0;
@@ -184,29 +221,41 @@ int main(int argc, char **argv) {
   }
   if (!timing) dump(out + "/order.i64", order.data(), order.size() * 8);
 
-  /* arithmetic coder on the reordered quality stream, factor 1 (N*L < 2^32) */
-  std::vector<uint8_t> qs((size_t)N * L);
-  for (int64_t k = 0; k < N; k++) memcpy(&qs[(size_t)k * L], &quals[(size_t)order[k] * L], L);
-  static ac_stat as;
-  for (int i = 0; i < AC_DEPTH * AC_DEPTH * AC_DEPTH; i++) if (!ac_freq4[0][i]) ac_freq4[0][i] = 1;
-  as = ac_stat(ac_freq3[0], ac_freq4[0]);
+  /* arithmetic coder on the reordered quality stream(s); the table is scaled by `factor` first (1 when N*L < 2^32) */
   const size_t BS = 10 * 1024 * 1024;
   std::vector<uint8_t> enc, blk(BS * 2), dec(BS);
   size_t bad = 0;
-  for (size_t off = 0; off < qs.size(); off += BS) {
-    size_t n = qs.size() - off < BS ? qs.size() - off : BS;
-    ac_coder ax(blk.data(), &as);
-    ax.write(&qs[off], (int)n);
-    ax.flush();
-    uint32_t sz = (uint32_t)(ax.output() - blk.data());
-    enc.insert(enc.end(), (uint8_t *)&sz, (uint8_t *)&sz + 4);
-    enc.insert(enc.end(), blk.data(), blk.data() + sz);
-    if (timing) continue;
-    ac_decoder ad(&as, blk.data());
-    ad.read(dec.data(), (int)n);
-    if (memcmp(dec.data(), &qs[off], n)) bad++;
+  for (int m = 0; m < (f2 ? 2 : 1); m++) {
+    const int Lm = m ? L2 : L;
+    const std::vector<uint8_t> &qin = m ? quals2 : quals;
+    std::vector<uint8_t> qs((size_t)N * Lm);
+    for (int64_t k = 0; k < N; k++) memcpy(&qs[(size_t)k * Lm], &qin[(size_t)order[k] * Lm], Lm);
+    static ac_stat as;
+    std::vector<uint32_t> table(AC_DEPTH * AC_DEPTH * AC_DEPTH);
+    for (int i = 0; i < AC_DEPTH * AC_DEPTH * AC_DEPTH; i++) {
+      uint64_t *p = &ac_freq4[m][i];
+      *p = *p / factor; /* compress.cpp:310-313 */
+      if (*p == 0) *p = 1;
+      table[i] = (uint32_t)*p;
+    }
+    if (!timing) dump(out + (m ? "/table2.u32" : "/table.u32"), table.data(), table.size() * 4);
+    as = ac_stat(ac_freq3[m], ac_freq4[m]);
+    enc.clear();
+    for (size_t off = 0; off < qs.size(); off += BS) {
+      size_t n = qs.size() - off < BS ? qs.size() - off : BS;
+      ac_coder ax(blk.data(), &as);
+      ax.write(&qs[off], (int)n);
+      ax.flush();
+      uint32_t sz = (uint32_t)(ax.output() - blk.data());
+      enc.insert(enc.end(), (uint8_t *)&sz, (uint8_t *)&sz + 4);
+      enc.insert(enc.end(), blk.data(), blk.data() + sz);
+      if (timing) continue;
+      ac_decoder ad(&as, blk.data());
+      ad.read(dec.data(), (int)n);
+      if (memcmp(dec.data(), &qs[off], n)) bad++;
+    }
+    dump(out + (m ? "/ac2.bin" : "/ac.bin"), enc.data(), enc.size());
   }
-  dump(out + "/ac.bin", enc.data(), enc.size());
   if (timing) {
     struct timespec ts1;
     clock_gettime(CLOCK_MONOTONIC, &ts1);

@@ -1019,7 +1019,12 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
           const u32 nr = block_len(blk0 + rw);
           const u32 rest = nr - (r << 6);
           const u32 jend = rest < 64 ? rest : 64, jstart = (r == 0) ? 2u : 0u;
-          u32 glo = __builtin_amdgcn_readlane(s_lo, rw * R + R - 1) & 0x7FFFFFFFu;
+          // The systolic path lets lo travel with a stray bit 31 (sys_step), which is removed here.  Under GENERAL the
+          // state only ever comes from ac_step<true>, where bit 31 of lo is real (lo = 1.., hi = 0.. is a state the
+          // reference's 32-bit coder runs into once a context total passes 2^30): lo goes through untouched and
+          // hi = lo + M - 1 modulo 2^32 is exact for inverted intervals as well.
+          u32 glo = __builtin_amdgcn_readlane(s_lo, rw * R + R - 1);
+          if (!GENERAL) glo &= 0x7FFFFFFFu;
           u32 ghi = glo + __builtin_amdgcn_readlane(s_M, rw * R + R - 1) - 1;
 #pragma unroll
           for (int q = 0; q < NQ; q++) {

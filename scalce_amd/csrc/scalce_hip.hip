@@ -1287,6 +1287,13 @@ extern "C" int scalce_batch_entropy_stream(scalce_batch *b, int mate, const uint
   return entropy_collect(b, (hipStream_t)stream);
 }
 
+extern "C" int scalce_ac_scale(scalce_ctx *c, const uint64_t *d_counters, uint32_t factor, uint32_t *d_table, void *stream) {
+  if (!c || !d_counters || !d_table || !factor) return SCALCE_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  LAUNCH(ac_scale_k, cdiv(512000, 256), 256, 0, (hipStream_t)stream, reinterpret_cast<const u64 *>(d_counters), factor, d_table);
+  return SCALCE_OK;
+}
+
 // dst[piece_dst[p] + i] = src[piece_src[p] + i] for i < piece_len[p]; pieces sorted by piece_src, contiguous in src
 extern "C" int scalce_copy_pieces(scalce_ctx *c, const uint8_t *d_src, uint8_t *d_dst, const uint64_t *d_piece_src,
                                   const uint64_t *d_piece_dst, uint32_t npieces, uint64_t total_bytes, void *stream) {

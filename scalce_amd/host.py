@@ -102,6 +102,7 @@ def lib():
     L.scalce_batch_tokenize_end.argtypes = [vp, vp]
     L.scalce_batch_set_chunks.argtypes = [vp, C.POINTER(u64), C.c_uint32]
     L.scalce_batch_entropy_stream.argtypes = [vp, i32, vp, vp, u64, vp]
+    L.scalce_ac_scale.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.scalce_copy_pieces.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, u64, vp]
     L.scalce_patterns_describe_host.argtypes = [C.c_char_p, C.c_size_t, i32, vp, C.c_size_t, C.POINTER(C.c_int32),
                                                 C.POINTER(C.c_int32)]
@@ -179,6 +180,10 @@ class Context:
 
     def copy_pieces(self, d_src, d_dst, d_piece_src, d_piece_dst, npieces, total, stream=0):
         self._check(self.L.scalce_copy_pieces(self.h, d_src, d_dst, d_piece_src, d_piece_dst, int(npieces), int(total), stream))
+
+    def ac_scale(self, d_counters, factor, d_table, stream=0):
+        """compress.cpp:297-313 on the device: table = max(1, (1 + counters) / factor)."""
+        self._check(self.L.scalce_ac_scale(self.h, d_counters, int(factor), d_table, stream))
 
     def copy_d2d(self, dst, src, nbytes, stream=0):
         self._check(self.L.scalce_memcpy_d2d(self.h, dst, src, int(nbytes), stream))

@@ -29,6 +29,11 @@ CASES = {
     "se150_text": dict(n=1500, L=150, seed=12, kw=dict(dup_frac=0.1), ptxt="mixed", lossy=0),
     "se36_ties": dict(n=4000, L=36, seed=13, kw=dict(dup_frac=0.3), ptxt="fourmers", lossy=0),
     "se100_110k": dict(n=110000, L=100, seed=14, kw=dict(), ptxt=None, lossy=0, hash_only=True),
+    # shrink factor of compress.cpp:297-313 (every GPU config of BASELINE.json has factor >= 2: C2 2, C3 7, C4 24)
+    "se100_f7": dict(n=3000, L=100, seed=11, kw=dict(dup_frac=0.2, n_frac=0.01), ptxt=None, lossy=0, factor=7),
+    # paired (-r): mate 2 through the reference's output_read(.., 0, 0) / output_quality(.., ZZ = 1)
+    "pe150": dict(n=2500, L=150, seed=15, seed2=16, kw=dict(dup_frac=0.1, n_frac=0.005), ptxt=None, lossy=0),
+    "pe150_lossy_f2": dict(n=2500, L=150, seed=17, seed2=18, kw=dict(dup_frac=0.1, n_frac=0.005), ptxt=None, lossy=30, factor=2),
 }
 
 
@@ -50,10 +55,22 @@ def run_case(name, c):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib as O
     bases, quals = synth.reads_and_quals(c["n"], c["L"], seed=c["seed"], **c["kw"])
+    paired = "seed2" in c
+    if paired:
+        bases2, quals2 = synth.reads_and_quals(c["n"], c["L"], seed=c["seed2"], **c["kw"])
     with tempfile.TemporaryDirectory() as d:
         fq = os.path.join(d, "in_1.fq")
-        open(fq, "wb").write(synth.fastq_bytes_fast(bases, quals))
+        if paired:
+            open(fq, "wb").write(synth.fastq_bytes_fast(bases, quals, prefix="p.", suffix="/1"))
+            fq2 = os.path.join(d, "in_2.fq")
+            open(fq2, "wb").write(synth.fastq_bytes_fast(bases2, quals2, prefix="p.", suffix="/2"))
+        else:
+            open(fq, "wb").write(synth.fastq_bytes_fast(bases, quals))
         args = [DRIVER, fq, d]
+        if paired:
+            args += ["-2", fq2]
+        if c.get("factor", 1) != 1:
+            args += ["-f", str(c["factor"])]
         ptxt = None
         if c["ptxt"]:
             ptxt = pattern_text(c["ptxt"])
@@ -66,6 +83,12 @@ def run_case(name, c):
             lut = np.concatenate([[off], vals]).astype(np.int32)
             open(os.path.join(d, "q.txt"), "w").write(" ".join(map(str, lut)))
             args += ["-q", os.path.join(d, "q.txt")]
+            if paired:  # the model of mate 2 comes from mate 2's own sample (get_quality_stats, compress.cpp:554-584)
+                stat2 = np.bincount(quals2.reshape(-1), minlength=128).astype(np.int32)
+                off2, vals2 = O.qmap_init(stat2, c["lossy"])
+                lut2 = np.concatenate([[off2], vals2]).astype(np.int32)
+                open(os.path.join(d, "q2.txt"), "w").write(" ".join(map(str, lut2)))
+                args += ["-q2", os.path.join(d, "q2.txt")]
         subprocess.run(args, check=True)
         tok = np.fromfile(os.path.join(d, "tok.i32"), dtype=np.int32).reshape(-1, 2)
         order = np.fromfile(os.path.join(d, "order.i64"), dtype=np.int64)
@@ -75,10 +98,23 @@ def run_case(name, c):
         qual = np.fromfile(os.path.join(d, "qual.bin"), dtype=np.uint8)
         freq4 = np.fromfile(os.path.join(d, "freq4.u64"), dtype=np.uint64)
         ac = np.fromfile(os.path.join(d, "ac.bin"), dtype=np.uint8)
+        table = np.fromfile(os.path.join(d, "table.u32"), dtype=np.uint32)
+        if paired:
+            packed2 = np.fromfile(os.path.join(d, "packed2.bin"), dtype=np.uint8)
+            qual2 = np.fromfile(os.path.join(d, "qual2.bin"), dtype=np.uint8)
+            freq4_2 = np.fromfile(os.path.join(d, "freq4_2.u64"), dtype=np.uint64)
+            ac2 = np.fromfile(os.path.join(d, "ac2.bin"), dtype=np.uint8)
+            table2 = np.fromfile(os.path.join(d, "table2.u32"), dtype=np.uint32)
     sha = lambda a: hashlib.sha256(a.tobytes()).hexdigest()
     out = dict(n=c["n"], L=c["L"], seed=c["seed"], kw=repr(c["kw"]), lossy=c["lossy"],
                sha_tok=sha(tok), sha_order=sha(order), sha_packed=sha(packed), sha_names=sha(names),
-               sha_qual=sha(qual), sha_freq4=sha(freq4), sha_ac=sha(ac), ac_len=len(ac))
+               sha_qual=sha(qual), sha_freq4=sha(freq4), sha_ac=sha(ac), ac_len=len(ac),
+               factor=c.get("factor", 1), sha_table=sha(table))
+    if paired:
+        out.update(seed2=c["seed2"], sha_packed2=sha(packed2), sha_qual2=sha(qual2), sha_freq4_2=sha(freq4_2),
+                   sha_ac2=sha(ac2), ac2_len=len(ac2), sha_table2=sha(table2), ac2_head=ac2[:4096])
+        if lut is not None:
+            out["lut2"] = lut2
     if ptxt is not None:
         out["ptxt"] = ptxt
     if lut is not None:

@@ -79,6 +79,7 @@ def test_golden_cases(name, patterns_blob):
     assert sha(b.output(host.OUT_QINPUT, 0)) == str(g["sha_qual"])
     assert sha(b.output(host.OUT_FREQ4, 0, np.uint64) + 1) == str(g["sha_freq4"])
     assert sha(b.output(host.OUT_QUAL, 0)) == str(g["sha_ac"])
+    assert sha(names_in_input_order(b)) == str(g["sha_names"])   # output_name (names.cpp:48-62) of the reference itself
     # .scalcer records (headers stripped) == concatenated output_read bytes in emission order
     lens = trie.pattern_lens()
     reads = b.output(host.OUT_READS, 0)
@@ -103,6 +104,78 @@ def test_golden_cases(name, patterns_blob):
             pos += nb + 1
         k += cnt
     assert pos == len(reads)
+
+
+def names_in_input_order(b):
+    """SCALCE_OUT_NAMES holds [u8 n][bytes] per record in emission order; put the records back into input order."""
+    names = b.output(host.OUT_NAMES, 0)
+    perm = b.output(host.OUT_PERM, 0, np.uint32)
+    n = len(perm)
+    start = np.zeros(n + 1, dtype=np.int64)
+    pos = 0
+    for k in range(n):
+        start[k] = pos
+        pos += 1 + int(names[pos])
+    start[n] = pos
+    assert pos == len(names)
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm] = np.arange(n)
+    return np.concatenate([names[start[inv[r]]:start[inv[r] + 1]] for r in range(n)])
+
+
+@pytest.mark.parametrize("name", ["se100_f7", "pe150", "pe150_lossy_f2"])
+def test_golden_paired_and_shrink_factor(name, ctx):
+    """Vectors from the reference's own objects for what every GPU config of BASELINE.json runs into and the round-1
+    tests never did: the shrink factor of compress.cpp:297-313 (> 1 from 43 M x 100 symbols on: C2 2, C3 7, C4 24) and
+    mate 2 of a paired run (output_read(.., 0, 0), output_quality(.., ZZ = 1) with its own prev[] and counters)."""
+    import torch
+    from gpu_util import device_bytes
+    g = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    kw = eval(str(g["kw"]))  # noqa: S307
+    n, L, factor = int(g["n"]), int(g["L"]), int(g["factor"])
+    paired = "seed2" in g
+    bases, quals = synth.reads_and_quals(n, L, seed=int(g["seed"]), **kw)
+    lut = lambda key: (int(g[key][0]), g[key][1:]) if key in g else (33, np.arange(128))  # noqa: E731
+    qm = [lut("lut"), lut("lut2") if paired else lut("lut")]
+    if paired:
+        bases2, quals2 = synth.reads_and_quals(n, L, seed=int(g["seed2"]), **kw)
+        fq1 = synth.fastq_bytes_fast(bases, quals, prefix="p.", suffix="/1")
+        fq2 = synth.fastq_bytes_fast(bases2, quals2, prefix="p.", suffix="/2")
+    else:
+        fq1, fq2 = synth.fastq_bytes_fast(bases, quals), None
+    t1 = device_bytes(fq1)
+    t2 = device_bytes(fq2) if paired else None
+    b = host.Batch(ctx, L, n + 8, max(len(fq1), len(fq2 or b"")) + 64, paired=paired, read_len2=L, qmap=qm)
+    b.front(t1.data_ptr(), len(fq1), t2.data_ptr() if paired else None, len(fq2 or b""))
+    b.finish()
+    assert sha(b.output(host.OUT_TOKENS, 0, np.int32)) == str(g["sha_tok"])
+    perm = b.output(host.OUT_PERM, 0, np.uint32)
+    assert sha(perm.astype(np.int64)) == str(g["sha_order"])
+    assert sha(names_in_input_order(b)) == str(g["sha_names"])
+    nm = 2 if paired else 1
+    tables = torch.zeros(2 * 512000, dtype=torch.int32, device="cuda:0")
+    for m in range(nm):
+        key = (lambda k: k if m == 0 else ("sha_freq4_2" if k == "sha_freq4" else k + "2"))  # golden keys of mate 2
+        assert sha(b.output(host.OUT_QINPUT, m)) == str(g[key("sha_qual")]), m
+        assert sha(b.output(host.OUT_FREQ4, m, np.uint64) + 1) == str(g[key("sha_freq4")]), m
+        f4p, _ = b.output_ptr(host.OUT_FREQ4, m)
+        ctx.ac_scale(f4p, factor, tables.data_ptr() + 4 * 512000 * m)
+        torch.cuda.synchronize()
+        tab = tables[512000 * m:512000 * (m + 1)].cpu().numpy().view(np.uint32)
+        assert (tab == O.ac_scale(b.output(host.OUT_FREQ4, m, np.uint64) + 1, factor)).all(), f"mate {m + 1}: scaled table vs oracle"
+        assert sha(tab) == str(g[key("sha_table")]), f"mate {m + 1}: scaled table (factor {factor}) vs the reference's"
+    b.entropy(tables.data_ptr())
+    b.finish()
+    for m in range(nm):
+        key = (lambda k: k if m == 0 else k + "2")
+        enc = b.output(host.OUT_QUAL, m)
+        assert len(enc) == int(g["ac_len" if m == 0 else "ac2_len"])
+        assert sha(enc) == str(g[key("sha_ac")]), f"mate {m + 1}: coder bytes against the scaled table"
+    if paired:  # mate 2's .scalcer payload: bare whole-read records in mate 1's order
+        r2 = b.output(host.OUT_READS, 1).reshape(n, (L + 3) // 4)
+        inv = np.empty(n, dtype=np.int64)
+        inv[perm] = np.arange(n)
+        assert sha(r2[inv]) == str(g["sha_packed2"])
 
 
 def test_two_ac_blocks_and_decode(ctx, oracle_trie):
@@ -330,6 +403,12 @@ def test_full_size_shard_properties(ctx):
     ctx.ac_decode(b.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nsym, out.data_ptr())
     want = dev_array(host.OUT_QSTREAM, torch.uint8, nsym)
     assert torch.equal(out, want), "decoded stream differs from the reordered quality stream"
+    # the bench workload runs at shrink factor 2 (5e9 symbols): the table the coder used against the oracle's scaling
+    f4 = b.output(host.OUT_FREQ4, 0, np.uint64)
+    assert int(f4.sum()) == nsym - 2
+    factor = 1 + nsym // 0xFFFFFFFF
+    assert factor == 2
+    assert (b.output(host.OUT_TABLE, 0, np.uint32) == O.ac_scale(f4 + 1, factor)).all(), "scaled table at factor 2"
     recsz = (L - lens.cpu().numpy() + 3) // 4 + 1
     assert b.output_ptr(host.OUT_READS, 0)[1] == int((counts * recsz).sum() + 12 * (counts > 0).sum())
     assert b.output_ptr(host.OUT_NAMES, 0)[1] == int(b.output(host.OUT_NAMELEN, 0).astype(np.int64).sum()) + n
@@ -506,3 +585,32 @@ def test_rows_coder_repeated_launches(ctx, oracle_trie, monkeypatch):
                 want = O.AcStat(b.output(host.OUT_TABLE, 0, np.uint32)).encode_stream(ref["qp"][ref["perm"]].reshape(-1))
             enc = b.output(host.OUT_QUAL, 0)
             assert len(enc) == len(want) and (enc == want).all(), f"launch {rep} with {bpw} blocks per wave differs"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks_per_wave", ["1", "4", "8"])
+def test_coder_general_step_through_inverted_intervals(blocks_per_wave, ctx, monkeypatch):
+    """A context total beyond 2^30 (reachable at 50 M x 100 with binned, low-entropy qualities) makes the reference's
+    32-bit coder run through inverted intervals: lo = 1.., hi = 0.. after a step (about 1 % of the steps with this
+    table).  The host then selects the all-states step; the rows kernels carry (lo, range) across super-rounds and must
+    not clear bit 31 of lo there (they once did: ADVICE r1).  One-, four- and eight-blocks-per-wave kernels against the
+    oracle's literal coder, two blocks, the second one short."""
+    import torch
+    monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", blocks_per_wave)
+    rng = np.random.default_rng(9)
+    nsym = 10 * 1024 * 1024 + 300_000
+    sym = rng.choice(np.array([30, 31, 32], dtype=np.uint8), size=nsym, p=[0.62, 0.03, 0.35]).astype(np.uint8)
+    table = np.ones((6400, 80), dtype=np.uint32)
+    table[:, 30] = 2_000_000_000
+    table[:, 32] = 1_000_000_000          # context totals 3e9 + 78: above 2^30, below 2^32
+    table = table.reshape(-1)
+    want = O.AcStat(table).encode_stream(sym)
+    b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
+    d_sym = torch.from_numpy(sym).to("cuda:0")
+    d_tab = torch.from_numpy(table.view(np.int32)).to("cuda:0")
+    b.entropy_stream(0, d_tab.data_ptr(), d_sym.data_ptr(), nsym)
+    b.finish()
+    enc = b.output(host.OUT_QUAL, 0)
+    assert len(enc) == len(want), f"{len(enc)} vs {len(want)} bytes"
+    bad = np.flatnonzero(enc != want)
+    assert len(bad) == 0, f"coder bytes differ from the oracle's first at byte {bad[:3]} of {len(want)}"

@@ -9,7 +9,7 @@ import oraclelib as O
 from scalce_amd import synth
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["se100", "se100_lossy", "se150_text", "se36_ties", "se100_110k"]
+CASES = ["se100", "se100_lossy", "se150_text", "se36_ties", "se100_110k", "se100_f7", "pe150", "pe150_lossy_f2"]
 
 
 def sha(a):
@@ -22,6 +22,16 @@ def load_case(name, patterns_blob):
     bases, quals = synth.reads_and_quals(int(g["n"]), int(g["L"]), seed=int(g["seed"]), **kw)
     trie = O.Trie(text=str(g["ptxt"]).encode()) if "ptxt" in g else O.Trie(blob=patterns_blob)
     return g, bases, quals, trie
+
+
+def name_stream(n, prefix, suffix):
+    """[u8 len][chars] per read, input order: what output_name (names.cpp:48-62) makes of the generator's names."""
+    out = bytearray()
+    for i in range(n):
+        nm = (prefix + str(i) + suffix).encode()
+        out.append(len(nm))
+        out += nm
+    return np.frombuffer(bytes(out), dtype=np.uint8)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -46,10 +56,26 @@ def test_oracle_matches_reference_vectors(name, patterns_blob):
     qp, f4 = O.quality_stream(quals, bases, off, vals)
     assert sha(qp) == str(g["sha_qual"])
     assert sha(f4) == str(g["sha_freq4"])
-    st = O.AcStat(O.ac_scale(f4, 1))
+    factor = int(g["factor"])
+    table = O.ac_scale(f4, factor)  # compress.cpp:297-313
+    assert sha(table) == str(g["sha_table"])
+    st = O.AcStat(table)
     enc = st.encode_stream(qp[perm].reshape(-1))
     assert len(enc) == int(g["ac_len"])
     assert sha(enc) == str(g["sha_ac"])
+    assert sha(name_stream(len(bases), "p." if "seed2" in g else "s.", "/1" if "seed2" in g else "")) == str(g["sha_names"])
+    if "seed2" in g:  # mate 2: whole read packed, own quality model and counters (qualities.cpp:179 prev[1])
+        bases2, quals2 = synth.reads_and_quals(int(g["n"]), int(g["L"]), seed=int(g["seed2"]), **eval(str(g["kw"])))  # noqa: S307
+        assert sha(np.concatenate([O.pack_read(r, 0, 0) for r in bases2])) == str(g["sha_packed2"])
+        off2, vals2 = (int(g["lut2"][0]), g["lut2"][1:]) if "lut2" in g else (33, np.arange(128))
+        qp2, f42 = O.quality_stream(quals2, bases2, off2, vals2)
+        assert sha(qp2) == str(g["sha_qual2"])
+        assert sha(f42) == str(g["sha_freq4_2"])
+        table2 = O.ac_scale(f42, factor)
+        assert sha(table2) == str(g["sha_table2"])
+        enc2 = O.AcStat(table2).encode_stream(qp2[perm].reshape(-1))
+        assert len(enc2) == int(g["ac2_len"]) and sha(enc2) == str(g["sha_ac2"])
+        assert (enc2[:4096] == g["ac2_head"]).all()
     if "tok" in g:  # element-wise views for debuggability
         assert (tok == g["tok"]).all()
         assert (perm == g["order"]).all()
