@@ -85,8 +85,27 @@ void scalce_batch_destroy(scalce_batch *b);
 
 /* record reader of thread() (compress.cpp:614-666): newline index of the FASTQ text of one
  * mate, validation of the fixed read length, 2-bit packing of the bases (getval, const.cpp:47),
- * name slicing (output_name, names.cpp:48-62).  d_text must stay valid until emit. */
+ * name slicing (output_name, names.cpp:48-62).  The text is not read again once the call has returned and `stream`
+ * has passed it. */
 int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_text, uint64_t nbytes, void *stream);
+/* The record reader for inputs that do not fit HBM as text (the reference reads records one by one from files of any
+ * size and spills buckets to disk, compress.cpp:614-717; here the TEXT is streamed and what is derived from it stays
+ * resident: 2-bit rows, q', names, tokens -- about two thirds of the text).  scalce_batch_append takes the next piece of the
+ * read stream BEHIND the rows the batch already holds: as many complete records as both mates' pieces contain (the
+ * mates are read in step), consumed[m] = bytes of piece m that were used -- the caller puts the rest in front of its
+ * next piece; final_piece = 1 makes a leftover an error (line count not a multiple of 4, mates of different length).
+ * Ingest, quality counters (prev[] runs across pieces, qualities.cpp:179) and the tie-break of the new rows against ALL
+ * rows before them (bin_size is cumulative, reads.cpp:246) are done when the call returns and the text may be
+ * overwritten; scalce_batch_order / _emit / _entropy then run once over everything.  d_text* 16-byte aligned, at most
+ * max_text bytes each; the row arrays grow beyond max_reads when they must.  The first append after create, reset or a
+ * one-piece ingest starts a new run.  Synchronises `stream`. */
+int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2,
+                        int final_piece, uint64_t consumed[2], void *stream);
+int scalce_batch_reset(scalce_batch *b);
+/* lean = 1: a stage releases the device buffers that no later stage reads (q' in input order once the reordered stream
+ * exists, rows and sort scratch once the records are emitted): outputs 5, 6, 9 become unavailable, runs sized for most
+ * of HBM fit. */
+void scalce_batch_set_lean(scalce_batch *b, int lean);
 /* output_quality (qualities.cpp:177-204): q' = map[q]-offset (N -> 0) and the order-2 trigram
  * counters ac_freq4 over the input-order stream of this shard. */
 int scalce_batch_quality(scalce_batch *b, void *stream);

@@ -104,6 +104,7 @@ struct UnpackArgs {
   const u8 *qlut;  // 128 bytes: (values[c] - offset) & 255
   int q_affine;    // >= 0: values[c] == c for every c, q' = (c & 127) - q_affine without the table
   DevErr *err;
+  u32 *max_namelen;  // longest stored name of the piece when it exceeds a cell (15 characters), else untouched
 };
 
 // 2-bit codes of four ASCII bases packed in a little-endian word -> one byte, first base in bits 7-6.
@@ -225,9 +226,28 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
         for (u32 k = 0; k < 15 && k < len; k++) w[(k + 1) >> 2] |= (u32)byte_at(ns + 1 + k) << (8 * ((k + 1) & 3));
         *reinterpret_cast<uint4 *>(a.namecell + 16 * r) = make_uint4(w[0], w[1], w[2], w[3]);
       }
+      if (len > 15 && a.max_namelen) atomicMax(a.max_namelen, len);
     }
     a.namelen[r] = (u8)len;
   }
+}
+
+// Names longer than a cell (15 characters) are kept in a byte store in input order, so that the text of a piece is not
+// needed once it is ingested: off[r] = where the name of row r starts (exclusive scan of LongNameLen + bytes in use).
+struct LongNameLen {
+  const u8 *namelen;
+  __device__ u64 operator()(u64 r) const { return namelen[r] > 15 ? (u64)namelen[r] : 0ull; }
+};
+__global__ __launch_bounds__(256) void long_names_k(u64 nrec, const u8 *text, const u64 *line_end, const u8 *namelen, u64 *off,
+                                                   u64 store_base, u8 *store) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrec) return;
+  const u64 at = off[r] + store_base;
+  off[r] = at;
+  const u32 n = namelen[r];
+  if (n <= 15) return;
+  const u64 src = (r ? line_end[4 * r - 1] + 1 : 0) + 1;  // behind the '@'
+  for (u32 i = 0; i < n; i++) store[at + i] = text[src + i];
 }
 
 // direct form: every thread reads its record straight from global memory (fallback for long reads / huge names)
@@ -350,7 +370,17 @@ __global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist 
 }
 
 // range[0] = smallest symbol < 80 that occurs, range[1] = A = span of the occurring symbols (0: none)
-__global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, u32 prev0, u32 prev1, u32 *range) {
+// The two symbols in front of a piece (qualities.cpp:179: prev[] runs across reads): the tail of the q' rows already
+// held when there are any (q_piece points behind them), else what the caller carried in (500 = none).
+__global__ void tri_prev_k(const u8 *q_piece, u64 symbols_before, u32 carried0, u32 carried1, u32 *prev /*[2]*/) {
+  if (threadIdx.x || blockIdx.x) return;
+  if (symbols_before >= 2) { prev[0] = *(q_piece - 2); prev[1] = *(q_piece - 1); }
+  else if (symbols_before == 1) { prev[0] = carried1; prev[1] = *(q_piece - 1); }
+  else { prev[0] = carried0; prev[1] = carried1; }
+}
+
+__global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, const u32 *prev, u32 *range) {
+  const u32 prev0 = prev[0], prev1 = prev[1];
   const u32 l = threadIdx.x;
   const bool live0 = sym_hist[l] != 0 || prev0 == l || prev1 == l;
   const bool live1 = l + 64 < 80 && (sym_hist[l + 64] != 0 || prev0 == l + 64 || prev1 == l + 64);
@@ -374,8 +404,9 @@ __global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, u32 prev0
 // fraction of the speed of the others, and with equal shares the whole workgroup -- and the kernel, one workgroup per
 // CU -- waited for them (4.4 -> 14 ms per pass).
 constexpr u32 TRI_TILE = 64 * 1024;
-__global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, u32 prev0, u32 prev1, u32 pass,
+__global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, const u32 *prev, u32 pass,
                                                              const u32 *range, u64 *freq4, unsigned long long *tile_counter) {
+  const u32 prev0 = prev[0], prev1 = prev[1];
   // Counters are 16-bit fields, two per word: twice the leading symbols per pass (a 39-symbol alphabet in ONE streaming
   // pass, the full 80 in nine instead of twenty).  LDS has 32-bit atomics only, so a field must never carry into its
   // neighbour: bit 15 is a guard -- the add that finds 0x7FFF takes 32768 off the field again and moves them to the

@@ -291,27 +291,24 @@ struct NameLenSeq {
   const u8 *outlen;
   __device__ u64 operator()(u64 k) const { return 1ull + outlen[k]; }
 };
-// cells = nullptr: name bytes from the FASTQ text (three gathers per record: length, line index, text); with the
-// 16-byte cells written by the ingest stage a name of up to 15 characters is ONE gather
-__global__ __launch_bounds__(256) void emit_names_k(u64 nrec, const u32 *perm, const u8 *namelen, const u64 *line_end,
-                                                   const u8 *text, const u64 *name_off, const u8 *cells, u8 *out) {
+// The 16-byte cell written by the ingest stage holds the length and up to 15 characters: ONE gather per record; a longer
+// name comes from the long-name store (input order, written when its piece was ingested).
+__global__ __launch_bounds__(256) void emit_names_k(u64 nrec, const u32 *perm, const u8 *cells, const u64 *store_off,
+                                                   const u8 *store, const u64 *name_off, u8 *out) {
   const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nrec) return;
   const u32 r = perm[k];
   u8 *dst = out + name_off[k];
-  if (cells) {
-    const uint4 c = *reinterpret_cast<const uint4 *>(cells + 16 * (u64)r);
-    const u32 n = c.x & 0xFFu;
-    if (n <= 15) {
-      const u32 w[4] = {c.x, c.y, c.z, c.w};
-      for (u32 i = 0; i <= n; i++) dst[i] = (u8)(w[i >> 2] >> (8 * (i & 3)));
-      return;
-    }
+  const uint4 c = *reinterpret_cast<const uint4 *>(cells + 16 * (u64)r);
+  const u32 n = c.x & 0xFFu;
+  if (n <= 15) {
+    const u32 w[4] = {c.x, c.y, c.z, c.w};
+    for (u32 i = 0; i <= n; i++) dst[i] = (u8)(w[i >> 2] >> (8 * (i & 3)));
+    return;
   }
-  const u32 n = namelen[r];
-  const u64 src = (r ? line_end[4 * (u64)r - 1] + 1 : 0) + 1;  // skip '@'
+  const u8 *src = store + store_off[r];
   dst[0] = (u8)n;
-  for (u32 i = 0; i < n; i++) dst[1 + i] = text[src + i];
+  for (u32 i = 0; i < n; i++) dst[1 + i] = src[i];
 }
 
 // row gather: out[k] = rows[perm[k]], `width` bytes per row, row stride `stride` in the source

@@ -443,6 +443,11 @@ __global__ __launch_bounds__(256) void seg_rescan_k(u32 nb1, const u32 *seg, con
   if (threadIdx.x == 0) counts[b] = (u64)(running - Gseg[b]);
 }
 
+__global__ __launch_bounds__(256) void add_counts_k(u32 n, const u64 *x, const u64 *y, u64 *out) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = x[i] + y[i];
+}
+
 // reads per bucket from the converged prefix sums
 __global__ __launch_bounds__(256) void bucket_counts_k(u32 nb1, const u32 *G, const u32 *seg, u64 *counts, u32 *Gseg) {
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;

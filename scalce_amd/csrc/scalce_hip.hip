@@ -233,8 +233,16 @@ struct scalce_batch {
   u64 max_reads = 0, max_text = 0;
   int nm = 1;
   int L[2] = {0, 0}, stride[2] = {0, 0}, szr[2] = {0, 0}, sz_meta = 1;
-  u64 N = 0;                 // records in the current shard
-  const u8 *d_text[2] = {nullptr, nullptr};
+  // Rows.  A batch takes its input in one piece (scalce_batch_ingest) or in several (scalce_batch_append): rows
+  // [base, base + NP) are the piece being ingested / tokenized, N = base + NP is everything the batch holds.  Packed
+  // bases, q', names and tokens are run-wide arrays indexed by row; the text of a piece is dead once it is ingested.
+  u64 N = 0, base = 0, NP = 0;
+  u64 row_cap = 0;           // rows the run-wide arrays hold
+  u64 piece_rows_cap = 0;    // records one piece may bring (size of the line index)
+  bool appending = false;    // the pieces came through scalce_batch_append
+  bool lean = false;         // release what a stage no longer needs (runs sized for most of HBM)
+  u64 tri_expected[2] = {0, 0};  // trigrams counted so far (tri_check_k)
+  u64 names_in_used = 0;     // bytes of the long-name store in use
   u64 text_bytes[2] = {0, 0};
   bool ingested[2] = {false, false};
   // device state
@@ -243,7 +251,8 @@ struct scalce_batch {
   u64 *d_small64 = nullptr;
   u8 *d_qlut[2] = {nullptr, nullptr};
   int q_affine[2] = {-1, -1};  // the quality map is q - offset for every character: no table lookups in the ingest kernel
-  DBuf line_end[2], packed[2], q[2], namelen, namecell, outlen, freq4[2], table[2], qs[2];
+  DBuf line_end[2], tile[2], packed[2], q[2], namelen, namecell, outlen, freq4[2], table[2], qs[2];
+  DBuf names_in, name_in_off, counts_total, prior_buf;  // names longer than a cell, input order; reads per bucket over all pieces
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
@@ -295,9 +304,39 @@ static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
   return SCALCE_OK;
 }
 #define ENSURE(b, buf, bytes) do { int rc_ = ensure(b, buf, bytes); if (rc_) return rc_; } while (0)
+// the same for run-wide arrays that grow while a run is ingested piece by piece: the first `used` bytes survive
+static int ensure_keep(scalce_batch *b, DBuf &d, size_t bytes, size_t used, hipStream_t s) {
+  if (bytes <= d.cap) return SCALCE_OK;
+  if (!d.p || !used) return ensure(b, d, bytes);
+  size_t want = d.cap + d.cap / 2;
+  if (want < bytes) want = bytes;
+  want = (want + 255) & ~size_t(255);
+  void *np = nullptr;
+  hipError_t e = hipMalloc(&np, want);
+  if (e != hipSuccess && want > bytes) { want = (bytes + 255) & ~size_t(255); e = hipMalloc(&np, want); }
+  if (e != hipSuccess) {
+    set_err(b->ctx, "hipMalloc(%zu) failed while growing a run-wide array: %s", want, hipGetErrorString(e));
+    return SCALCE_ERR_HIP;
+  }
+  if ((e = hipMemcpyAsync(np, d.p, used, hipMemcpyDeviceToDevice, s)) != hipSuccess || (e = hipStreamSynchronize(s)) != hipSuccess) {
+    hipFree(np);
+    set_err(b->ctx, "growing a run-wide array: %s", hipGetErrorString(e));
+    return SCALCE_ERR_HIP;
+  }
+  hipFree(d.p);
+  d.p = np;
+  d.cap = want;
+  return SCALCE_OK;
+}
+static void release(DBuf &d) {
+  if (d.p) hipFree(d.p);
+  d.p = nullptr;
+  d.cap = 0;
+}
 
 static void free_all(scalce_batch *b) {
-  DBuf *all[] = {&b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen, &b->namecell, &b->outlen,
+  DBuf *all[] = {&b->tile[0], &b->tile[1], &b->names_in, &b->name_in_off, &b->counts_total, &b->prior_buf,
+                 &b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen, &b->namecell, &b->outlen,
                  &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
                  &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
@@ -319,6 +358,26 @@ static void free_all(scalce_batch *b) {
 }
 
 static inline int sz_read(int l) { return (l + 3) / 4; }
+
+// run-wide arrays indexed by row: room for `rows` of them, the first `used` rows kept
+static int reserve_rows(scalce_batch *b, u64 rows, u64 used, hipStream_t s) {
+  if (rows <= b->row_cap) return SCALCE_OK;
+  if (rows >= (1ull << 32) - 64) { set_err(b->ctx, "a batch holds fewer than 2^32 reads"); return SCALCE_ERR_CAPACITY; }
+  if (b->row_cap && rows < b->row_cap + b->row_cap / 4) rows = b->row_cap + b->row_cap / 4;  // grow in steps
+  int rc;
+  for (int m = 0; m < b->nm; m++) {
+    if ((rc = ensure_keep(b, b->packed[m], (size_t)b->stride[m] * rows + 64, (size_t)b->stride[m] * used, s))) return rc;
+    if ((rc = ensure_keep(b, b->q[m], (size_t)b->L[m] * rows + 64, (size_t)b->L[m] * used, s))) return rc;
+  }
+  if ((rc = ensure_keep(b, b->namelen, rows + 64, used, s))) return rc;
+  if (b->p.use_names && (rc = ensure_keep(b, b->namecell, 16 * (rows + 8), 16 * used, s))) return rc;
+  if (b->name_in_off.p && (rc = ensure_keep(b, b->name_in_off, sizeof(u64) * (rows + 2), sizeof(u64) * used, s))) return rc;
+  if ((rc = ensure_keep(b, b->bucket, sizeof(u32) * (rows + 1), sizeof(u32) * used, s))) return rc;
+  if ((rc = ensure_keep(b, b->endv, sizeof(u16) * (rows + 1), sizeof(u16) * used, s))) return rc;
+  if ((rc = ensure_keep(b, b->tokens, sizeof(int32_t) * 2 * (rows + 1), sizeof(int32_t) * 2 * used, s))) return rc;
+  b->row_cap = rows;
+  return SCALCE_OK;
+}
 
 extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
                                    scalce_batch **out) {
@@ -359,19 +418,15 @@ extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64
     b->q_affine[m] = identity ? (int)p->qmap[m].offset : -1;
     HIP_TRY(c, hipMalloc(&b->d_qlut[m], 128));
     HIP_TRY(c, hipMemcpy(b->d_qlut[m], lut, 128, hipMemcpyHostToDevice));
-    ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (max_reads + 1));
-    ENSURE(b, b->packed[m], (size_t)b->stride[m] * max_reads + 64);
-    ENSURE(b, b->q[m], (size_t)b->L[m] * max_reads + 64);
-    ENSURE(b, b->qs[m], (size_t)b->L[m] * max_reads + 64);
     ENSURE(b, b->freq4[m], sizeof(u64) * 512000);
     ENSURE(b, b->table[m], sizeof(u32) * 512000);
   }
-  ENSURE(b, b->namelen, max_reads + 64);
-  if (b->p.use_names) {
-    ENSURE(b, b->namecell, 16 * (max_reads + 8));
-    ENSURE(b, b->outlen, max_reads + 64);
-  }
-  ENSURE(b, b->scan_ws, sizeof(u64) * (max_text / IDX_TILE + scan_ws_elems(4 * max_reads + 1024) + 4096));
+  // a record is at least "@x", L bases, "+", L qualities and four newlines: what one piece of max_text bytes can bring
+  const u64 per_piece = max_text / (2 * (u64)b->L[0] + 7) + 2;
+  b->piece_rows_cap = per_piece < max_reads ? per_piece : max_reads;
+  for (int m = 0; m < b->nm; m++) ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (b->piece_rows_cap + 1));
+  { int rc = reserve_rows(b, max_reads, 0, nullptr); if (rc) return rc; }
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(4 * b->piece_rows_cap + 1024) + 4096));
   return SCALCE_OK;
 }
 
@@ -433,29 +488,97 @@ static int check_device_error(scalce_batch *b, hipStream_t s) {
 static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 
 // ---- stage 0: ingest ------------------------------------------------------------------------------
+// newline count of one mate's text; the per-tile bases stay in b->tile[mate] for piece_unpack
+static int piece_count(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, hipStream_t s, u64 *nlines, u8 *last) {
+  scalce_ctx *c = b->ctx;
+  if (((uintptr_t)d_text & 15) != 0) { set_err(c, "FASTQ text must be 16-byte aligned"); return SCALCE_ERR_ARG; }
+  if (nbytes > b->max_text) { set_err(c, "text larger than the batch capacity"); return SCALCE_ERR_CAPACITY; }
+  b->text_bytes[mate] = nbytes;
+  const u32 ntiles = cdiv(nbytes, IDX_TILE);
+  ENSURE(b, b->tile[mate], (ntiles + 8) * sizeof(u64));
+  ENSURE(b, b->scan_ws, (scan_ws_elems(ntiles) + 64) * sizeof(u64));
+  u64 *tile = b->tile[mate].as<u64>();  // [ntiles] counts -> bases
+  *nlines = 0;
+  *last = '\n';
+  if (ntiles) {
+    LAUNCH(index_count_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, tile);
+    exclusive_scan<u64>(LoadAs<u64, u64>{tile}, ntiles, StoreTo<u64>{tile}, b->scan_ws.as<u64>(), b->d_small64 + 4 + mate, s);
+    HIP_TRY(c, hipMemcpyAsync(nlines, b->d_small64 + 4 + mate, sizeof(u64), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, s));
+  }
+  return SCALCE_OK;
+}
+
+// line index of the first `nrec` records of the text, then their rows [base, base + nrec): 2-bit bases, q', names
+static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  if (!nrec) return SCALCE_OK;
+  if (nrec > b->piece_rows_cap) {
+    b->piece_rows_cap = nrec;
+    for (int m = 0; m < b->nm; m++) ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (nrec + 1));
+  }
+  const u32 ntiles = cdiv(nbytes, IDX_TILE);
+  LAUNCH(index_write_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, b->tile[mate].as<u64>(), b->line_end[mate].as<u64>(), 4 * nrec);
+  UnpackArgs a;
+  a.text = d_text; a.nbytes = nbytes; a.line_end = b->line_end[mate].as<u64>(); a.nrec = nrec;
+  a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
+  a.packed = b->packed[mate].as<u8>() + b->base * (u64)b->stride[mate];
+  a.q = b->q[mate].as<u8>() + b->base * (u64)b->L[mate];
+  a.namelen = b->namelen.as<u8>() + b->base;
+  a.namecell = (mate == 0 && b->p.use_names) ? b->namecell.as<u8>() + 16 * b->base : nullptr;
+  a.qlut = b->d_qlut[mate]; a.err = b->d_err;
+  a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
+  a.max_namelen = b->d_small + 16;
+  if (mate == 0) HIP_TRY(c, hipMemsetAsync(b->d_small + 16, 0, sizeof(u32), s));
+  if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
+    LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
+  else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
+  if (mate == 0 && b->p.use_names) {
+    // names that do not fit their 16-byte cell go to the long-name store (input order): the text is not needed again
+    u32 maxlen = 0;
+    { int rc = read_u32(b, b->d_small + 16, &maxlen, 1, s); if (rc) return rc; }
+    if (maxlen > 15) {
+      if (!b->name_in_off.p) {
+        ENSURE(b, b->name_in_off, sizeof(u64) * (b->row_cap + 2));
+        HIP_TRY(c, hipMemsetAsync(b->name_in_off.p, 0, sizeof(u64) * (b->row_cap + 2), s));
+      }
+      ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nrec) + 64));
+      u64 *off = b->name_in_off.as<u64>() + b->base;
+      exclusive_scan<u64>(LongNameLen{a.namelen}, nrec, StoreTo<u64>{off}, b->scan_ws.as<u64>(), b->d_small64 + 6, s);
+      u64 total = 0;
+      { int rc = read_u64(b, b->d_small64 + 6, &total, 1, s); if (rc) return rc; }
+      { int rc = ensure_keep(b, b->names_in, b->names_in_used + total + 64, b->names_in_used, s); if (rc) return rc; }
+      LAUNCH(long_names_k, cdiv(nrec, 256), 256, 0, s, nrec, d_text, a.line_end, a.namelen, off, b->names_in_used, b->names_in.as<u8>());
+      b->names_in_used += total;
+    }
+  }
+  return SCALCE_OK;
+}
+
+static void batch_restart(scalce_batch *b) {
+  b->N = b->base = b->NP = 0;
+  b->appending = false;
+  b->names_in_used = 0;
+  b->tri_expected[0] = b->tri_expected[1] = 0;
+  b->ingested[0] = b->ingested[1] = false;
+}
+
+extern "C" int scalce_batch_reset(scalce_batch *b) {
+  if (!b) return SCALCE_ERR_ARG;
+  batch_restart(b);
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_text, uint64_t nbytes, void *stream) {
   if (!b || mate < 0 || mate >= b->nm || !d_text) return SCALCE_ERR_ARG;
   scalce_ctx *c = b->ctx;
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (((uintptr_t)d_text & 15) != 0) { set_err(c, "FASTQ text must be 16-byte aligned"); return SCALCE_ERR_ARG; }
-  if (nbytes > b->max_text) { set_err(c, "text larger than the batch capacity"); return SCALCE_ERR_CAPACITY; }
   StageTimer tm(b, ST_INGEST, s);
-  b->d_text[mate] = d_text;
-  b->text_bytes[mate] = nbytes;
-  const u32 ntiles = cdiv(nbytes, IDX_TILE);
-  ENSURE(b, b->scan_ws, (ntiles + 8 + scan_ws_elems(ntiles) + 64) * sizeof(u64));
-  u64 *tile = b->scan_ws.as<u64>();                 // [ntiles] counts -> bases
-  u64 *ws = tile + ntiles + 8;                      // scan workspace behind it
+  if (mate == 0) batch_restart(b);  // one piece = the whole shard
   u64 nlines = 0;
-  if (ntiles) {
-    LAUNCH(index_count_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, tile);
-    exclusive_scan<u64>(LoadAs<u64, u64>{tile}, ntiles, StoreTo<u64>{tile}, ws, b->d_small64, s);
-    int rc = read_u64(b, b->d_small64, &nlines, 1, s);
-    if (rc) return rc;
-  }
   u8 last = '\n';
-  if (nbytes) HIP_TRY(c, hipMemcpyAsync(&last, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, s));
+  { int rc = piece_count(b, mate, d_text, nbytes, s, &nlines, &last); if (rc) return rc; }
   HIP_TRY(c, hipStreamSynchronize(s));
   if ((nlines & 3) || last != '\n') {
     set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)nlines);
@@ -463,23 +586,67 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
   }
   const u64 nrec = nlines / 4;
   if (nrec > b->max_reads) { set_err(c, "%llu records exceed the batch capacity", (unsigned long long)nrec); return SCALCE_ERR_CAPACITY; }
-  if (mate == 0) b->N = nrec;
+  if (mate == 0) { b->N = b->NP = nrec; }
   else if (nrec != b->N) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
-  if (ntiles) LAUNCH(index_write_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, tile, b->line_end[mate].as<u64>(), nlines);
-  if (nrec) {
-    UnpackArgs a;
-    a.text = d_text; a.nbytes = nbytes; a.line_end = b->line_end[mate].as<u64>(); a.nrec = nrec;
-    a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
-    a.packed = b->packed[mate].as<u8>(); a.q = b->q[mate].as<u8>(); a.namelen = b->namelen.as<u8>();
-    a.namecell = (mate == 0 && b->p.use_names) ? b->namecell.as<u8>() : nullptr;
-    a.qlut = b->d_qlut[mate]; a.err = b->d_err;
-    a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
-    if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
-      LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
-    else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
-  }
+  { int rc = piece_unpack(b, mate, d_text, nbytes, nrec, s); if (rc) return rc; }
   b->ingested[mate] = true;
   return SCALCE_OK;
+}
+
+// Streaming form of the record reader: the next piece of the read stream goes BEHIND the rows the batch already holds.
+// As many complete records as both mates' pieces hold are taken (compress.cpp:614-666 reads the mates in step);
+// consumed[m] says how many bytes of each piece that was, the caller hands the rest in again in front of the next
+// piece.  Ingest, quality counters and the tie-break of the new rows (against all rows before them) run here; order,
+// emit and entropy run once, over everything, when the caller has no more input.
+extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2,
+                                   int final_piece, uint64_t consumed[2], void *stream) {
+  if (!b || !consumed || (n1 && !d_text1) || (b->nm == 2 && n2 && !d_text2)) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (b->tok_open) { set_err(c, "a tokenization is still open"); return SCALCE_ERR_ARG; }
+  if (!b->appending) { batch_restart(b); b->appending = true; }
+  const uint8_t *text[2] = {d_text1, d_text2};
+  const u64 nbytes[2] = {n1, b->nm == 2 ? n2 : 0};
+  consumed[0] = consumed[1] = 0;
+  u64 nlines[2] = {0, 0}, nrec = ~0ull;
+  u8 last[2] = {'\n', '\n'};
+  {
+    StageTimer tm(b, ST_INGEST, s);
+    for (int m = 0; m < b->nm; m++)
+      if (nbytes[m]) { int rc = piece_count(b, m, text[m], nbytes[m], s, &nlines[m], &last[m]); if (rc) return rc; }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    for (int m = 0; m < b->nm; m++) nrec = nlines[m] / 4 < nrec ? nlines[m] / 4 : nrec;
+    if (final_piece) {
+      for (int m = 0; m < b->nm; m++)
+        if ((nlines[m] & 3) || last[m] != '\n') {
+          set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)(4 * b->N + nlines[m]));
+          return SCALCE_ERR_FORMAT;
+        }
+      if (b->nm == 2 && nlines[0] != nlines[1]) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
+    }
+    b->base = b->N;
+    b->NP = nrec;
+    if (b->base + nrec >= (1ull << 32) - 64) { set_err(c, "a batch holds fewer than 2^32 reads"); return SCALCE_ERR_CAPACITY; }
+    { int rc = reserve_rows(b, b->base + nrec, b->base, s); if (rc) return rc; }
+    for (int m = 0; m < b->nm; m++) {
+      int rc = piece_unpack(b, m, text[m], nbytes[m], nrec, s);
+      if (rc) return rc;
+      b->ingested[m] = true;
+      if (nrec) HIP_TRY(c, hipMemcpyAsync(&consumed[m], b->line_end[m].as<u64>() + 4 * nrec - 1, sizeof(u64), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (nrec) for (int m = 0; m < b->nm; m++) consumed[m] += 1;  // behind the newline that ends the last record taken
+  }
+  b->N = b->base + nrec;
+  int rc;
+  if ((rc = scalce_batch_quality(b, stream))) return rc;
+  if ((rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
+  return SCALCE_OK;
+}
+
+extern "C" void scalce_batch_set_lean(scalce_batch *b, int lean) {
+  if (b) b->lean = lean != 0;
 }
 
 // ---- stage 1: quality statistics -------------------------------------------------------------------
@@ -491,27 +658,33 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
   StageTimer tm(b, ST_QUALITY, s);
   for (int m = 0; m < b->nm; m++) {
     if (!b->ingested[m]) { set_err(c, "ingest mate %d first", m + 1); return SCALCE_ERR_ARG; }
-    HIP_TRY(c, hipMemsetAsync(b->freq4[m].p, 0, sizeof(u64) * 512000, s));
+    if (b->base == 0) {  // counters run over all pieces of the batch
+      HIP_TRY(c, hipMemsetAsync(b->freq4[m].p, 0, sizeof(u64) * 512000, s));
+      b->tri_expected[m] = 0;
+    }
     if (b->p.no_ac) continue;  // statistics are skipped under -A (qualities.cpp:185)
-    const u64 n = b->N * (u64)b->L[m];
+    const u64 n = b->NP * (u64)b->L[m], before = b->base * (u64)b->L[m];
     if (!n) continue;
+    const u8 *q = b->q[m].as<u8>() + before;
     u64 *hist = b->d_small64 + 16;  // 256 symbol counters live behind the scalar scratch
     HIP_TRY(c, hipMemsetAsync(hist, 0, sizeof(u64) * 256, s));
-    LAUNCH(sym_hist_k, 2048, 256, 0, s, b->q[m].as<u8>(), n, hist);
+    LAUNCH(sym_hist_k, 2048, 256, 0, s, q, n, hist);
+    u32 *prev = b->d_small + 20 + 2 * m;  // the two symbols in front of this piece
+    LAUNCH(tri_prev_k, 1, 1, 0, s, q, before, b->p.qprev[m][0], b->p.qprev[m][1], prev);
     u32 *range = b->d_small + 14;  // {lo, A}: span of the symbols that occur
-    LAUNCH(tri_range_k, 1, 64, 0, s, hist, b->p.qprev[m][0], b->p.qprev[m][1], range);
+    LAUNCH(tri_range_k, 1, 64, 0, s, hist, prev, range);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(b->d_small64 + 300);  // one tile counter per pass
     HIP_TRY(c, hipMemsetAsync(tiles, 0, sizeof(u64) * TRI_MAX_PASSES, s));
     for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
-      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, b->q[m].as<u8>(), n, b->p.qprev[m][0], b->p.qprev[m][1], pass, range,
-             b->freq4[m].as<u64>(), tiles);
-    {  // one count per symbol with two predecessors (the shard's first two have them only when the caller passed qprev)
+      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, q, n, prev, pass, range, b->freq4[m].as<u64>(), tiles);
+    {  // one count per symbol with two predecessors (the run's first two have them only when the caller passed qprev)
       const bool p0 = b->p.qprev[m][0] < 80, p1 = b->p.qprev[m][1] < 80;
-      const u64 skip = p1 ? (p0 ? 0 : 1) : 2;
-      const u64 expected = n > skip ? n - skip : 0;
+      const u64 carried = p1 ? (p0 ? 2 : 1) : 0;
+      const u64 have = carried + before >= 2 ? 2 : carried + before;
+      b->tri_expected[m] += n > 2 - have ? n - (2 - have) : 0;
       u64 *acc = b->d_small64 + 400 + 2 * m;
       HIP_TRY(c, hipMemsetAsync(acc, 0, 2 * sizeof(u64), s));
-      LAUNCH(tri_check_k, 64, 256, 0, s, b->freq4[m].as<u64>(), expected, acc, reinterpret_cast<u32 *>(acc + 1), b->d_err);
+      LAUNCH(tri_check_k, 64, 256, 0, s, b->freq4[m].as<u64>(), b->tri_expected[m], acc, reinterpret_cast<u32 *>(acc + 1), b->d_err);
     }
   }
   return SCALCE_OK;
@@ -524,7 +697,8 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
-  const u64 N = b->N;
+  const u64 N = b->NP;  // the rows of this piece, [base, base + NP); earlier pieces are settled
+  const u8 *packed0 = b->packed[0].as<u8>() + b->base * (u64)b->stride[0];
   b->jacobi_iters = 0;
   b->tok_open = true;
   const u32 nb1 = (u32)c->A.n_buckets + 1;  // buckets incl. root
@@ -532,10 +706,12 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   ENSURE(b, b->tok_pos, sizeof(u32) * (N + 1));
   ENSURE(b, b->tie_index, sizeof(u32) * (N + 1));
   ENSURE(b, b->ev_off, sizeof(u32) * (N + 1));
-  ENSURE(b, b->bucket, sizeof(u32) * (N + 1));
-  ENSURE(b, b->endv, sizeof(u16) * (N + 1));
-  ENSURE(b, b->tokens, sizeof(int32_t) * 2 * (N + 1));
   ENSURE(b, b->counts, sizeof(u64) * (nb1 + 1));
+  if (!b->counts_total.p) {
+    ENSURE(b, b->counts_total, sizeof(u64) * (nb1 + 1));
+    ENSURE(b, b->prior_buf, sizeof(u64) * (nb1 + 1));
+  }
+  if (b->base == 0) HIP_TRY(c, hipMemsetAsync(b->counts_total.p, 0, sizeof(u64) * (nb1 + 1), s));
   ENSURE(b, b->seg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->Gseg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(2 * N + 1024) + 1024));
@@ -550,7 +726,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   {
     TokArgs a;
     a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
-    a.packed = b->packed[0].as<u8>(); a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
+    a.packed = packed0; a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     const size_t sh = (size_t)a.lds_states * 20;
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
@@ -581,7 +757,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   ENSURE(b, b->cand_place, sizeof(u32) * (ncap + 2));
   if (ntie) {
     TieArgs a;
-    a.next = c->d_next; a.outinfo = c->d_outinfo; a.packed = b->packed[0].as<u8>(); a.L = b->L[0]; a.stride = b->stride[0];
+    a.next = c->d_next; a.outinfo = c->d_outinfo; a.packed = packed0; a.L = b->L[0]; a.stride = b->stride[0];
     a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.bucket_level = c->d_bucket_level;
     a.tok_bucket = b->tok_bucket.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_pos = b->cand_pos.as<u32>();
     a.tie_ncand = b->tie_ncand.as<u32>();
@@ -653,6 +829,14 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
 static int tokenize_sweep_enqueue(scalce_batch *b, const uint64_t *d_prior, u32 *flag, hipStream_t s) {
   scalce_ctx *c = b->ctx;
   const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie;
+  if (b->base) {  // reads of this batch's earlier pieces count as well (bin_size is cumulative, reads.cpp:246)
+    if (d_prior) {
+      LAUNCH(add_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), b->counts_total.as<u64>(), b->prior_buf.as<u64>());
+      d_prior = b->prior_buf.as<uint64_t>();
+    } else {
+      d_prior = b->counts_total.as<uint64_t>();
+    }
+  }
   u32 *d0 = b->dirty.as<u32>(), *d1 = d0 + nb1 + 64;
   u32 *dirty_in = b->dirty_cur ? d1 : d0, *dirty_out = b->dirty_cur ? d0 : d1;
   u64 *prior_seen = reinterpret_cast<u64 *>(d0 + 2 * (size_t)(nb1 + 64));
@@ -681,7 +865,7 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   *changed = 0;
-  if (!b->N || !b->ntie) return SCALCE_OK;
+  if (!b->NP || !b->ntie) return SCALCE_OK;
   { int rc = tokenize_sweep_enqueue(b, d_prior, b->d_small + 4, s); if (rc) return rc; }
   u32 ch = 0;
   { int rc = read_u32(b, b->d_small + 4, &ch, 1, s); if (rc) return rc; }
@@ -697,13 +881,16 @@ extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   b->tok_open = false;
-  const u64 N = b->N;
+  const u64 N = b->NP;
+  const u32 nb1 = (u32)c->A.n_buckets + 1;
+  // reads per bucket over all pieces so far: what the next piece's tie-break starts from, and what the emit stage lays out
+  LAUNCH(add_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, b->counts.as<u64>(), b->counts_total.as<u64>(), b->counts_total.as<u64>());
   if (!N) return SCALCE_OK;
   FinalizeArgs a;
   a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
   a.tie_off = b->tie_off.as<u32>(); a.choice = b->choice.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
   a.cand_pos = b->cand_pos.as<u32>(); a.bucket_pattern = c->d_bucket_pattern; a.root_bucket = (u32)c->A.n_buckets;
-  a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>(); a.tokens = b->tokens.as<int32_t>();
+  a.bucket = b->bucket.as<u32>() + b->base; a.end = b->endv.as<u16>() + b->base; a.tokens = b->tokens.as<int32_t>() + 2 * b->base;
   LAUNCH(finalize_k, cdiv(N, 256), 256, 0, s, a);
   return SCALCE_OK;
 }
@@ -715,7 +902,7 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
   // nothing (and costs next to nothing), while a round trip per sweep left the stream idle 47 times per shard.
   hipStream_t s = (hipStream_t)stream;
   constexpr int SWEEPS_PER_LOOK = 4;
-  for (bool done = !(b->N && b->ntie); !done;) {
+  for (bool done = !(b->NP && b->ntie); !done;) {
     StageTimer tm(b, ST_TOKENIZE, s);
     u32 *flags = b->d_small + 32;
     for (int i = 0; i < SWEEPS_PER_LOOK; i++)
@@ -888,12 +1075,14 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
   ENSURE(b, b->bucket_off, sizeof(u64) * (nb1 + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(nb1) + scan_ws_elems(N + 1) + 1024));
   u64 *ws = b->scan_ws.as<u64>();
-  u64 *counts = b->counts.as<u64>();
+  u64 *counts = b->counts_total.as<u64>();  // reads per bucket over every piece of the batch
+  if (!counts) { set_err(c, "tokenize first"); return SCALCE_ERR_ARG; }
   exclusive_scan<u64>(LoadAs<u64, u64>{counts}, nb1, StoreTo<u64>{b->bucket_first.as<u64>()}, ws, b->d_small64 + 1, s);
   exclusive_scan<u64>(BucketBytes{counts, c->d_bucket_level, b->L[0], b->sz_meta}, nb1, StoreTo<u64>{b->bucket_off.as<u64>()}, ws,
                       b->d_small64 + 2, s);
   if (b->p.use_names) {
     ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
+    ENSURE(b, b->outlen, N + 64);
     if (N) LAUNCH(name_outlen_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->outlen.as<u8>());
     exclusive_scan<u64>(NameLenSeq{b->outlen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
   }
@@ -913,10 +1102,11 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.key_end_bits = b->key_end_bits;
     LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
     if (b->p.use_names)
-      LAUNCH(emit_names_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->line_end[0].as<u64>(), b->d_text[0],
-             b->name_off.as<u64>(), b->namecell.as<u8>(), b->out_names.as<u8>());
+      LAUNCH(emit_names_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namecell.as<u8>(), b->name_in_off.as<u64>(),
+             b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
     for (int m = 0; m < b->nm; m++) {
       const u32 w = (u32)b->L[m];
+      ENSURE(b, b->qs[m], (size_t)w * N + 64);
       const u64 items = ((w & 3) == 0) ? N * (w / 4) : N * w;
       LAUNCH(gather_rows_k, cdiv(items, 256), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
     }
@@ -1346,7 +1536,7 @@ extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, c
     case SCALCE_OUT_TOKENS: *d_ptr = b->tokens.p; *nbytes = sizeof(int32_t) * 2 * b->N; break;
     case SCALCE_OUT_PERM: *d_ptr = b->perm; *nbytes = sizeof(u32) * b->N; break;
     case SCALCE_OUT_QSTREAM: *d_ptr = b->qs[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
-    case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->counts.p; *nbytes = sizeof(u64) * nb1; break;
+    case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->tok_open ? b->counts.p : b->counts_total.p; *nbytes = sizeof(u64) * nb1; break;
     case SCALCE_OUT_QINPUT: *d_ptr = b->q[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
     case SCALCE_OUT_NAMELEN: *d_ptr = b->namelen.p; *nbytes = b->N; break;
     default: return SCALCE_ERR_ARG;

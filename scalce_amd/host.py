@@ -72,6 +72,10 @@ def lib():
     L.scalce_batch_create.argtypes = [vp, C.POINTER(Params), u64, u64, C.POINTER(vp)]
     L.scalce_batch_destroy.argtypes = [vp]
     L.scalce_batch_ingest.argtypes = [vp, i32, vp, u64, vp]
+    L.scalce_batch_append.argtypes = [vp, vp, u64, vp, u64, i32, C.POINTER(u64), vp]
+    L.scalce_batch_reset.argtypes = [vp]
+    L.scalce_batch_set_lean.argtypes = [vp, i32]
+    L.scalce_batch_set_lean.restype = None
     L.scalce_batch_quality.argtypes = [vp, vp]
     L.scalce_batch_tokenize.argtypes = [vp, vp, vp]
     L.scalce_batch_order.argtypes = [vp, vp]
@@ -260,6 +264,18 @@ class Batch:
 
     def ingest(self, mate, d_text, nbytes, stream=0):
         self._check(self.L.scalce_batch_ingest(self.h, mate, d_text, int(nbytes), stream))
+
+    def append(self, d_text1, n1, d_text2=None, n2=0, final=False, stream=0):
+        """Next piece of the read stream behind the rows already held; returns the bytes consumed per mate."""
+        used = (C.c_uint64 * 2)()
+        self._check(self.L.scalce_batch_append(self.h, d_text1, int(n1), d_text2, int(n2), int(final), used, stream))
+        return used[0], used[1]
+
+    def reset(self):
+        self._check(self.L.scalce_batch_reset(self.h))
+
+    def set_lean(self, lean=True):
+        self.L.scalce_batch_set_lean(self.h, int(lean))
 
     def quality(self, stream=0):
         self._check(self.L.scalce_batch_quality(self.h, stream))
