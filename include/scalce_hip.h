@@ -102,6 +102,23 @@ int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_text, uint64
 int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2,
                         int final_piece, uint64_t consumed[2], void *stream);
 int scalce_batch_reset(scalce_batch *b);
+
+/* The streaming host around scalce_batch_append -- what replaces the reader half of thread() (compress.cpp:614-671) and
+ * the spill files (:708-715) for inputs of any size: one reader thread per mate pulls the stream through `rd` into
+ * pinned chunks of piece_bytes (0 = 1 GiB), the chunks go up with hipMemcpyAsync while the previous piece is ingested,
+ * counted and tokenized, the unconsumed tail of a piece is put in front of the next one on the device; then order, emit
+ * and entropy run once over the run.  On success *out holds the results (scalce_batch_output; the caller destroys it).
+ * rd(user, dst, cap) returns the bytes it stored (any number up to cap), 0 at the end of the stream, < 0 on error; it is
+ * called from the reader thread of its mate only.  reads_hint sizes the row arrays (0: they grow as the run comes in);
+ * lean = 1 releases device buffers as stages finish (scalce_batch_set_lean).  errbuf receives the message on failure. */
+typedef int64_t (*scalce_read_fn)(void *user, void *dst, uint64_t cap);
+typedef struct {
+  double total_s, read_wait_s, h2d_wait_s, front_s, order_s, emit_s, entropy_s;
+  uint64_t rounds, reads, bytes[2];
+} scalce_stream_stats;
+int scalce_stream_compress(scalce_ctx *ctx, const scalce_params *p, scalce_read_fn rd1, void *user1, scalce_read_fn rd2,
+                           void *user2, uint64_t piece_bytes, uint64_t reads_hint, int lean, scalce_batch **out,
+                           scalce_stream_stats *stats, char *errbuf, size_t errcap);
 /* lean = 1: a stage releases the device buffers that no later stage reads (q' in input order once the reordered stream
  * exists, rows and sort scratch once the records are emitted): outputs 5, 6, 9 become unavailable, runs sized for most
  * of HBM fit. */

@@ -11,7 +11,9 @@
 // fallback -- without a GPU the tool stops with an error.
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <sys/time.h>
 #include <zlib.h>
 #include <atomic>
@@ -113,13 +115,16 @@ static int g_threads = 1;
 struct OutFile {
   bool gz = false;
   FILE *f = nullptr;
-  std::vector<uint8_t> pending;  // gz only
+  std::vector<uint8_t> pending;  // gz only: bytes not deflated yet
+  uint64_t written = 0;
+  static constexpr size_t MEMBER = 4u << 20;
   void open(const std::string &path, bool gz_) {
     gz = gz_;
     f = path == "-" ? stdout : fopen(path.c_str(), "wb");
     if (!f) FAIL("Cannot create %s\n", path.c_str());
   }
   void raw(const uint8_t *b, size_t n) {
+    written += n;
     while (n) {
       size_t k = n > (1u << 30) ? (1u << 30) : n;
       if (fwrite(b, 1, k, f) != k) FAIL("write failed\n");
@@ -128,8 +133,10 @@ struct OutFile {
   }
   void write(const void *p, size_t n) {
     const uint8_t *b = static_cast<const uint8_t *>(p);
-    if (gz) pending.insert(pending.end(), b, b + n);
-    else raw(b, n);
+    if (!gz) { raw(b, n); return; }
+    pending.insert(pending.end(), b, b + n);
+    // enough for every thread: deflate what is there, member by member (the stream never has to sit in memory whole)
+    if (pending.size() >= MEMBER * (size_t)std::max(1, g_threads) * 2) flush_members(false);
   }
   static void deflate_member(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
     z_stream z;
@@ -142,23 +149,31 @@ struct OutFile {
     out.resize(z.total_out);
     deflateEnd(&z);
   }
+  void flush_members(bool all) {
+    const size_t whole = pending.size() / MEMBER, nchunks = all ? (pending.empty() ? 0 : (pending.size() + MEMBER - 1) / MEMBER) : whole;
+    if (!nchunks) return;
+    std::vector<std::vector<uint8_t>> members(nchunks);
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t i; (i = next.fetch_add(1)) < nchunks;) {
+        const size_t a = i * MEMBER, b = std::min(pending.size(), a + MEMBER);
+        deflate_member(pending.data() + a, b - a, members[i]);
+      }
+    };
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, g_threads), nchunks);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (auto &m : members) raw(m.data(), m.size());
+    const size_t done = std::min(pending.size(), nchunks * MEMBER);
+    pending.erase(pending.begin(), pending.begin() + done);
+  }
   void close() {
     if (gz && f) {
-      const size_t chunk = 4u << 20, nchunks = pending.empty() ? 1 : (pending.size() + chunk - 1) / chunk;
-      std::vector<std::vector<uint8_t>> members(nchunks);
-      std::atomic<size_t> next{0};
-      auto work = [&]() {
-        for (size_t i; (i = next.fetch_add(1)) < nchunks;) {
-          const size_t a = i * chunk, b = std::min(pending.size(), a + chunk);
-          deflate_member(pending.data() + a, b - a, members[i]);
-        }
-      };
-      const int nt = (int)std::min<size_t>((size_t)std::max(1, g_threads), nchunks);
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nt; t++) pool.emplace_back(work);
-      work();
-      for (auto &t : pool) t.join();
-      for (auto &m : members) raw(m.data(), m.size());
+      const bool nothing = written == 0 && pending.empty();
+      flush_members(true);
+      if (nothing) { std::vector<uint8_t> m; deflate_member(nullptr, 0, m); raw(m.data(), m.size()); }  // an empty gzip file
       pending.clear(); pending.shrink_to_fit();
     }
     if (f && f != stdout) fclose(f);
@@ -177,7 +192,124 @@ static std::vector<uint8_t> fetch(scalce_ctx *ctx, scalce_batch *b, int which, i
   return v;
 }
 
-// sampling loop of quality_mapping_init (qualities.cpp:64-97) on the in-memory text
+// A device stream to a file: slices come down into two pinned buffers in turn, the write (or deflate) of one slice runs
+// while the next is on its way.
+struct Downloader {
+  static constexpr size_t SLICE = 64u << 20;
+  uint8_t *pin[2] = {nullptr, nullptr};
+  hipStream_t s = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  Downloader() {
+    HIPOK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) { HIPOK(hipHostMalloc(reinterpret_cast<void **>(&pin[i]), SLICE, hipHostMallocDefault)); HIPOK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); }
+  }
+  ~Downloader() {
+    for (int i = 0; i < 2; i++) { if (pin[i]) hipHostFree(pin[i]); if (ev[i]) hipEventDestroy(ev[i]); }
+    if (s) hipStreamDestroy(s);
+  }
+  void to_file(scalce_ctx *ctx, scalce_batch *b, int which, int mate, OutFile &f) {
+    const void *d = nullptr;
+    uint64_t n = 0;
+    SCOK(ctx, scalce_batch_output(b, which, mate, &d, &n));
+    const uint8_t *src = static_cast<const uint8_t *>(d);
+    const uint64_t nslices = (n + SLICE - 1) / SLICE;
+    auto start = [&](uint64_t i) {
+      const uint64_t off = i * SLICE, k = std::min<uint64_t>(SLICE, n - off);
+      HIPOK(hipMemcpyAsync(pin[i & 1], src + off, k, hipMemcpyDeviceToHost, s));
+      HIPOK(hipEventRecord(ev[i & 1], s));
+    };
+    if (nslices) start(0);
+    for (uint64_t i = 0; i < nslices; i++) {
+      HIPOK(hipEventSynchronize(ev[i & 1]));
+      if (i + 1 < nslices) start(i + 1);
+      f.write(pin[i & 1], (size_t)std::min<uint64_t>(SLICE, n - i * SLICE));
+    }
+  }
+};
+
+// One mate's input: the files of the command line one after the other (compress.cpp:756-797 runs them through the same
+// trie; the record stream is their concatenation), each plain or gzip (the reference opens everything through zlib,
+// :767-779).  Plain files are read with read(2) straight into the pinned chunk the streaming host hands in.
+struct MateSource {
+  std::vector<std::string> files;
+  size_t cur = 0;
+  int fd = -1;
+  gzFile gz = nullptr;
+  std::vector<uint8_t> peek;  // bytes read ahead for the quality sample, served first
+  size_t peek_pos = 0;
+  bool all_plain = true;
+  bool open_next() {
+    while (cur < files.size()) {
+      const std::string &path = files[cur++];
+      fd = ::open(path.c_str(), O_RDONLY);
+      if (fd < 0) FAIL("Cannot read file %s\n", path.c_str());
+      uint8_t mg[2] = {0, 0};
+      const ssize_t k = ::pread(fd, mg, 2, 0);
+      if (k == 2 && mg[0] == 0x1F && mg[1] == 0x8B) {
+        all_plain = false;
+        gz = gzdopen(fd, "rb");
+        if (!gz) FAIL("Cannot read file %s\n", path.c_str());
+        gzbuffer(gz, 1 << 20);
+        fd = -1;
+      } else {
+#ifdef POSIX_FADV_SEQUENTIAL
+        posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+#endif
+      }
+      return true;
+    }
+    return false;
+  }
+  int64_t read_raw(void *dst, uint64_t cap) {
+    for (;;) {
+      if (fd < 0 && !gz && !open_next()) return 0;
+      int64_t k;
+      if (gz) k = gzread(gz, dst, (unsigned)std::min<uint64_t>(cap, 1u << 30));
+      else k = ::read(fd, dst, (size_t)std::min<uint64_t>(cap, 1u << 30));
+      if (k < 0) return -1;
+      if (k > 0) return k;
+      if (gz) { gzclose(gz); gz = nullptr; } else { ::close(fd); fd = -1; }
+    }
+  }
+  int64_t read(void *dst, uint64_t cap) {
+    if (peek_pos < peek.size()) {
+      const size_t k = (size_t)std::min<uint64_t>(cap, peek.size() - peek_pos);
+      memcpy(dst, peek.data() + peek_pos, k);
+      peek_pos += k;
+      if (peek_pos == peek.size()) { std::vector<uint8_t>().swap(peek); peek_pos = 0; }
+      return (int64_t)k;
+    }
+    return read_raw(dst, cap);
+  }
+  // read ahead until the text holds `records` records (or the stream ends): quality_mapping_init's sample
+  void fill_peek(int records) {
+    size_t lines = 0, scanned = 0;
+    for (;;) {
+      const uint8_t *p = peek.data();
+      while (scanned < peek.size() && lines < 4 * (size_t)records) {
+        const void *nl = memchr(p + scanned, '\n', peek.size() - scanned);
+        if (!nl) { scanned = peek.size(); break; }
+        scanned = (size_t)((const uint8_t *)nl - p) + 1;
+        lines++;
+      }
+      if (lines >= 4 * (size_t)records) return;
+      const size_t old = peek.size(), step = 16u << 20;
+      peek.resize(old + step);
+      int64_t got = 0;
+      while ((size_t)got < step) {
+        const int64_t k = read_raw(peek.data() + old + got, step - (size_t)got);
+        if (k < 0) FAIL("Read error\n");
+        if (k == 0) break;
+        got += k;
+      }
+      peek.resize(old + (size_t)got);
+      if (!got) return;
+    }
+  }
+  static int64_t read_cb(void *user, void *dst, uint64_t cap) { return static_cast<MateSource *>(user)->read(dst, cap); }
+};
+
+// sampling loop of quality_mapping_init (qualities.cpp:64-97) on the text read ahead
 static void sample_stats(const std::vector<uint8_t> &t, int sample, int32_t stat[128], int &read_length) {
   memset(stat, 0, 128 * sizeof(int32_t));
   size_t pos = 0;
@@ -219,43 +351,55 @@ static std::vector<uint8_t> load_core_table(const Options &o, const char *argv0,
 static int do_compress(const Options &o, const std::vector<std::string> &files, scalce_ctx *ctx) {
   const double t0 = now();
   const int nm = o.paired ? 2 : 1;
-  std::vector<uint8_t> text[2];
   uint64_t original = 0;
   int32_t qhist[128];
   scalce_params p;
   scalce_params_default(&p);
   p.paired = o.paired; p.use_names = o.use_names; p.no_ac = o.no_ac; p.bucket_set_size = o.bucket_set_size;
   LOG("Preprocessing FASTQ files ...\n");
-  for (size_t F = 0; F < files.size(); F++)
-    for (int m = 0; m < nm; m++) {
+  MateSource src[2];
+  for (int m = 0; m < nm; m++) {
+    for (size_t F = 0; F < files.size(); F++) {
       std::string path = files[F];
       if (m && !second_file(files[F], path))
         FAIL("Cannot get file name for paired end for file %s. File should contain character 1.\n", files[F].c_str());
-      std::vector<uint8_t> t = read_maybe_gz(path);
       struct stat st;
       if (stat(path.c_str(), &st) == 0) original += (uint64_t)st.st_size;
-      if (F == 0) {  // get_quality_stats looks at the first file only (compress.cpp:761)
-        int rl = 0;
-        sample_stats(t, o.sample, qhist, rl);
-        scalce_qmap_init(&p.qmap[m], qhist, o.lossy);
-        p.read_len[m] = rl;
-        LOG("\tPaired end #%d, quality offset: %d\n\t               read length: %d\n", m + 1, p.qmap[m].offset, rl);
-      }
-      if (text[m].empty()) text[m].swap(t); else text[m].insert(text[m].end(), t.begin(), t.end());
+      src[m].files.push_back(path);
     }
-  if (p.read_len[0] <= 0) FAIL("Cannot determine the read length of %s\n", files[0].c_str());
-  const uint64_t max_text = (text[0].size() > text[1].size() ? text[0].size() : text[1].size()) + 64;
-  const uint64_t max_reads = text[0].size() / (2 * (uint64_t)p.read_len[0] + 4) + 16;
-  scalce_batch *b = nullptr;
-  SCOK(ctx, scalce_batch_create(ctx, &p, max_reads, max_text, &b));
-  void *d[2] = {nullptr, nullptr};
-  for (int m = 0; m < nm; m++) {
-    HIPOK(hipMalloc(&d[m], text[m].size() + 64));
-    HIPOK(hipMemcpy(d[m], text[m].data(), text[m].size(), hipMemcpyHostToDevice));
+    // get_quality_stats looks at the first file only (compress.cpp:761)
+    int rl = 0;
+    src[m].fill_peek(o.sample);
+    sample_stats(src[m].peek, o.sample, qhist, rl);
+    scalce_qmap_init(&p.qmap[m], qhist, o.lossy);
+    p.read_len[m] = rl;
+    LOG("\tPaired end #%d, quality offset: %d\n\t               read length: %d\n", m + 1, p.qmap[m].offset, rl);
   }
+  if (p.read_len[0] <= 0) FAIL("Cannot determine the read length of %s\n", files[0].c_str());
+  // rows to expect: exact enough for plain text (a record is 2 L + 6 bytes plus its name), unknown behind gzip
+  uint64_t hint = 0;
+  if (src[0].all_plain && !src[0].gz) {
+    uint64_t bytes = 0;
+    for (auto &f : src[0].files) { struct stat st; if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size; }
+    hint = bytes / (2 * (uint64_t)p.read_len[0] + 8) + 64;
+    for (auto &f : src[0].files) { int fd = ::open(f.c_str(), O_RDONLY); uint8_t mg[2] = {0, 0}; if (fd >= 0) { if (::pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1F && mg[1] == 0x8B) hint = 0; ::close(fd); } }
+  }
+  uint64_t piece = 1ull << 30;
+  if (const char *e = getenv("SCALCE_PIECE_BYTES")) piece = strtoull(e, nullptr, 10);
+  {  // small inputs: no point in pinning gigabytes
+    uint64_t bytes = 0;
+    for (auto &f : src[0].files) { struct stat st; if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size; }
+    if (hint && bytes + (1u << 20) < piece) piece = bytes + (1u << 20);
+  }
+  scalce_batch *b = nullptr;
+  scalce_stream_stats ss;
+  char emsg[512] = "";
   const double t1 = now();
-  SCOK(ctx, scalce_batch_compress(b, (const uint8_t *)d[0], text[0].size(), (const uint8_t *)d[1], text[1].size(), nullptr));
-  SCOK(ctx, scalce_batch_finish(b, nullptr));
+  if (scalce_stream_compress(ctx, &p, MateSource::read_cb, &src[0], nm == 2 ? MateSource::read_cb : nullptr, nm == 2 ? &src[1] : nullptr, piece,
+                             hint, 1, &b, &ss, emsg, sizeof emsg)) {
+    fprintf(stderr, "%s\n", emsg[0] ? emsg : scalce_last_error(ctx));
+    exit(1);
+  }
   const double t2 = now();
   const uint64_t N = scalce_batch_reads(b);
   LOG("\tDone with file %s, %llu reads found\n", files[0].c_str(), (unsigned long long)N);
@@ -266,14 +410,14 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   const uint8_t magic[8] = {'s', 'c', 'a', 'l', 'c', 'e', '2', '2'};
   const bool gz = o.container == 1;
   uint64_t new_size = 0;
-  std::vector<uint8_t> names = o.use_names ? fetch(ctx, b, SCALCE_OUT_NAMES, 0) : std::vector<uint8_t>();
+  Downloader down;
   for (int m = 0; m < nm; m++) {
     char fn[4096];
     OutFile fR, fQ, fN;
     snprintf(fn, sizeof fn, "%s_%d.scalcer", o.out.c_str(), m + 1); fR.open(fn, gz);
     const int32_t noac = o.no_ac, len32 = p.read_len[m];
     fR.write(magic, 8); fR.write(&noac, 4); fR.write(&len32, 4);
-    { auto v = fetch(ctx, b, SCALCE_OUT_READS, m); fR.write(v.data(), v.size()); }
+    down.to_file(ctx, b, SCALCE_OUT_READS, m, fR);
     fR.close();
     snprintf(fn, sizeof fn, "%s_%d.scalceq", o.out.c_str(), m + 1); fQ.open(fn, o.no_ac ? gz : false);  // :249
     const int64_t phred = p.qmap[0].offset;  // mate 1's offset for both (compress.cpp:294,816-817)
@@ -284,12 +428,12 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
       const uint64_t total = N * (uint64_t)p.read_len[m];
       fQ.write(&total, 8);
     }
-    { auto v = fetch(ctx, b, SCALCE_OUT_QUAL, m); fQ.write(v.data(), v.size()); }
+    down.to_file(ctx, b, SCALCE_OUT_QUAL, m, fQ);
     fQ.close();
     snprintf(fn, sizeof fn, "%s_%d.scalcen", o.out.c_str(), m + 1); fN.open(fn, gz);
     const uint8_t un = o.use_names ? 1 : 0;
     fN.write(magic, 8); fN.write(&un, 1);
-    if (o.use_names) fN.write(names.data(), names.size());  // mate 2 repeats mate 1's names (:450-454)
+    if (o.use_names) down.to_file(ctx, b, SCALCE_OUT_NAMES, 0, fN);  // mate 2 repeats mate 1's names (:450-454)
     else { const int64_t z = 0; fN.write(&z, 8); fN.write(o.library.data(), o.library.size()); }
     fN.close();
     for (const char *ext : {"r", "q", "n"}) {
@@ -304,15 +448,17 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   uint64_t unbucketed = 0;
   if (nc >= 8) SCOK(ctx, scalce_memcpy_d2h(ctx, &unbucketed, (const uint8_t *)dc + nc - 8, 8));
   scalce_batch_destroy(b);
-  for (int m = 0; m < nm; m++) hipFree(d[m]);
   const double t3 = now();
   LOG("Statistics:\n\tTotal number of reads: %llu\n\tRead length: first end %d\n", (unsigned long long)N, p.read_len[0]);
   if (o.paired) LOG("\t             second end %d\n", p.read_len[1]);
   LOG("\tUnbucketed reads count: %llu, bucketed percentage %.2lf\n", (unsigned long long)unbucketed,
       N ? 100.0 * (double)(N - unbucketed) / (double)N : 0.0);
   LOG("\tLossy percentage: %d\n", o.lossy);
-  LOG("\tTie reads: %u, fixed-point sweeps: %u, spill chunks: %u\n", st4[0], st4[2], st4[3]);
-  LOG("\tTime elapsed: %.2f s (read+upload %.2f, GPU hot path %.2f, write %.2f)\n", t3 - t0, t1 - t0, t2 - t1, t3 - t2);
+  LOG("\tSpill chunks: %u, pieces streamed: %llu\n", st4[3], (unsigned long long)ss.rounds);
+  LOG("\tTime elapsed: %.2f s (sample %.2f; stream %.2f = waiting for the reader %.2f + for uploads %.2f + ingest/count/tokenize %.2f; "
+      "order %.2f, emit %.2f, entropy %.2f; download+write %.2f)\n",
+      t3 - t0, t1 - t0, ss.total_s - ss.order_s - ss.emit_s - ss.entropy_s, ss.read_wait_s, ss.h2d_wait_s, ss.front_s, ss.order_s, ss.emit_s,
+      ss.entropy_s, t3 - t2);
   LOG("\tOriginal size: %.2lfM, new size: %.2lfM, compression factor: %.2lf\n", original / (1024.0 * 1024.0),
       new_size / (1024.0 * 1024.0), new_size ? (double)original / (double)new_size : 0.0);
   return 0;

@@ -261,7 +261,8 @@ struct scalce_batch {
   DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, name_off, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
-  std::vector<AcBlockDesc> ac_desc_host;  // block descriptors of the last coder launch this shard led
+  AcBlockDesc *ac_desc_host = nullptr;  // block descriptors of the last coder launch this shard led: pinned, so that the
+  u32 ac_desc_cap = 0;                  // asynchronous upload never reads memory the next launch is already rewriting
   u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
   // host-side results
   u64 out_reads_bytes[2] = {0, 0}, out_names_bytes = 0, out_qual_bytes[2] = {0, 0};
@@ -352,6 +353,7 @@ static void free_all(scalce_batch *b) {
   if (b->d_small) hipFree(b->d_small);
   if (b->d_small64) hipFree(b->d_small64);
   for (int m = 0; m < 2; m++) if (b->d_qlut[m]) hipFree(b->d_qlut[m]);
+  if (b->ac_desc_host) hipHostFree(b->ac_desc_host);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   for (auto &pr : b->kev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -1109,6 +1111,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
       ENSURE(b, b->qs[m], (size_t)w * N + 64);
       const u64 items = ((w & 3) == 0) ? N * (w / 4) : N * w;
       LAUNCH(gather_rows_k, cdiv(items, 256), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
+      if (b->lean) { HIP_TRY(c, hipStreamSynchronize(s)); release(b->q[m]); }  // the next mate's stream takes its place
     }
     if (b->nm == 2) {  // mate 2: bare packed reads in the same order (compress.cpp:380-383 with fR = file 4)
       const u32 w = (u32)b->szr[1];
@@ -1119,6 +1122,19 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
              b->out_reads[1].as<u8>());
     }
   } else if (b->nm == 2) b->out_reads_bytes[1] = 0;
+  if (b->lean) {  // nothing behind this stage reads the rows, the tokens or the sort scratch
+    HIP_TRY(c, hipStreamSynchronize(s));
+    DBuf *dead[] = {&b->packed[0], &b->packed[1], &b->namecell, &b->names_in, &b->name_in_off, &b->name_off, &b->outlen,
+                    &b->line_end[0], &b->line_end[1], &b->tile[0], &b->tile[1], &b->tok_bucket, &b->tok_pos, &b->tie_index,
+                    &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos, &b->choice, &b->ev_off,
+                    &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place, &b->chosen, &b->G, &b->cand_place,
+                    &b->bucket, &b->endv, &b->tokens, &b->chunk, &b->perm_a, &b->perm_b, &b->key_a, &b->key_b, &b->hist, &b->S,
+                    &b->run_head, &b->run_hcount, &b->run_rank, &b->runid, &b->run_items_a, &b->run_items_b, &b->run_pos};
+    for (DBuf *d : dead) release(*d);
+    b->perm = nullptr;
+    b->sorted_keys = nullptr;
+    b->row_cap = 0;
+  }
   return SCALCE_OK;
 }
 
@@ -1138,7 +1154,7 @@ struct AcJob {
 static const u64 AC_STRIDE = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
 
 // table -> reciprocal fractions, buffers; one short wait for the largest context total
-static int ac_prepare(AcJob &j, hipStream_t s) {
+static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true) {
   scalce_batch *b = j.b;
   scalce_ctx *c = b->ctx;
   const int m = j.m;
@@ -1159,7 +1175,7 @@ static int ac_prepare(AcJob &j, hipStream_t s) {
   ENSURE(b, b->ac_off[m], sizeof(u64) * (j.nblk + 2));
   // the framed stream is sized for the worst case (every block at its cap): no size has to come back from the
   // device before the frame kernel can be enqueued
-  ENSURE(b, b->out_qual[m], (size_t)j.nblk * (AC_STRIDE + 4) + 64);
+  if (framed_output) ENSURE(b, b->out_qual[m], (size_t)j.nblk * (AC_STRIDE + 4) + 64);
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(j.nblk ? j.nblk : 1) + 64));
   if (!j.nblk) b->out_qual_bytes[m] = 0;
   return SCALCE_OK;
@@ -1230,9 +1246,15 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     }
   } else {
     // block descriptors: the launch may hold blocks of several shards, each with its own table and output
-    std::vector<AcBlockDesc> &d = lead->ac_desc_host;
-    d.clear();
-    d.reserve(total);
+    if (total > lead->ac_desc_cap) {
+      if (lead->ac_desc_host) hipHostFree(lead->ac_desc_host);
+      lead->ac_desc_host = nullptr;
+      lead->ac_desc_cap = 0;
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&lead->ac_desc_host), sizeof(AcBlockDesc) * (size_t)(total + total / 2), hipHostMallocDefault));
+      lead->ac_desc_cap = total + total / 2;
+    }
+    AcBlockDesc *d = lead->ac_desc_host;
+    u32 nd = 0;
     for (int i = 0; i < njobs; i++) {
       scalce_batch *b = jobs[i].b;
       const int m = jobs[i].m;
@@ -1246,11 +1268,11 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
         x.err = b->d_err;
         x.n = (u32)std::min<u64>(AC_BLOCK_SYMS, jobs[i].nsym - off);
         x.index = k;
-        d.push_back(x);
+        d[nd++] = x;
       }
     }
     ENSURE(lead, lead->ac_desc, sizeof(AcBlockDesc) * total);
-    HIP_TRY(c, hipMemcpyAsync(lead->ac_desc.p, d.data(), sizeof(AcBlockDesc) * total, hipMemcpyHostToDevice, ps));
+    HIP_TRY(c, hipMemcpyAsync(lead->ac_desc.p, d, sizeof(AcBlockDesc) * total, hipMemcpyHostToDevice, ps));
     a.desc = lead->ac_desc.as<AcBlockDesc>();
     a.nblocks = total;
     a.out_cap = (u32)AC_STRIDE;
@@ -1348,12 +1370,75 @@ static int ac_table_for(scalce_batch *b, int m, const uint32_t *d_table_override
   return SCALCE_OK;
 }
 
+// Runs with more blocks than a launch should hold (200 M x 150 bp paired: 5 724): the streams are coded window by window --
+// up to AC_WINDOW_BLOCKS blocks per launch over both mates -- into block buffers sized for one window, and every window
+// is framed straight behind the previous one.  Sized for the worst case as the one-launch path does, the buffers of
+// such a run would take 2 x 60 GB per mate.
+constexpr u32 AC_WINDOW_BLOCKS = 2048;  // 256 workgroups of eight
+static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  const u64 N = b->N;
+  const u32 W = AC_WINDOW_BLOCKS / (u32)b->nm;
+  u64 used[2] = {0, 0}, nsym[2] = {0, 0};
+  u32 nblk[2] = {0, 0}, most = 0;
+  for (int m = 0; m < b->nm; m++) {
+    nsym[m] = N * (u64)b->L[m];
+    nblk[m] = cdiv(nsym[m], AC_BLOCK_SYMS);
+    most = nblk[m] > most ? nblk[m] : most;
+    int rc = ac_table_for(b, m, d_table_override, nsym[m], s);
+    if (rc) return rc;
+    b->out_qual_bytes[m] = 0;
+  }
+  bool first = true;
+  for (u32 w0 = 0; w0 < most; w0 += W) {
+    AcJob jobs[2];
+    int nj = 0;
+    for (int m = 0; m < b->nm; m++) {
+      if (w0 >= nblk[m]) continue;
+      const u64 off = (u64)w0 * AC_BLOCK_SYMS;
+      const u64 n = std::min<u64>(nsym[m] - off, (u64)W * AC_BLOCK_SYMS);
+      jobs[nj] = AcJob{b, m, b->qs[m].as<u8>() + off, n, 0, false};
+      int rc = ac_prepare(jobs[nj], s, /*framed_output=*/false);
+      if (rc) return rc;
+      nj++;
+    }
+    if (!nj) break;
+    int rc = ac_launch(jobs, nj, 8, s, s);
+    if (rc) return rc;
+    for (int i = 0; i < nj; i++) {
+      const int m = jobs[i].m;
+      exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, jobs[i].nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->scan_ws.as<u64>(),
+                          b->d_small64 + 8 + m, s);
+      u64 total = 0;
+      if ((rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s))) return rc;
+      if (first) {  // size the framed stream from the first window's ratio; it grows if a later window codes worse
+        const u64 est = (u64)((double)total / (double)jobs[i].nsym * 1.03 * (double)nsym[m]) + (64u << 20);
+        ENSURE(b, b->out_qual[m], est);
+      }
+      if ((rc = ensure_keep(b, b->out_qual[m], used[m] + total + 64, used[m], s))) return rc;
+      LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), jobs[i].nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), AC_STRIDE,
+             b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>() + used[m]);
+      used[m] += total;
+      b->k_out_bytes += total - 4ull * jobs[i].nblk;
+    }
+    first = false;
+  }
+  HIP_TRY(c, hipStreamSynchronize(s));
+  for (int m = 0; m < b->nm; m++) { b->out_qual_bytes[m] = used[m]; b->ent_pending[m] = 0; }
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_table_override, void *stream) {
   if (!b) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
   const u64 N = b->N;
+  if (!b->p.no_ac) {
+    u64 blocks = 0;
+    for (int m = 0; m < b->nm; m++) blocks += cdiv(N * (u64)b->L[m], AC_BLOCK_SYMS);
+    if (blocks > AC_WINDOW_BLOCKS || getenv("SCALCE_AC_WINDOWED")) return entropy_windowed(b, d_table_override, s);
+  }
   if (b->nm == 2 && !b->p.no_ac && ac_blocks_per_wg() == 1) {
     // paired reads: both mates' streams in ONE launch (several blocks per chain wave) instead of two launches of the
     // one-block kernel behind each other -- the same chip, half the time

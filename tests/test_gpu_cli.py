@@ -154,3 +154,58 @@ def test_cli_short_and_long_reads(L, tmp_path):
     run_cli("-d", "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
     O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback")
     assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()
+
+
+@pytest.mark.parametrize("case", ["se_tiny_pieces", "pe_uneven_mates", "gz_input_two_files", "chunks_across_pieces"])
+def test_cli_streams_any_input_in_pieces(case, tmp_path, monkeypatch):
+    """The CLI streams its input through pinned chunks (scalce_stream_compress); however the pieces fall -- cut
+    mid-record, mates with different bytes per record so that one mate's tail grows, gzip input, several input files,
+    -B chunks cut on run-wide sizes -- the archive is the oracle's."""
+    n, L = 30000, 100
+    paired = case == "pe_uneven_mates"
+    files = [tmp_path / "in_1.fq"]
+    b1, q1 = synth.reads_and_quals(n, L, seed=51, n_frac=0.003, dup_frac=0.1)
+    if paired:
+        b2, q2 = synth.reads_and_quals(n, L, seed=52)
+        # mate 2's names carry a long comment: its text is a third longer than mate 1's
+        open(files[0], "wb").write(synth.fastq_bytes_fast(b1, q1, prefix="p.", suffix="/1"))
+        recs = [b"@p.%d/2 " % i + b"c" * 60 + b"\n" + b2[i].tobytes() + b"\n+\n" + q2[i].tobytes() + b"\n" for i in range(n)]
+        open(tmp_path / "in_2.fq", "wb").write(b"".join(recs))
+    elif case == "gz_input_two_files":
+        fq = synth.fastq_bytes_fast(b1, q1)
+        cut = fq.index(b"\n@s.17001\n") + 1
+        open(files[0], "wb").write(gzip.compress(fq[:cut], 1))
+        files.append(tmp_path / "more_1.fq")
+        open(files[1], "wb").write(fq[cut:])
+        open(tmp_path / "whole_1.fq", "wb").write(fq)
+    else:
+        open(files[0], "wb").write(synth.fastq_bytes_fast(b1, q1))
+    monkeypatch.setenv("SCALCE_PIECE_BYTES", "700000" if case != "se_tiny_pieces" else "40000")
+    flags = (["-r"] if paired else []) + (["-B", "1M"] if case == "chunks_across_pieces" else [])
+    r = run_cli(*flags, "-c", "no", "-o", tmp_path / "hip", *files, "--patterns-bin", PBIN)
+    assert "pieces streamed" in r.stderr
+    oin = tmp_path / ("whole_1.fq" if case == "gz_input_two_files" else "in_1.fq")
+    O.orc_cli("compress", PBIN, oin, tmp_path / "orc", *[("1048576" if f == "1M" else f) for f in flags])
+    for m in ((1, 2) if paired else (1,)):
+        for ext in "nrq":
+            a = open(tmp_path / f"orc_{m}.scalce{ext}", "rb").read()
+            h = open(tmp_path / f"hip_{m}.scalce{ext}", "rb").read()
+            assert a == h, f"{case} .scalce{ext} mate {m}: {len(h)} vs {len(a)} bytes"
+
+
+def test_cli_stream_errors(tmp_path, monkeypatch):
+    """A mate that ends early and a text cut inside a record are errors however the pieces fall."""
+    n, L = 3000, 60
+    b1, q1 = synth.reads_and_quals(n, L, seed=61)
+    b2, q2 = synth.reads_and_quals(n, L, seed=62)
+    open(tmp_path / "in_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1, prefix="p.", suffix="/1"))
+    fq2 = synth.fastq_bytes_fast(b2[:-5], q2[:-5], prefix="p.", suffix="/2")
+    open(tmp_path / "in_2.fq", "wb").write(fq2)
+    monkeypatch.setenv("SCALCE_PIECE_BYTES", "50000")
+    r = subprocess.run([CLI, "-r", "-c", "no", "-o", str(tmp_path / "o"), str(tmp_path / "in_1.fq"), "--patterns-bin", PBIN],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "(ERROR)" in r.stderr, r.stderr[-300:]
+    open(tmp_path / "cut_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1)[:-7])
+    r = subprocess.run([CLI, "-c", "no", "-o", str(tmp_path / "o"), str(tmp_path / "cut_1.fq"), "--patterns-bin", PBIN],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "(ERROR)" in r.stderr, r.stderr[-300:]
