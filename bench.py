@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--length", type=int, default=100)
     ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="records of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stage-times", action="store_true", help="also print per-stage HIP-event times to stderr")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> archive leg (the `scalce` binary on the same shard written to a file)")
     args = ap.parse_args()
 
     import numpy as np
@@ -168,6 +169,12 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         cpu = cpu_baseline(text, n, L, args.cpu_sample)
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        for b in batches:   # the CLI is a process of its own and needs the card's memory
+            b.close()
+        del batches[:], pipe
+        e2e = end_to_end(text, nbytes)
 
     traffic, traffic_src = None, None
     kname = "ac_encode_rows_k" if G > 1 else "ac_encode_k"
@@ -197,6 +204,7 @@ def main():
             "steps": args.steps,
             "warmup": warm,
             "ms_per_step": round(ms_per_step, 3),
+            "value_single_job": round(nbytes / single_ms / 1e3, 2) if single_ms else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -218,10 +226,52 @@ def main():
                                  + ("four or eight per chain wave, one launch for %d shards at one workgroup per CU" % G
                                     if G > 1 else "one 2-wave workgroup each")},
             "cpu_baseline": cpu,
+            "e2e": e2e,
+            "note": "value = device-resident steady state with %d shards (independent jobs of the configs[1] size) in flight; "
+                    "value_single_job = one such job alone, input already in HBM; e2e = the scalce binary, file in, archive out" % D,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def end_to_end(text, nbytes):
+    """File -> archive with the `scalce` binary (C++ streaming host: reader threads, pinned chunks, uploads beside the
+    ingest of the previous piece) on the SAME shard written to a file in /dev/shm (tmpfs: what is measured is the host
+    path, not a disk).  Never `value`: PCIe, file reads and writes and process start-up are all inside."""
+    import re
+    import shutil
+    cli = os.path.join(ROOT, "scalce_amd", "bin", "scalce")
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    try:
+        free = shutil.disk_usage(base).free
+    except OSError:
+        free = 0
+    if not os.path.exists(cli) or free < 2 * nbytes:
+        return None
+    d = tempfile.mkdtemp(prefix="scalce_e2e_", dir=base)
+    try:
+        fq = os.path.join(d, "in_1.fq")
+        with open(fq, "wb") as f:
+            step = 1 << 30
+            for a in range(0, nbytes, step):
+                f.write(text[a:min(nbytes, a + step)].cpu().numpy().tobytes())
+        out = {}
+        for cont in ("no", "gz"):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "-c", cont, "-o", os.path.join(d, "arc_" + cont), fq, "--patterns-bin",
+                                os.path.join(ROOT, "tests", "golden", "patterns.bin")], capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            m = re.search(r"Time elapsed: (.*)", r.stderr)
+            asz = sum(os.path.getsize(os.path.join(d, f"arc_{cont}_1.scalce{e}")) for e in "nrq")
+            out["c_" + cont] = {"value": round(nbytes / dt / 1e6, 1), "unit": "MB/s", "wall_s": round(dt, 3), "archive_bytes": asz,
+                                "where": m.group(1) if m else None}
+        out["input"] = f"the bench shard as a file in {base} ({nbytes} bytes), process start to exit"
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cpu_baseline(text, n, L, sample):
@@ -255,11 +305,25 @@ def cpu_baseline(text, n, L, sample):
             subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
                             os.path.join(d, "o"), "-c", "no", "-T", "1"], check=True, capture_output=True)
         dt = time.perf_counter() - t0
+        # second leg: the reference's default thread count, main.cpp:171.  The reference's own thread() is not
+        # linkable here (needs buffio) and is racy at -T > 1; the C port codes the arithmetic-coder blocks on T threads and
+        # keeps the record loop on one.
+        T = max(1, min(4, (os.cpu_count() or 2) - 1))
+        if not os.path.exists(exe):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+        t1 = time.perf_counter()
+        r4 = subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
+                             os.path.join(d, "o4"), "-c", "no", "-T", str(T)], capture_output=True)
+        dt4 = time.perf_counter() - t1 if r4.returncode == 0 else None
     what = ("oracle/_ref/ref_driver -t (the reference's own objects, one thread)" if use_ref
             else "orc_cli compress -c no -T 1 (C restatement, one thread)")
     return {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
             "sample": f"first {sample} records ({end} bytes) of the same shard, {what}, {dt:.2f} s wall incl. file I/O",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(),
+            "threads_default": None if dt4 is None else {
+                "value": round(end / dt4 / 1e6, 2), "unit": "MB/s", "cores": T, "kind": "port",
+                "sample": f"same sample, orc_cli compress -c no -T {T} (main.cpp:171 default thread count; coder blocks on "
+                          f"{T} threads, record loop on one), {dt4:.2f} s wall"}}
 
 
 if __name__ == "__main__":

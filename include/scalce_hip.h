@@ -109,15 +109,19 @@ int scalce_batch_reset(scalce_batch *b);
  * counted and tokenized, the unconsumed tail of a piece is put in front of the next one on the device; then order, emit
  * and entropy run once over the run.  On success *out holds the results (scalce_batch_output; the caller destroys it).
  * rd(user, dst, cap) returns the bytes it stored (any number up to cap), 0 at the end of the stream, < 0 on error; it is
- * called from the reader thread of its mate only.  reads_hint sizes the row arrays (0: they grow as the run comes in);
- * lean = 1 releases device buffers as stages finish (scalce_batch_set_lean).  errbuf receives the message on failure. */
+ * called from the reader thread of its mate only.  reads_hint sizes the row arrays (0: they grow as the run comes in).
+ * flags: SCALCE_STREAM_LEAN releases device buffers as stages finish (scalce_batch_set_lean); SCALCE_STREAM_DEFER_ENTROPY
+ * returns behind the emit stage -- the caller runs scalce_batch_entropy_begin on a stream of its own and fetches the
+ * read and name streams while the coder works.  errbuf receives the message on failure. */
+#define SCALCE_STREAM_LEAN 1
+#define SCALCE_STREAM_DEFER_ENTROPY 2
 typedef int64_t (*scalce_read_fn)(void *user, void *dst, uint64_t cap);
 typedef struct {
   double total_s, read_wait_s, h2d_wait_s, front_s, order_s, emit_s, entropy_s;
   uint64_t rounds, reads, bytes[2];
 } scalce_stream_stats;
 int scalce_stream_compress(scalce_ctx *ctx, const scalce_params *p, scalce_read_fn rd1, void *user1, scalce_read_fn rd2,
-                           void *user2, uint64_t piece_bytes, uint64_t reads_hint, int lean, scalce_batch **out,
+                           void *user2, uint64_t piece_bytes, uint64_t reads_hint, int flags, scalce_batch **out,
                            scalce_stream_stats *stats, char *errbuf, size_t errcap);
 /* lean = 1: a stage releases the device buffers that no later stage reads (q' in input order once the reordered stream
  * exists, rows and sort scratch once the records are emitted): outputs 5, 6, 9 become unavailable, runs sized for most

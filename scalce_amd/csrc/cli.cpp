@@ -75,7 +75,8 @@ static const char *HELP_TEXT =
     "  -s, --sample-size INT       records sampled for the quality model (default 100000)\n"
     "  -B, --bucket-set-size NUM[M|G]  bucket storage that triggers a spill chunk (default 4G); order follows the reference\n"
     "  -P, --patterns FILE         text list of cores instead of the built-in table\n"
-    "  -T, --threads INT           host threads that deflate the gz containers (default: cores - 1, at most 16);\n"
+    "  -T, --threads INT           host threads that read plain input and deflate the gz containers (default: cores - 1,\n"
+    "                              at most 32);\n"
     "                              the hot path itself runs on the GPU\n"
     "  -t, --temp-directory STR    accepted for compatibility (nothing is spilled)\n"
     "  -S, --split-reads INT       decompression: reads per output part\n"
@@ -260,16 +261,52 @@ struct MateSource {
     }
     return false;
   }
+  uint64_t fpos = 0;  // plain files: where the next read starts
   int64_t read_raw(void *dst, uint64_t cap) {
     for (;;) {
-      if (fd < 0 && !gz && !open_next()) return 0;
+      if (fd < 0 && !gz) { if (!open_next()) return 0; fpos = 0; }
       int64_t k;
       if (gz) k = gzread(gz, dst, (unsigned)std::min<uint64_t>(cap, 1u << 30));
-      else k = ::read(fd, dst, (size_t)std::min<uint64_t>(cap, 1u << 30));
+      else k = read_plain(static_cast<uint8_t *>(dst), cap);
       if (k < 0) return -1;
       if (k > 0) return k;
       if (gz) { gzclose(gz); gz = nullptr; } else { ::close(fd); fd = -1; }
     }
+  }
+  // A big request on a plain file is cut into slices read by several threads at once (pread): one thread copying out
+  // of the page cache delivers about 5 GB/s, a tenth of what the upload behind it can take.
+  int64_t read_plain(uint8_t *dst, uint64_t cap) {
+    const uint64_t SLICE = 16u << 20;
+    const int nt = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(g_threads, 8)), (cap + SLICE - 1) / SLICE);
+    if (nt <= 1) {
+      const int64_t k = ::pread(fd, dst, (size_t)std::min<uint64_t>(cap, 1u << 30), (off_t)fpos);
+      if (k > 0) fpos += (uint64_t)k;
+      return k;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) return -1;
+    const uint64_t left = (uint64_t)st.st_size > fpos ? (uint64_t)st.st_size - fpos : 0;
+    const uint64_t want = std::min(cap, left);
+    if (!want) return 0;
+    const uint64_t per = ((want + nt - 1) / nt + 4095) & ~4095ull;
+    std::atomic<bool> bad{false};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) {
+      const uint64_t a = (uint64_t)t * per, b = std::min(want, a + per);
+      if (a >= b) break;
+      pool.emplace_back([&, a, b]() {
+        uint64_t done = a;
+        while (done < b) {
+          const ssize_t k = ::pread(fd, dst + done, (size_t)(b - done), (off_t)(fpos + done));
+          if (k <= 0) { bad = true; return; }
+          done += (uint64_t)k;
+        }
+      });
+    }
+    for (auto &t : pool) t.join();
+    if (bad) return -1;
+    fpos += want;
+    return (int64_t)want;
   }
   int64_t read(void *dst, uint64_t cap) {
     if (peek_pos < peek.size()) {
@@ -384,7 +421,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
     hint = bytes / (2 * (uint64_t)p.read_len[0] + 8) + 64;
     for (auto &f : src[0].files) { int fd = ::open(f.c_str(), O_RDONLY); uint8_t mg[2] = {0, 0}; if (fd >= 0) { if (::pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1F && mg[1] == 0x8B) hint = 0; ::close(fd); } }
   }
-  uint64_t piece = 1ull << 30;
+  uint64_t piece = 256ull << 20;  // per chunk; three of them are pinned per mate
   if (const char *e = getenv("SCALCE_PIECE_BYTES")) piece = strtoull(e, nullptr, 10);
   {  // small inputs: no point in pinning gigabytes
     uint64_t bytes = 0;
@@ -396,7 +433,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   char emsg[512] = "";
   const double t1 = now();
   if (scalce_stream_compress(ctx, &p, MateSource::read_cb, &src[0], nm == 2 ? MateSource::read_cb : nullptr, nm == 2 ? &src[1] : nullptr, piece,
-                             hint, 1, &b, &ss, emsg, sizeof emsg)) {
+                             hint, SCALCE_STREAM_LEAN | SCALCE_STREAM_DEFER_ENTROPY, &b, &ss, emsg, sizeof emsg)) {
     fprintf(stderr, "%s\n", emsg[0] ? emsg : scalce_last_error(ctx));
     exit(1);
   }
@@ -405,20 +442,37 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   LOG("\tDone with file %s, %llu reads found\n", files[0].c_str(), (unsigned long long)N);
   uint32_t st4[5] = {0, 0, 0, 0, 0};
   scalce_batch_stats(b, st4);
+  // the arithmetic coder starts on its own stream; the read and name streams come down and are written beside it
+  // (a run of up to 2048 blocks is one launch that takes as long as ONE block's serial chain, about 0.3 s)
+  hipStream_t s_ent = nullptr;
+  HIPOK(hipStreamCreateWithFlags(&s_ent, hipStreamNonBlocking));
+  SCOK(ctx, scalce_batch_entropy_begin(b, nullptr, s_ent));
 
   // final writer: headers of combine_and_compress_with_split (compress.cpp:263-343)
   const uint8_t magic[8] = {'s', 'c', 'a', 'l', 'c', 'e', '2', '2'};
   const bool gz = o.container == 1;
   uint64_t new_size = 0;
   Downloader down;
+  char fn[4096];
   for (int m = 0; m < nm; m++) {
-    char fn[4096];
-    OutFile fR, fQ, fN;
+    OutFile fR, fN;
     snprintf(fn, sizeof fn, "%s_%d.scalcer", o.out.c_str(), m + 1); fR.open(fn, gz);
     const int32_t noac = o.no_ac, len32 = p.read_len[m];
     fR.write(magic, 8); fR.write(&noac, 4); fR.write(&len32, 4);
     down.to_file(ctx, b, SCALCE_OUT_READS, m, fR);
     fR.close();
+    snprintf(fn, sizeof fn, "%s_%d.scalcen", o.out.c_str(), m + 1); fN.open(fn, gz);
+    const uint8_t un = o.use_names ? 1 : 0;
+    fN.write(magic, 8); fN.write(&un, 1);
+    if (o.use_names) down.to_file(ctx, b, SCALCE_OUT_NAMES, 0, fN);  // mate 2 repeats mate 1's names (:450-454)
+    else { const int64_t z = 0; fN.write(&z, 8); fN.write(o.library.data(), o.library.size()); }
+    fN.close();
+  }
+  const double t2b = now();
+  SCOK(ctx, scalce_batch_finish(b, s_ent));  // the coder is through: sizes of the coded streams, device error word
+  const double t2c = now();
+  for (int m = 0; m < nm; m++) {
+    OutFile fQ;
     snprintf(fn, sizeof fn, "%s_%d.scalceq", o.out.c_str(), m + 1); fQ.open(fn, o.no_ac ? gz : false);  // :249
     const int64_t phred = p.qmap[0].offset;  // mate 1's offset for both (compress.cpp:294,816-817)
     fQ.write(magic, 8); fQ.write(&phred, 8);
@@ -430,18 +484,13 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
     }
     down.to_file(ctx, b, SCALCE_OUT_QUAL, m, fQ);
     fQ.close();
-    snprintf(fn, sizeof fn, "%s_%d.scalcen", o.out.c_str(), m + 1); fN.open(fn, gz);
-    const uint8_t un = o.use_names ? 1 : 0;
-    fN.write(magic, 8); fN.write(&un, 1);
-    if (o.use_names) down.to_file(ctx, b, SCALCE_OUT_NAMES, 0, fN);  // mate 2 repeats mate 1's names (:450-454)
-    else { const int64_t z = 0; fN.write(&z, 8); fN.write(o.library.data(), o.library.size()); }
-    fN.close();
     for (const char *ext : {"r", "q", "n"}) {
       snprintf(fn, sizeof fn, "%s_%d.scalce%s", o.out.c_str(), m + 1, ext);
       struct stat st;
       if (stat(fn, &st) == 0) new_size += (uint64_t)st.st_size;
     }
   }
+  hipStreamDestroy(s_ent);
   const void *dc = nullptr;
   uint64_t nc = 0;
   SCOK(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dc, &nc));
@@ -456,9 +505,9 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   LOG("\tLossy percentage: %d\n", o.lossy);
   LOG("\tSpill chunks: %u, pieces streamed: %llu\n", st4[3], (unsigned long long)ss.rounds);
   LOG("\tTime elapsed: %.2f s (sample %.2f; stream %.2f = waiting for the reader %.2f + for uploads %.2f + ingest/count/tokenize %.2f; "
-      "order %.2f, emit %.2f, entropy %.2f; download+write %.2f)\n",
-      t3 - t0, t1 - t0, ss.total_s - ss.order_s - ss.emit_s - ss.entropy_s, ss.read_wait_s, ss.h2d_wait_s, ss.front_s, ss.order_s, ss.emit_s,
-      ss.entropy_s, t3 - t2);
+      "order %.2f, emit %.2f; reads+names down and written beside the coder %.2f, waiting for the coder %.2f, qualities down and written %.2f)\n",
+      t3 - t0, t1 - t0, ss.total_s - ss.order_s - ss.emit_s, ss.read_wait_s, ss.h2d_wait_s, ss.front_s, ss.order_s, ss.emit_s,
+      t2b - t2, t2c - t2b, t3 - t2c);
   LOG("\tOriginal size: %.2lfM, new size: %.2lfM, compression factor: %.2lf\n", original / (1024.0 * 1024.0),
       new_size / (1024.0 * 1024.0), new_size ? (double)original / (double)new_size : 0.0);
   return 0;
@@ -648,7 +697,7 @@ int main(int argc, char **argv) {
   else SCOK(ctx, scalce_patterns_load_bin(ctx, table.data(), table.size()));
   {
     const int hw = (int)std::thread::hardware_concurrency();
-    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(16, hw - 1));
+    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(32, hw - 1));
   }
   const int rc = o.decompress ? do_decompress(o, files[0], ctx) : do_compress(o, files, ctx);
   scalce_ctx_destroy(ctx);

@@ -122,7 +122,7 @@ struct Mate {
   } while (0)
 
 extern "C" int scalce_stream_compress(scalce_ctx *ctx, const scalce_params *p, scalce_read_fn rd1, void *user1, scalce_read_fn rd2,
-                                      void *user2, uint64_t piece_bytes, uint64_t reads_hint, int lean, scalce_batch **out,
+                                      void *user2, uint64_t piece_bytes, uint64_t reads_hint, int flags, scalce_batch **out,
                                       scalce_stream_stats *st, char *errbuf, size_t errcap) {
   if (!ctx || !p || !rd1 || !out || (p->paired && !rd2)) return SCALCE_ERR_ARG;
   const int nm = p->paired ? 2 : 1;
@@ -163,7 +163,7 @@ extern "C" int scalce_stream_compress(scalce_ctx *ctx, const scalce_params *p, s
     const uint64_t rows0 = reads_hint ? reads_hint + 16 : piece / (2 * (uint64_t)p->read_len[0] + 7) + 16;
     rc = scalce_batch_create(ctx, p, rows0, cap + 256, &b);
     if (rc) { err = scalce_last_error(ctx); goto fail_rc; }
-    scalce_batch_set_lean(b, lean);
+    scalce_batch_set_lean(b, (flags & SCALCE_STREAM_LEAN) ? 1 : 0);
   }
   for (int m = 0; m < nm; m++) M[m].reader = std::thread(reader_main, &M[m].ring, rd[m], user[m], piece);
   started = true;
@@ -264,9 +264,11 @@ extern "C" int scalce_stream_compress(scalce_ctx *ctx, const scalce_params *p, s
     t0 = now_s();
     if ((rc = scalce_batch_emit(b, s_main)) || (rc = scalce_batch_finish(b, s_main))) { err = scalce_last_error(ctx); goto fail_rc; }
     S.emit_s = now_s() - t0;
-    t0 = now_s();
-    if ((rc = scalce_batch_entropy(b, nullptr, s_main)) || (rc = scalce_batch_finish(b, s_main))) { err = scalce_last_error(ctx); goto fail_rc; }
-    S.entropy_s = now_s() - t0;
+    if (!(flags & SCALCE_STREAM_DEFER_ENTROPY)) {
+      t0 = now_s();
+      if ((rc = scalce_batch_entropy(b, nullptr, s_main)) || (rc = scalce_batch_finish(b, s_main))) { err = scalce_last_error(ctx); goto fail_rc; }
+      S.entropy_s = now_s() - t0;
+    }
   }
   S.total_s = now_s() - t_start;
   S.reads = scalce_batch_reads(b);
