@@ -146,7 +146,13 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
                                               bool qrow_aligned) {
   const u64 p0 = a.line_end[4 * r], p1 = a.line_end[4 * r + 1], p2 = a.line_end[4 * r + 2], p3 = a.line_end[4 * r + 3];
   if (p1 - p0 - 1 != (u64)a.L || p3 - p2 - 1 != (u64)a.L) {
-    if (PART & 1) dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
+    if (PART & 1) {
+      dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
+      if (a.mate == 0) {  // the run ends with an error; until the host sees it, later stages must find a well-formed row
+        a.namelen[r] = 0;
+        if (a.namecell) *reinterpret_cast<uint4 *>(a.namecell + 16 * r) = make_uint4(0, 0, 0, 0);
+      }
+    }
     return;
   }
   const int L = a.L;
@@ -220,7 +226,7 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
       while (i < p0 && byte_at(i) != ' ') i++;
       const u64 l = i - (ns + 1);
       if (l > 255 || p0 <= ns) dev_fail(a.err, E_NAMELEN, r);
-      len = (u32)(l & 255);
+      len = l > 255 ? 0u : (u32)l;
       if (a.namecell) {
         u32 w[4] = {len, 0, 0, 0};
         for (u32 k = 0; k < 15 && k < len; k++) w[(k + 1) >> 2] |= (u32)byte_at(ns + 1 + k) << (8 * ((k + 1) & 3));

@@ -311,22 +311,42 @@ __global__ __launch_bounds__(256) void emit_names_k(u64 nrec, const u32 *perm, c
   for (u32 i = 0; i < n; i++) dst[1 + i] = src[i];
 }
 
-// row gather: out[k] = rows[perm[k]], `width` bytes per row, row stride `stride` in the source
+// row gather: out[k] = rows[perm[k]], `width` bytes per row, row stride `stride` in the source.  A thread produces 16
+// consecutive output bytes (one aligned 16-byte store; they span at most two rows when width >= 16) and the grid strides
+// over the output: 200 M rows of 150 bytes are 3e10 bytes, far beyond the 2^32 threads a launch may have.
+__host__ __device__ inline u32 gather_grid(u64 nrec, u32 width) {
+  const u64 chunks = (nrec * (u64)width + 15) / 16, blocks = (chunks + 255) / 256;
+  return (u32)(blocks < (1u << 22) ? (blocks ? blocks : 1) : (1u << 22));
+}
 __global__ __launch_bounds__(256) void gather_rows_k(u64 nrec, const u32 *perm, const u8 *rows, u64 stride, u32 width,
                                                     u8 *out) {
-  // one thread per 4-byte word of the output when width % 4 == 0, else per byte
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if ((width & 3) == 0 && (stride & 3) == 0) {
-    const u32 wpr = width >> 2;
-    const u64 k = i / wpr;
-    if (k >= nrec) return;
-    const u32 w = (u32)(i - k * wpr);
-    reinterpret_cast<u32 *>(out)[i] = reinterpret_cast<const u32 *>(rows + (u64)perm[k] * stride)[w];
-  } else {
-    const u64 k = i / width;
-    if (k >= nrec) return;
-    const u32 w = (u32)(i - k * width);
-    out[i] = rows[(u64)perm[k] * stride + w];
+  const u64 total = nrec * (u64)width;
+  const u64 step = (u64)gridDim.x * blockDim.x * 16;
+  const bool words = (width & 3) == 0 && (stride & 3) == 0;
+  for (u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16; i0 < total; i0 += step) {
+    u64 k = i0 / width;
+    u32 w = (u32)(i0 - k * width);
+    const u8 *src = rows + (u64)perm[k] * stride;
+    if (words) {  // rows are whole words: four 4-byte moves
+      u32 v[4] = {0, 0, 0, 0};
+      for (int j = 0; j < 4; j++) {
+        if (i0 + 4 * j >= total) break;
+        v[j] = *reinterpret_cast<const u32 *>(src + w);
+        w += 4;
+        if (w == width) { w = 0; k++; if (k < nrec) src = rows + (u64)perm[k] * stride; }
+      }
+      if (i0 + 16 <= total) *reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+      else for (u64 i = i0; i < total; i++) out[i] = (u8)(v[(i - i0) >> 2] >> (8 * ((i - i0) & 3)));
+    } else {
+      u32 v[4] = {0, 0, 0, 0};
+      const int cnt = total - i0 < 16 ? (int)(total - i0) : 16;
+      for (int j = 0; j < cnt; j++) {
+        v[j >> 2] |= (u32)src[w] << (8 * (j & 3));
+        if (++w == width) { w = 0; k++; if (k < nrec) src = rows + (u64)perm[k] * stride; }
+      }
+      if (cnt == 16) *reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+      else for (int j = 0; j < cnt; j++) out[i0 + j] = (u8)(v[j >> 2] >> (8 * (j & 3)));
+    }
   }
 }
 

@@ -458,18 +458,23 @@ struct StageTimer {
   }
 };
 
+static int launch_failed(scalce_ctx *c);
 static int read_u32(scalce_batch *b, const u32 *d, u32 *h, int n, hipStream_t s) {
+  { int rc = launch_failed(b->ctx); if (rc) return rc; }
   HIP_TRY(b->ctx, hipMemcpyAsync(h, d, sizeof(u32) * n, hipMemcpyDeviceToHost, s));
   HIP_TRY(b->ctx, hipStreamSynchronize(s));
   return SCALCE_OK;
 }
 static int read_u64(scalce_batch *b, const u64 *d, u64 *h, int n, hipStream_t s) {
+  { int rc = launch_failed(b->ctx); if (rc) return rc; }
   HIP_TRY(b->ctx, hipMemcpyAsync(h, d, sizeof(u64) * n, hipMemcpyDeviceToHost, s));
   HIP_TRY(b->ctx, hipStreamSynchronize(s));
   return SCALCE_OK;
 }
 
+static int launch_failed(scalce_ctx *c);
 static int check_device_error(scalce_batch *b, hipStream_t s) {
+  { int rc = launch_failed(b->ctx); if (rc) return rc; }
   DevErr e;
   HIP_TRY(b->ctx, hipMemcpyAsync(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost, s));
   HIP_TRY(b->ctx, hipStreamSynchronize(s));
@@ -486,8 +491,27 @@ static int check_device_error(scalce_batch *b, hipStream_t s) {
   return SCALCE_ERR_FORMAT;
 }
 
-#define LAUNCH(kernel, grid, block, shmem, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
-static inline u32 cdiv(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+// A launch that the runtime refuses (a grid beyond 2^32 threads, say) must not pass for a kernel that ran: HIP's "last
+// error" is overwritten by the next call that succeeds, so it is looked at right behind every launch and kept until
+// scalce_batch_finish / the next read-back reports it.
+static thread_local hipError_t g_launch_err = hipSuccess;
+static thread_local const char *g_launch_what = "";
+#define LAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
+  do {                                                                                               \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__);                 \
+    const hipError_t le_ = hipGetLastError();                                                        \
+    if (le_ != hipSuccess && g_launch_err == hipSuccess) { g_launch_err = le_; g_launch_what = #kernel; } \
+  } while (0)
+static int launch_failed(scalce_ctx *c) {
+  if (g_launch_err == hipSuccess) return SCALCE_OK;
+  set_err(c, "launch of %s failed: %s", g_launch_what, hipGetErrorString(g_launch_err));
+  g_launch_err = hipSuccess;
+  return SCALCE_ERR_HIP;
+}
+static inline u32 cdiv(u64 a, u64 b) {
+  const u64 q = (a + b - 1) / b;
+  return q > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)q;  // callers whose grids can get there use grid-stride kernels
+}
 
 // ---- stage 0: ingest ------------------------------------------------------------------------------
 // newline count of one mate's text; the per-tile bases stay in b->tile[mate] for piece_unpack
@@ -742,6 +766,8 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
                       TieCompact{b->tok_pos.as<u32>(), b->tie_index.as<u32>(), b->tie_read.as<u32>()}, ws32, b->d_small, s);
   u32 ntie = 0;
   { int rc = read_u32(b, b->d_small, &ntie, 1, s); if (rc) return rc; }
+  // a malformed record (compress.cpp:628-634 exits there) ends the run here, before later stages size anything from its row
+  { int rc = check_device_error(b, s); if (rc) { b->tok_open = false; return rc; } }
   b->ntie = ntie;
   ENSURE(b, b->tie_off, sizeof(u32) * (ntie + 2));
   ENSURE(b, b->tie_ncand, sizeof(u32) * (ntie + 2));
@@ -1109,16 +1135,14 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     for (int m = 0; m < b->nm; m++) {
       const u32 w = (u32)b->L[m];
       ENSURE(b, b->qs[m], (size_t)w * N + 64);
-      const u64 items = ((w & 3) == 0) ? N * (w / 4) : N * w;
-      LAUNCH(gather_rows_k, cdiv(items, 256), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
+      LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
       if (b->lean) { HIP_TRY(c, hipStreamSynchronize(s)); release(b->q[m]); }  // the next mate's stream takes its place
     }
     if (b->nm == 2) {  // mate 2: bare packed reads in the same order (compress.cpp:380-383 with fR = file 4)
       const u32 w = (u32)b->szr[1];
       b->out_reads_bytes[1] = N * w;
       ENSURE(b, b->out_reads[1], N * w + 64);
-      const u64 items2 = ((w & 3) == 0) ? N * (w / 4) : N * w;
-      LAUNCH(gather_rows_k, cdiv(items2, 256), 256, 0, s, N, b->perm, b->packed[1].as<u8>(), (u64)b->stride[1], w,
+      LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->packed[1].as<u8>(), (u64)b->stride[1], w,
              b->out_reads[1].as<u8>());
     }
   } else if (b->nm == 2) b->out_reads_bytes[1] = 0;
@@ -1378,7 +1402,8 @@ constexpr u32 AC_WINDOW_BLOCKS = 2048;  // 256 workgroups of eight
 static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, hipStream_t s) {
   scalce_ctx *c = b->ctx;
   const u64 N = b->N;
-  const u32 W = AC_WINDOW_BLOCKS / (u32)b->nm;
+  u32 W = AC_WINDOW_BLOCKS / (u32)b->nm;
+  if (const char *e = getenv("SCALCE_AC_WINDOW_BLOCKS")) W = (u32)std::max(1, atoi(e));  // test hook: blocks per mate and window
   u64 used[2] = {0, 0}, nsym[2] = {0, 0};
   u32 nblk[2] = {0, 0}, most = 0;
   for (int m = 0; m < b->nm; m++) {

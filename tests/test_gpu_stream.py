@@ -139,3 +139,25 @@ def test_append_errors(patterns_blob):
         rest = fq[used[0]:len(fq) - 10]
         tr = device_bytes(rest)
         b.append(tr.data_ptr(), len(rest), final=True)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_windowed_coder_equals_one_launch(paired, patterns_blob, monkeypatch):
+    """Runs with more than 2048 blocks are coded window by window into bounded buffers (entropy_windowed); with the window
+    shrunk to one block per mate the same path runs here: three windows, the framed stream grown twice."""
+    from gpu_util import device_bytes
+    ctx = host.Context(0, patterns_bin=patterns_blob)
+    n, L = 230_000, 100   # three blocks per mate, the last one short
+    texts = [synth.fastq_bytes_fast(*synth.reads_and_quals(n, L, seed=71 + m)) for m in range(2 if paired else 1)]
+    dev = [device_bytes(t) for t in texts]
+    outs = []
+    for windowed in (False, True):
+        if windowed:
+            monkeypatch.setenv("SCALCE_AC_WINDOWED", "1")
+            monkeypatch.setenv("SCALCE_AC_WINDOW_BLOCKS", "1")
+        b = host.Batch(ctx, L, n + 8, max(len(t) for t in texts) + 64, paired=paired, read_len2=L)
+        b.compress(dev[0].data_ptr(), len(texts[0]), dev[1].data_ptr() if paired else None, len(texts[1]) if paired else 0)
+        b.finish()
+        outs.append([b.output(host.OUT_QUAL, m).copy() for m in range(len(texts))])
+    for m in range(len(texts)):
+        assert len(outs[0][m]) == len(outs[1][m]) and (outs[0][m] == outs[1][m]).all(), f"mate {m + 1}"
