@@ -98,9 +98,15 @@ int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_text, uint64
  * rows before them (bin_size is cumulative, reads.cpp:246) are done when the call returns and the text may be
  * overwritten; scalce_batch_order / _emit / _entropy then run once over everything.  d_text* 16-byte aligned, at most
  * max_text bytes each; the row arrays grow beyond max_reads when they must.  The first append after create, reset or a
- * one-piece ingest starts a new run.  Synchronises `stream`. */
+ * one-piece ingest starts a new run.  Synchronises `stream`.
+ * flags: SCALCE_APPEND_FINAL = the final piece; SCALCE_APPEND_NO_QUALITY leaves the trigram counters alone (the rows were
+ * counted elsewhere: sharded runs); SCALCE_APPEND_NO_TOKENIZE defers the tie-break -- scalce_batch_tokenize / _begin then
+ * cover every row not tokenized yet (sharded runs resolve it across ranks once all rows are in place). */
+#define SCALCE_APPEND_FINAL 1
+#define SCALCE_APPEND_NO_QUALITY 2
+#define SCALCE_APPEND_NO_TOKENIZE 4
 int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2,
-                        int final_piece, uint64_t consumed[2], void *stream);
+                        int flags, uint64_t consumed[2], void *stream);
 int scalce_batch_reset(scalce_batch *b);
 
 /* The streaming host around scalce_batch_append -- what replaces the reader half of thread() (compress.cpp:614-671) and
@@ -142,6 +148,14 @@ int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior_counts, void 
 int scalce_batch_tokenize_begin(scalce_batch *b, void *stream);
 int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior_counts, int *changed, void *stream);
 int scalce_batch_tokenize_end(scalce_batch *b, void *stream);
+/* Sharded runs: the cuts the -B rule makes inside this batch's rows when `carry_in` bytes of records are already in the
+ * chunk that is open where they begin (the rows of the ranks before): cuts_host[i] = row in front of which chunk i + 1
+ * begins (1 .. N; at most cap), carry_out = bytes in the chunk still open behind the last row.  Needs the rows ingested,
+ * not tokenized (record sizes depend on the core's length only). */
+int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint64_t *cuts_host, uint32_t cap, uint32_t *ncuts,
+                            uint64_t *carry_out, void *stream);
+/* Byte offset, in the text of the piece ingested last, at which record `row` (0 .. rows of that piece) begins. */
+int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset);
 /* Spill-chunk boundaries given by the caller instead of the -B rule: starts[0] = 0 < starts[1] < ...;
  * records of chunk i precede those of chunk i+1 inside every bucket (merge order, compress.cpp:104-159).
  * A sharded run uses one chunk per shard. */
@@ -208,7 +222,8 @@ enum {
   SCALCE_OUT_QSTREAM = 7,   /* N*L bytes: reordered q' stream, mate m                         */
   SCALCE_OUT_BUCKET_COUNTS = 8, /* (buckets+1) x u64 reads per bucket, emission order, root last */
   SCALCE_OUT_QINPUT = 9,    /* N*L bytes: q' in input order, mate m                          */
-  SCALCE_OUT_NAMELEN = 10   /* N bytes: stored name length per read, input order             */
+  SCALCE_OUT_NAMELEN = 10,  /* N bytes: stored name length per read, input order             */
+  SCALCE_OUT_BUCKET_NAME_BYTES = 11 /* (buckets+1) x u64: bytes of each bucket's records in SCALCE_OUT_NAMES (after emit) */
 };
 int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes);
 uint64_t scalce_batch_reads(const scalce_batch *b);
@@ -261,6 +276,58 @@ int scalce_fastq_records(scalce_ctx *ctx, int read_len, int has_buckets, const u
                          uint64_t nrecords, const uint8_t *d_qual, int64_t phred_offset, const uint8_t *names_host,
                          uint64_t names_bytes, const char *library, int mate_digit, uint8_t *d_out, uint64_t out_cap,
                          uint64_t *out_bytes, uint64_t *record_offsets_host, void *stream);
+
+/* ---- runs sharded over several GPUs: one process per GPU, ONE archive -----------------------------------------
+ * The reference has no distributed mode; what it carries across reads is what ranks exchange (see comm.cpp).  The
+ * archive of a sharded run is byte for byte the archive of the same input on one GPU -- and of the reference at -T 1 with
+ * the same -B -- for any number of ranks: rank boundaries are moved to the nearest spill-chunk boundary of the run-wide -B
+ * rule (records change owner as text, once), so that "rank-major inside a bucket" IS the merge order of compress.cpp:104-159.
+ * -B must be set (the reference's default is 4G) and a chunk must not span more than two neighbouring ranks. */
+typedef struct scalce_comm scalce_comm;
+#define SCALCE_COMM_ID_BYTES 128
+int scalce_comm_unique_id(uint8_t id[SCALCE_COMM_ID_BYTES]);  /* rank 0 makes it, the launcher hands it to every rank */
+int scalce_comm_create_rccl(int device, int world, int rank, const uint8_t id[SCALCE_COMM_ID_BYTES], scalce_comm **out);
+/* rehearsal transport: `world` processes sharing one GPU, staged through POSIX shared memory `name` (slot_bytes per rank,
+ * 0 = 64 MiB: the largest message) */
+int scalce_comm_create_shm(int device, int world, int rank, const char *name, uint64_t slot_bytes, scalce_comm **out);
+void scalce_comm_destroy(scalce_comm *c);
+const char *scalce_comm_error(const scalce_comm *c);
+int scalce_comm_world(const scalce_comm *c);
+int scalce_comm_rank(const scalce_comm *c);
+int scalce_comm_barrier(scalce_comm *c, void *stream);
+int scalce_comm_all_gather(scalce_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
+int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, uint64_t count, void *stream);
+int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, const uint64_t *send_bytes, void *d_recv,
+                             const uint64_t *recv_bytes, void *stream);
+
+typedef struct {
+  int32_t world, rank;
+  uint32_t nb1;              /* buckets + 1 (root last) */
+  uint32_t rounds;           /* collective rounds of the tie-break */
+  uint32_t sweeps;           /* local sweeps of this rank */
+  uint32_t chunks_total;     /* spill chunks of the run */
+  uint64_t reads_total;      /* of the run */
+  uint64_t first_read;       /* run-wide index of this rank's first record AFTER the boundaries moved */
+  uint64_t reads_local;      /* records this rank holds after the move */
+  uint64_t moved_in[2];      /* records received from the rank before / behind */
+  uint64_t *counts;          /* [world][nb1] reads per (rank, bucket), emission order */
+  uint64_t *name_bytes;      /* [world][nb1] bytes of their name records */
+  uint64_t sym_lo[2], sym_hi[2];  /* per mate: this rank's range of the run-wide reordered quality stream (whole 10 MiB blocks) */
+  uint64_t coded_bytes[2][64];    /* per mate and rank: bytes of framed blocks (0 with SCALCE_SHARD_PREPARE_ONLY) */
+  void *keep[8];             /* device buffers the coder still reads (freed by scalce_shard_result_free) */
+} scalce_shard_result;
+#define SCALCE_SHARD_PREPARE_ONLY 1  /* hand the rank's block range to the batch (scalce_batch_entropy_stream_prepare): the
+                                        caller codes several shards with one scalce_batch_entropy_begin_group */
+#define SCALCE_SHARD_CODER_ASYNC 2   /* only enqueue the coder on coder_stream (scalce_batch_entropy_stream_begin) */
+/* SPMD: every rank calls it with its own contiguous piece of the read stream (rank order = input order), resident in
+ * HBM.  On return the batch holds this rank's pieces of the archive: SCALCE_OUT_READS / _NAMES = its records per bucket
+ * (bucket b of the archive = header, then rank 0's records of b, rank 1's, ...: result->counts / name_bytes say where),
+ * SCALCE_OUT_QUAL = the framed blocks of sym_lo .. sym_hi, SCALCE_OUT_TABLE = the run-wide table.  `b` must have been
+ * created with bucket_set_size != 0 and default qprev. */
+int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalce_batch *b, const uint8_t *d_text1, uint64_t n1,
+                            const uint8_t *d_text2, uint64_t n2, int flags, void *stream, void *coder_stream,
+                            scalce_shard_result *result);
+void scalce_shard_result_free(scalce_shard_result *r);
 
 #ifdef __cplusplus
 }

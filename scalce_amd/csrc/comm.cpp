@@ -1,0 +1,296 @@
+// comm.cpp -- the collectives a sharded run needs, over device buffers.
+//
+// The reference has no distributed mode; what it carries ACROSS reads -- bin_size of the tie-break
+// (reads.cpp:246,420), prev[] and the 80^3 counters of the quality model (qualities.cpp:179-198), the running record size
+// of the spill rule (compress.cpp:702-715), the 10 MiB cuts of the coder on the reordered stream (arithmetic.cpp:318-363)
+// -- is what ranks have to exchange when the read stream is split over GPUs.  Two transports:
+//   rccl  one process per GPU, RCCL over xGMI: ncclAllGather / ncclAllReduce / grouped ncclSend + ncclRecv, enqueued on
+//         the caller's stream.  librccl is opened at run time (dlopen): inside a PyTorch process that is the copy torch
+//         has already loaded, so there is one RCCL per process.
+//   shm   several processes sharing ONE GPU (or none): POSIX shared memory and a process-shared barrier, device buffers
+//         staged through the host.  This is the rehearsal transport of the tests, not a product path.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scalce_hip.h"
+
+namespace {
+
+// ---- the few RCCL entry points used, resolved at run time -------------------------------------------------
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclUint8 = 1, ncclUint64 = 5 };  // ncclDataType_t (rccl.h)
+enum { ncclSum = 0, ncclMax = 2 };        // ncclRedOp_t
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(ncclComm_t, int *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string error;
+  bool load() {
+    if (lib) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) { error = std::string("cannot open librccl: ") + dlerror(); return false; }
+    auto sym = [&](const char *n) { void *p = dlsym(lib, n); if (!p) error = std::string("librccl lacks ") + n; return p; };
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+    AllGather = reinterpret_cast<decltype(AllGather)>(sym("ncclAllGather"));
+    AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    return error.empty();
+  }
+};
+Rccl g_rccl;
+
+// ---- shared-memory transport ----------------------------------------------------------------------------------
+struct ShmHeader {
+  pthread_barrier_t barrier;
+  uint64_t ready;      // set by rank 0 once the barrier is initialised
+  uint64_t slot_bytes;
+  uint64_t sizes[64][64];  // all_to_all_v: sizes[src][dst]
+};
+
+}  // namespace
+
+struct scalce_comm {
+  int world = 1, rank = 0, device = 0;
+  std::string err;
+  // rccl
+  ncclComm_t nccl = nullptr;
+  // shm
+  bool shm = false;
+  std::string shm_name;
+  ShmHeader *hdr = nullptr;
+  uint8_t *slots = nullptr;  // world x slot_bytes
+  size_t map_bytes = 0;
+  uint64_t slot_bytes = 0;
+  std::vector<uint8_t> stage;
+};
+
+#define CM_HIP(c, expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) { (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return SCALCE_ERR_HIP; } \
+  } while (0)
+#define CM_NCCL(c, expr)                                                                                               \
+  do {                                                                                                                 \
+    int r_ = (expr);                                                                                                   \
+    if (r_ != ncclSuccess) { (c)->err = std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); return SCALCE_ERR_HIP; } \
+  } while (0)
+
+extern "C" const char *scalce_comm_error(const scalce_comm *c) { return c ? c->err.c_str() : "null communicator"; }
+extern "C" int scalce_comm_world(const scalce_comm *c) { return c ? c->world : 1; }
+extern "C" int scalce_comm_rank(const scalce_comm *c) { return c ? c->rank : 0; }
+
+extern "C" int scalce_comm_unique_id(uint8_t id[SCALCE_COMM_ID_BYTES]) {
+  if (!id || !g_rccl.load()) return SCALCE_ERR_HIP;
+  ncclUniqueId u;
+  if (g_rccl.GetUniqueId(&u) != ncclSuccess) return SCALCE_ERR_HIP;
+  static_assert(sizeof u == SCALCE_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  memcpy(id, &u, sizeof u);
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_comm_create_rccl(int device, int world, int rank, const uint8_t id[SCALCE_COMM_ID_BYTES], scalce_comm **out) {
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) return SCALCE_ERR_ARG;
+  scalce_comm *c = new scalce_comm();
+  c->world = world; c->rank = rank; c->device = device;
+  *out = c;
+  if (!g_rccl.load()) { c->err = g_rccl.error; return SCALCE_ERR_HIP; }
+  CM_HIP(c, hipSetDevice(device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  CM_NCCL(c, g_rccl.CommInitRank(&c->nccl, world, u, rank));
+  int n = 0;
+  CM_NCCL(c, g_rccl.CommCount(c->nccl, &n));
+  if (n != world) { c->err = "RCCL reports a different world size"; return SCALCE_ERR_HIP; }
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_comm_create_shm(int device, int world, int rank, const char *name, uint64_t slot_bytes, scalce_comm **out) {
+  if (!out || !name || world < 1 || world > 64 || rank < 0 || rank >= world) return SCALCE_ERR_ARG;
+  scalce_comm *c = new scalce_comm();
+  c->world = world; c->rank = rank; c->device = device; c->shm = true;
+  c->shm_name = name;
+  c->slot_bytes = slot_bytes ? slot_bytes : (64ull << 20);
+  *out = c;
+  c->map_bytes = sizeof(ShmHeader) + (size_t)world * c->slot_bytes;
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(name);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)c->map_bytes) != 0) { c->err = "shm_open / ftruncate failed"; return SCALCE_ERR_HIP; }
+  } else {
+    for (int tries = 0; tries < 30000 && fd < 0; tries++) {  // wait for rank 0 to create and size it
+      fd = shm_open(name, O_RDWR, 0600);
+      struct stat st;
+      if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < c->map_bytes)) { close(fd); fd = -1; }
+      if (fd < 0) usleep(1000);
+    }
+    if (fd < 0) { c->err = "shared segment of rank 0 did not appear"; return SCALCE_ERR_HIP; }
+  }
+  void *p = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) { c->err = "mmap of the shared segment failed"; return SCALCE_ERR_HIP; }
+  c->hdr = static_cast<ShmHeader *>(p);
+  c->slots = static_cast<uint8_t *>(p) + sizeof(ShmHeader);
+  if (rank == 0) {
+    pthread_barrierattr_t a;
+    pthread_barrierattr_init(&a);
+    pthread_barrierattr_setpshared(&a, PTHREAD_PROCESS_SHARED);
+    pthread_barrier_init(&c->hdr->barrier, &a, (unsigned)world);
+    pthread_barrierattr_destroy(&a);
+    c->hdr->slot_bytes = c->slot_bytes;
+    __atomic_store_n(&c->hdr->ready, 1ull, __ATOMIC_RELEASE);
+  } else {
+    for (int tries = 0; tries < 30000 && !__atomic_load_n(&c->hdr->ready, __ATOMIC_ACQUIRE); tries++) usleep(1000);
+    if (!__atomic_load_n(&c->hdr->ready, __ATOMIC_ACQUIRE)) { c->err = "rank 0 never initialised the shared segment"; return SCALCE_ERR_HIP; }
+  }
+  pthread_barrier_wait(&c->hdr->barrier);
+  if (rank == 0) shm_unlink(name);  // everybody has it mapped: the name can go
+  return SCALCE_OK;
+}
+
+extern "C" void scalce_comm_destroy(scalce_comm *c) {
+  if (!c) return;
+  if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
+  if (c->hdr) munmap(c->hdr, c->map_bytes);
+  delete c;
+}
+
+extern "C" int scalce_comm_barrier(scalce_comm *c, void *stream) {
+  if (!c) return SCALCE_ERR_ARG;
+  if (c->world == 1 && !c->nccl) return SCALCE_OK;
+  if (c->shm) { pthread_barrier_wait(&c->hdr->barrier); return SCALCE_OK; }
+  // RCCL has no barrier: a one-element all-reduce on the stream, then wait for it
+  static thread_local uint64_t *d_one = nullptr;
+  if (!d_one) CM_HIP(c, hipMalloc(reinterpret_cast<void **>(&d_one), 8));
+  CM_NCCL(c, g_rccl.AllReduce(d_one, d_one, 1, ncclUint64, ncclSum, c->nccl, (hipStream_t)stream));
+  CM_HIP(c, hipStreamSynchronize((hipStream_t)stream));
+  return SCALCE_OK;
+}
+
+// recv[r * bytes .. ) = rank r's send
+extern "C" int scalce_comm_all_gather(scalce_comm *c, const void *d_send, void *d_recv, uint64_t bytes, void *stream) {
+  if (!c || (bytes && (!d_send || !d_recv))) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!bytes) return SCALCE_OK;
+  if (c->world == 1 && !c->nccl) {
+    if (d_send != d_recv) CM_HIP(c, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s));
+    return SCALCE_OK;
+  }
+  if (!c->shm) {
+    CM_NCCL(c, g_rccl.AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, s));
+    return SCALCE_OK;
+  }
+  if (bytes > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
+  CM_HIP(c, hipMemcpyAsync(c->slots + (size_t)c->rank * c->slot_bytes, d_send, bytes, hipMemcpyDeviceToHost, s));
+  CM_HIP(c, hipStreamSynchronize(s));
+  pthread_barrier_wait(&c->hdr->barrier);
+  for (int r = 0; r < c->world; r++)
+    CM_HIP(c, hipMemcpyAsync(static_cast<uint8_t *>(d_recv) + (size_t)r * bytes, c->slots + (size_t)r * c->slot_bytes, bytes, hipMemcpyHostToDevice, s));
+  CM_HIP(c, hipStreamSynchronize(s));
+  pthread_barrier_wait(&c->hdr->barrier);
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, uint64_t count, void *stream) {
+  if (!c || (count && !d_buf)) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!count || (c->world == 1 && !c->nccl)) return SCALCE_OK;
+  if (!c->shm) {
+    CM_NCCL(c, g_rccl.AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->nccl, s));
+    return SCALCE_OK;
+  }
+  const uint64_t bytes = count * 8;
+  if (bytes > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
+  uint64_t *mine = reinterpret_cast<uint64_t *>(c->slots + (size_t)c->rank * c->slot_bytes);
+  CM_HIP(c, hipMemcpyAsync(mine, d_buf, bytes, hipMemcpyDeviceToHost, s));
+  CM_HIP(c, hipStreamSynchronize(s));
+  pthread_barrier_wait(&c->hdr->barrier);
+  c->stage.resize(bytes);
+  uint64_t *acc = reinterpret_cast<uint64_t *>(c->stage.data());
+  memset(acc, 0, bytes);
+  for (int r = 0; r < c->world; r++) {
+    const uint64_t *x = reinterpret_cast<const uint64_t *>(c->slots + (size_t)r * c->slot_bytes);
+    for (uint64_t i = 0; i < count; i++) acc[i] += x[i];
+  }
+  pthread_barrier_wait(&c->hdr->barrier);
+  CM_HIP(c, hipMemcpyAsync(d_buf, acc, bytes, hipMemcpyHostToDevice, s));
+  CM_HIP(c, hipStreamSynchronize(s));
+  return SCALCE_OK;
+}
+
+// Rank r sends send_bytes[d] bytes to every rank d (consecutive ranges of d_send, rank order) and receives
+// recv_bytes[src] from every rank src into consecutive ranges of d_recv (rank order).
+extern "C" int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, const uint64_t *send_bytes, void *d_recv,
+                                        const uint64_t *recv_bytes, void *stream) {
+  if (!c || !send_bytes || !recv_bytes) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const uint8_t *src = static_cast<const uint8_t *>(d_send);
+  uint8_t *dst = static_cast<uint8_t *>(d_recv);
+  if (c->world == 1 && !c->nccl) {
+    if (send_bytes[0] != recv_bytes[0]) { c->err = "all_to_all_v: sizes disagree"; return SCALCE_ERR_ARG; }
+    if (send_bytes[0]) CM_HIP(c, hipMemcpyAsync(dst, src, send_bytes[0], hipMemcpyDeviceToDevice, s));
+    return SCALCE_OK;
+  }
+  if (!c->shm) {
+    // the usual grouped send / receive pattern; messages of any size (RCCL takes a size_t count)
+    CM_NCCL(c, g_rccl.GroupStart());
+    uint64_t so = 0, ro = 0;
+    for (int r = 0; r < c->world; r++) {
+      if (send_bytes[r]) CM_NCCL(c, g_rccl.Send(src + so, send_bytes[r], ncclUint8, r, c->nccl, s));
+      if (recv_bytes[r]) CM_NCCL(c, g_rccl.Recv(dst + ro, recv_bytes[r], ncclUint8, r, c->nccl, s));
+      so += send_bytes[r];
+      ro += recv_bytes[r];
+    }
+    CM_NCCL(c, g_rccl.GroupEnd());
+    return SCALCE_OK;
+  }
+  uint64_t total = 0;
+  for (int r = 0; r < c->world; r++) total += send_bytes[r];
+  if (total > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
+  if (total) CM_HIP(c, hipMemcpyAsync(c->slots + (size_t)c->rank * c->slot_bytes, src, total, hipMemcpyDeviceToHost, s));
+  for (int r = 0; r < c->world; r++) c->hdr->sizes[c->rank][r] = send_bytes[r];
+  CM_HIP(c, hipStreamSynchronize(s));
+  pthread_barrier_wait(&c->hdr->barrier);
+  uint64_t ro = 0;
+  for (int r = 0; r < c->world; r++) {
+    if (c->hdr->sizes[r][c->rank] != recv_bytes[r]) { c->err = "all_to_all_v: a sender's size differs from what the receiver expects"; pthread_barrier_wait(&c->hdr->barrier); return SCALCE_ERR_ARG; }
+    uint64_t off = 0;
+    for (int d = 0; d < c->rank; d++) off += c->hdr->sizes[r][d];
+    if (recv_bytes[r]) CM_HIP(c, hipMemcpyAsync(dst + ro, c->slots + (size_t)r * c->slot_bytes + off, recv_bytes[r], hipMemcpyHostToDevice, s));
+    ro += recv_bytes[r];
+  }
+  CM_HIP(c, hipStreamSynchronize(s));
+  pthread_barrier_wait(&c->hdr->barrier);
+  return SCALCE_OK;
+}

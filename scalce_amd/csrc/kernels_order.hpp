@@ -151,6 +151,29 @@ __global__ void chunk_bounds_k(const u64 *S /*exclusive prefix, S[n] = total*/, 
   chunk_start[c] = n;
   *nchunks = c;
 }
+// The same rule for a rank of a sharded run: `carry_in` bytes are already in the chunk that is open when this rank's rows
+// begin (the rows of the ranks before it), cuts[] = rows in front of which a new chunk starts (1 .. n), carry_out = bytes
+// in the chunk still open behind the last row.
+__global__ void chunk_cuts_k(const u64 *S /*exclusive prefix, S[n] = total*/, u64 n, u64 limit, u64 carry_in, u32 max_cuts,
+                             u64 *cuts, u32 *ncuts, u64 *carry_out) {
+  if (threadIdx.x || blockIdx.x) return;
+  u32 c = 0;
+  u64 start = 0, carry = carry_in;
+  while (limit && start < n && c < max_cuts) {
+    const u64 need = S[start] + (limit > carry ? limit - carry : 0);
+    u64 lo = start, hi = n;  // smallest r in [start, n) with S[r + 1] >= need
+    while (lo < hi) {
+      const u64 mid = (lo + hi) >> 1;
+      if (S[mid + 1] >= need) hi = mid; else lo = mid + 1;
+    }
+    if (lo >= n) break;
+    start = lo + 1;
+    cuts[c++] = start;
+    carry = 0;
+  }
+  *carry_out = carry + (S[n] - S[start]);
+  *ncuts = c;
+}
 __global__ __launch_bounds__(256) void chunk_assign_k(u64 n, const u64 *chunk_start, const u32 *nchunks, u32 *chunk) {
   const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -291,6 +314,16 @@ struct NameLenSeq {
   const u8 *outlen;
   __device__ u64 operator()(u64 k) const { return 1ull + outlen[k]; }
 };
+// bytes of the name records of every bucket (sharded runs: where a rank's names go in the run-wide stream)
+__global__ __launch_bounds__(256) void bucket_name_bytes_k(u32 nb1, const u64 *bucket_first, const u64 *counts, const u64 *name_off,
+                                                          const u64 *names_total, u64 nrec, u64 *out) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb1) return;
+  const u64 f = bucket_first[b], e = f + counts[b];
+  const u64 lo = f < nrec ? name_off[f] : *names_total, hi = e < nrec ? name_off[e] : *names_total;
+  out[b] = counts[b] ? hi - lo : 0;
+}
+
 // The 16-byte cell written by the ingest stage holds the length and up to 15 characters: ONE gather per record; a longer
 // name comes from the long-name store (input order, written when its piece was ingested).
 __global__ __launch_bounds__(256) void emit_names_k(u64 nrec, const u32 *perm, const u8 *cells, const u64 *store_off,

@@ -237,12 +237,14 @@ struct scalce_batch {
   // [base, base + NP) are the piece being ingested / tokenized, N = base + NP is everything the batch holds.  Packed
   // bases, q', names and tokens are run-wide arrays indexed by row; the text of a piece is dead once it is ingested.
   u64 N = 0, base = 0, NP = 0;
+  u64 tok_done = 0, tok_base = 0, tok_n = 0;  // rows tokenized so far / the rows of the tokenization in progress
   u64 row_cap = 0;           // rows the run-wide arrays hold
   u64 piece_rows_cap = 0;    // records one piece may bring (size of the line index)
   bool appending = false;    // the pieces came through scalce_batch_append
   bool lean = false;         // release what a stage no longer needs (runs sized for most of HBM)
   u64 tri_expected[2] = {0, 0};  // trigrams counted so far (tri_check_k)
   u64 names_in_used = 0;     // bytes of the long-name store in use
+  u64 S_rows = ~0ull;        // rows the record-size prefix sums in S cover (scalce_batch_chunk_plan), ~0 = stale
   u64 text_bytes[2] = {0, 0};
   bool ingested[2] = {false, false};
   // device state
@@ -252,7 +254,7 @@ struct scalce_batch {
   u8 *d_qlut[2] = {nullptr, nullptr};
   int q_affine[2] = {-1, -1};  // the quality map is q - offset for every character: no table lookups in the ingest kernel
   DBuf line_end[2], tile[2], packed[2], q[2], namelen, namecell, outlen, freq4[2], table[2], qs[2];
-  DBuf names_in, name_in_off, counts_total, prior_buf;  // names longer than a cell, input order; reads per bucket over all pieces
+  DBuf names_in, name_in_off, counts_total, prior_buf, bucket_name_bytes;  // names longer than a cell, input order; reads per bucket over all pieces
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
   DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
@@ -336,7 +338,7 @@ static void release(DBuf &d) {
 }
 
 static void free_all(scalce_batch *b) {
-  DBuf *all[] = {&b->tile[0], &b->tile[1], &b->names_in, &b->name_in_off, &b->counts_total, &b->prior_buf,
+  DBuf *all[] = {&b->bucket_name_bytes, &b->tile[0], &b->tile[1], &b->names_in, &b->name_in_off, &b->counts_total, &b->prior_buf,
                  &b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen, &b->namecell, &b->outlen,
                  &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
                  &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
@@ -518,7 +520,7 @@ static inline u32 cdiv(u64 a, u64 b) {
 static int piece_count(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, hipStream_t s, u64 *nlines, u8 *last) {
   scalce_ctx *c = b->ctx;
   if (((uintptr_t)d_text & 15) != 0) { set_err(c, "FASTQ text must be 16-byte aligned"); return SCALCE_ERR_ARG; }
-  if (nbytes > b->max_text) { set_err(c, "text larger than the batch capacity"); return SCALCE_ERR_CAPACITY; }
+  if (nbytes > b->max_text) b->max_text = nbytes;  // max_text only sizes the first allocations; everything below grows
   b->text_bytes[mate] = nbytes;
   const u32 ntiles = cdiv(nbytes, IDX_TILE);
   ENSURE(b, b->tile[mate], (ntiles + 8) * sizeof(u64));
@@ -583,6 +585,8 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
 
 static void batch_restart(scalce_batch *b) {
   b->N = b->base = b->NP = 0;
+  b->S_rows = ~0ull;
+  b->tok_done = b->tok_base = b->tok_n = 0;
   b->appending = false;
   b->names_in_used = 0;
   b->tri_expected[0] = b->tri_expected[1] = 0;
@@ -625,7 +629,8 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
 // piece.  Ingest, quality counters and the tie-break of the new rows (against all rows before them) run here; order,
 // emit and entropy run once, over everything, when the caller has no more input.
 extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2,
-                                   int final_piece, uint64_t consumed[2], void *stream) {
+                                   int flags, uint64_t consumed[2], void *stream) {
+  const int final_piece = flags & SCALCE_APPEND_FINAL;
   if (!b || !consumed || (n1 && !d_text1) || (b->nm == 2 && n2 && !d_text2)) return SCALCE_ERR_ARG;
   scalce_ctx *c = b->ctx;
   hipStream_t s = (hipStream_t)stream;
@@ -666,8 +671,8 @@ extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint
   }
   b->N = b->base + nrec;
   int rc;
-  if ((rc = scalce_batch_quality(b, stream))) return rc;
-  if ((rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
+  if (!(flags & SCALCE_APPEND_NO_QUALITY) && (rc = scalce_batch_quality(b, stream))) return rc;
+  if (!(flags & SCALCE_APPEND_NO_TOKENIZE) && (rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
   return SCALCE_OK;
 }
 
@@ -723,8 +728,11 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   scalce_ctx *c = b->ctx;
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
-  const u64 N = b->NP;  // the rows of this piece, [base, base + NP); earlier pieces are settled
-  const u8 *packed0 = b->packed[0].as<u8>() + b->base * (u64)b->stride[0];
+  // the rows not tokenized yet, [tok_base, N): the piece just appended, or everything when the caller deferred it
+  b->tok_base = b->tok_done;
+  b->tok_n = b->N - b->tok_done;
+  const u64 N = b->tok_n;
+  const u8 *packed0 = b->packed[0].as<u8>() + b->tok_base * (u64)b->stride[0];
   b->jacobi_iters = 0;
   b->tok_open = true;
   const u32 nb1 = (u32)c->A.n_buckets + 1;  // buckets incl. root
@@ -737,7 +745,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     ENSURE(b, b->counts_total, sizeof(u64) * (nb1 + 1));
     ENSURE(b, b->prior_buf, sizeof(u64) * (nb1 + 1));
   }
-  if (b->base == 0) HIP_TRY(c, hipMemsetAsync(b->counts_total.p, 0, sizeof(u64) * (nb1 + 1), s));
+  if (b->tok_base == 0) HIP_TRY(c, hipMemsetAsync(b->counts_total.p, 0, sizeof(u64) * (nb1 + 1), s));
   ENSURE(b, b->seg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->Gseg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(2 * N + 1024) + 1024));
@@ -857,7 +865,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
 static int tokenize_sweep_enqueue(scalce_batch *b, const uint64_t *d_prior, u32 *flag, hipStream_t s) {
   scalce_ctx *c = b->ctx;
   const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie;
-  if (b->base) {  // reads of this batch's earlier pieces count as well (bin_size is cumulative, reads.cpp:246)
+  if (b->tok_base) {  // reads of this batch's earlier pieces count as well (bin_size is cumulative, reads.cpp:246)
     if (d_prior) {
       LAUNCH(add_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), b->counts_total.as<u64>(), b->prior_buf.as<u64>());
       d_prior = b->prior_buf.as<uint64_t>();
@@ -893,7 +901,7 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   *changed = 0;
-  if (!b->NP || !b->ntie) return SCALCE_OK;
+  if (!b->tok_n || !b->ntie) return SCALCE_OK;
   { int rc = tokenize_sweep_enqueue(b, d_prior, b->d_small + 4, s); if (rc) return rc; }
   u32 ch = 0;
   { int rc = read_u32(b, b->d_small + 4, &ch, 1, s); if (rc) return rc; }
@@ -909,7 +917,8 @@ extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
   HIP_TRY(c, hipSetDevice(c->device));
   StageTimer tm(b, ST_TOKENIZE, s);
   b->tok_open = false;
-  const u64 N = b->NP;
+  const u64 N = b->tok_n;
+  b->tok_done = b->tok_base + b->tok_n;
   const u32 nb1 = (u32)c->A.n_buckets + 1;
   // reads per bucket over all pieces so far: what the next piece's tie-break starts from, and what the emit stage lays out
   LAUNCH(add_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, b->counts.as<u64>(), b->counts_total.as<u64>(), b->counts_total.as<u64>());
@@ -918,7 +927,7 @@ extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
   a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
   a.tie_off = b->tie_off.as<u32>(); a.choice = b->choice.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
   a.cand_pos = b->cand_pos.as<u32>(); a.bucket_pattern = c->d_bucket_pattern; a.root_bucket = (u32)c->A.n_buckets;
-  a.bucket = b->bucket.as<u32>() + b->base; a.end = b->endv.as<u16>() + b->base; a.tokens = b->tokens.as<int32_t>() + 2 * b->base;
+  a.bucket = b->bucket.as<u32>() + b->tok_base; a.end = b->endv.as<u16>() + b->tok_base; a.tokens = b->tokens.as<int32_t>() + 2 * b->tok_base;
   LAUNCH(finalize_k, cdiv(N, 256), 256, 0, s, a);
   return SCALCE_OK;
 }
@@ -930,7 +939,7 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
   // nothing (and costs next to nothing), while a round trip per sweep left the stream idle 47 times per shard.
   hipStream_t s = (hipStream_t)stream;
   constexpr int SWEEPS_PER_LOOK = 4;
-  for (bool done = !(b->NP && b->ntie); !done;) {
+  for (bool done = !(b->tok_n && b->ntie); !done;) {
     StageTimer tm(b, ST_TOKENIZE, s);
     u32 *flags = b->d_small + 32;
     for (int i = 0; i < SWEEPS_PER_LOOK; i++)
@@ -944,6 +953,62 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
     if (b->jacobi_iters > b->ntie + 1 + SWEEPS_PER_LOOK) { set_err(b->ctx, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
   }
   return scalce_batch_tokenize_end(b, stream);
+}
+
+// Sharded runs: where the -B rule (compress.cpp:702-715) cuts this rank's rows, given the bytes already in the chunk that
+// is open when they begin.  Record sizes need every row's core LENGTH only (the candidates of a tie are equally long), so
+// this runs before the tie-break: the first scan of the tokenizer over all rows, a prefix sum of the sizes, the cuts.
+extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint64_t *cuts_host, uint32_t cap, uint32_t *ncuts,
+                                       uint64_t *carry_out, void *stream) {
+  if (!b || !ncuts || !carry_out || (cap && !cuts_host) || !b->ingested[0]) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_TOKENIZE, s);
+  const u64 N = b->N;
+  *ncuts = 0;
+  *carry_out = carry_in;
+  if (!N) return SCALCE_OK;
+  ENSURE(b, b->tok_bucket, sizeof(u32) * (N + 1));
+  ENSURE(b, b->tok_pos, sizeof(u32) * (N + 1));
+  if (b->S_rows != N) {  // (a second call with another carry_in only redoes the cuts)
+    TokArgs a;
+    a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
+    a.packed = b->packed[0].as<u8>(); a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
+    a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
+    a.kmer = c->d_kmer; a.id8_first = c->id8_first;
+    const size_t sh = (size_t)a.lds_states * 20;
+    if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+    else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
+    else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+  }
+  ENSURE(b, b->S, sizeof(u64) * (N + 2));
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(N + 1) + 1024));
+  ENSURE(b, b->chunk_start, sizeof(u64) * (cap + 8));
+  u64 *S = b->S.as<u64>();
+  if (b->S_rows != N) {
+    RecSize rs{b->tok_bucket.as<u32>(), c->d_bucket_level, b->namelen.as<u8>(), b->L[0], b->L[1], b->p.paired, b->p.use_names, 1};
+    exclusive_scan<u64>(rs, N, StoreTo<u64>{S}, b->scan_ws.as<u64>(), S + N, s);
+    b->S_rows = N;
+  }
+  LAUNCH(chunk_cuts_k, 1, 1, 0, s, S, N, (u64)b->p.bucket_set_size, (u64)carry_in, cap, b->chunk_start.as<u64>(), b->d_small + 8, b->d_small64 + 7);
+  u32 n = 0;
+  { int rc = read_u32(b, b->d_small + 8, &n, 1, s); if (rc) return rc; }
+  { u64 co = 0; int rc = read_u64(b, b->d_small64 + 7, &co, 1, s); if (rc) return rc; *carry_out = co; }
+  if (n) HIP_TRY(c, hipMemcpy(cuts_host, b->chunk_start.p, sizeof(u64) * n, hipMemcpyDeviceToHost));
+  *ncuts = n;
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset) {
+  if (!b || !offset || mate < 0 || mate >= b->nm || row > b->NP) return SCALCE_ERR_ARG;
+  *offset = 0;
+  if (!row) return SCALCE_OK;
+  HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  u64 v = 0;
+  HIP_TRY(b->ctx, hipMemcpy(&v, b->line_end[mate].as<u64>() + 4 * row - 1, sizeof(u64), hipMemcpyDeviceToHost));
+  *offset = v + 1;
+  return SCALCE_OK;
 }
 
 extern "C" int scalce_batch_set_chunks(scalce_batch *b, const uint64_t *starts, uint32_t n) {
@@ -984,6 +1049,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
     if (nc > 1) LAUNCH(chunk_assign_k, cdiv(N, 256), 256, 0, s, N, b->chunk_start.as<u64>(), b->d_small + 8, b->chunk.as<u32>());
   } else if (b->p.bucket_set_size) {
     ENSURE(b, b->S, sizeof(u64) * (N + 2));
+    b->S_rows = ~0ull;
     ENSURE(b, b->chunk, sizeof(u32) * (N + 2));
     const u32 max_chunks = 4096;
     ENSURE(b, b->chunk_start, sizeof(u64) * (max_chunks + 2));
@@ -1113,6 +1179,9 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     ENSURE(b, b->outlen, N + 64);
     if (N) LAUNCH(name_outlen_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->outlen.as<u8>());
     exclusive_scan<u64>(NameLenSeq{b->outlen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
+    ENSURE(b, b->bucket_name_bytes, sizeof(u64) * (nb1 + 1));
+    LAUNCH(bucket_name_bytes_k, cdiv(nb1, 256), 256, 0, s, nb1, b->bucket_first.as<u64>(), counts, b->name_off.as<u64>(), b->d_small64 + 3, N,
+           b->bucket_name_bytes.as<u64>());
   }
   u64 h[4] = {0, 0, 0, 0};
   { int rc = read_u64(b, b->d_small64, h, 4, s); if (rc) return rc; }
@@ -1649,6 +1718,7 @@ extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, c
     case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->tok_open ? b->counts.p : b->counts_total.p; *nbytes = sizeof(u64) * nb1; break;
     case SCALCE_OUT_QINPUT: *d_ptr = b->q[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
     case SCALCE_OUT_NAMELEN: *d_ptr = b->namelen.p; *nbytes = b->N; break;
+    case SCALCE_OUT_BUCKET_NAME_BYTES: *d_ptr = b->bucket_name_bytes.p; *nbytes = b->bucket_name_bytes.p ? sizeof(u64) * nb1 : 0; break;
     default: return SCALCE_ERR_ARG;
   }
   return SCALCE_OK;

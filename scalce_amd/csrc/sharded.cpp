@@ -1,0 +1,441 @@
+// sharded.cpp -- one archive from a read stream split over several GPUs (one process per GPU, RCCL over xGMI).
+//
+// Every rank holds a contiguous piece of the input (rank order = input order).  What the reference carries across reads
+// is exchanged, nothing else (sizes for 8 ranks x 50 M reads of 100 bp):
+//   spill rule      compress.cpp:702-715  running record bytes of the open chunk: a chain of `world` 8-byte messages, then
+//                                         an all-gather of the cuts; rank boundaries move to the nearest cut and the records
+//                                         in between change owner AS TEXT (at most half a chunk per boundary, ~2.6 GB)
+//   quality model   qualities.cpp:179-198 all-reduce of the 80^3 counters (4 MB per mate) + the trigrams that straddle a
+//                                         rank boundary (all-gather of 4 edge symbols)
+//   tie-break       reads.cpp:246,420     per round an all-gather of the per-bucket counts (125 KB); a rank's prior is the
+//                                         sum over the ranks before it; several local sweeps per round
+//   bucket layout   compress.cpp:364-379  all-gather of final counts and name bytes per bucket (2 x 125 KB)
+//   coder blocks    arithmetic.cpp:318-363 cut every 10 MiB of the RUN-WIDE reordered stream: one all-to-all of q' bytes
+//                                         into contiguous block ranges (~ L bytes per read, 7/8 of it leaves the rank)
+// With rank boundaries ON chunk boundaries, "inside a bucket: rank 0's records, rank 1's, ..." is exactly the merge order
+// of compress.cpp:104-159, so the archive equals the one-GPU archive and the reference's at -T 1 with the same -B.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scalce_hip.h"
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr u64 AC_BLOCK = 10ull * 1024 * 1024;
+
+// prior[b] = reads of bucket b held by the ranks before `rank`; gathered = [world][stride] u64
+__global__ void prior_from_gathered_k(uint32_t nb1, const u64 *gathered, uint32_t stride, int rank, u64 *prior) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb1) return;
+  u64 s = 0;
+  for (int r = 0; r < rank; r++) s += gathered[(size_t)r * stride + b];
+  prior[b] = s;
+}
+__global__ void add_ones_k(u64 *table, const uint32_t *keys, uint32_t n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    for (uint32_t i = 0; i < n; i++) table[keys[i]] += 1;
+}
+
+struct Fail {
+  std::string msg;
+  int rc;
+};
+
+}  // namespace
+
+#define SH_RC(ctx, expr)                                                        \
+  do {                                                                          \
+    int rc_ = (expr);                                                           \
+    if (rc_) throw Fail{std::string(#expr) + ": " + scalce_last_error(ctx), rc_}; \
+  } while (0)
+#define SH_CM(comm, expr)                                                        \
+  do {                                                                           \
+    int rc_ = (expr);                                                            \
+    if (rc_) throw Fail{std::string(#expr) + ": " + scalce_comm_error(comm), rc_}; \
+  } while (0)
+#define SH_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) throw Fail{std::string(#expr) + ": " + hipGetErrorString(e_), SCALCE_ERR_HIP}; \
+  } while (0)
+
+namespace {
+
+struct DevMem {  // freed on scope exit unless released
+  std::vector<void *> ptrs;
+  ~DevMem() { for (void *p : ptrs) if (p) hipFree(p); }
+  template <typename T> T *alloc(size_t n) {
+    void *p = nullptr;
+    SH_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T) + 64));
+    ptrs.push_back(p);
+    return static_cast<T *>(p);
+  }
+  void *release(void *p) {
+    for (auto &q : ptrs) if (q == p) q = nullptr;
+    return p;
+  }
+};
+
+template <typename T> std::vector<T> gather_host(scalce_comm *comm, const T *mine, size_t count, T *d_send, T *d_recv, hipStream_t s) {
+  const int W = scalce_comm_world(comm);
+  SH_HIP(hipMemcpyAsync(d_send, mine, count * sizeof(T), hipMemcpyHostToDevice, s));
+  SH_CM(comm, scalce_comm_all_gather(comm, d_send, d_recv, count * sizeof(T), s));
+  std::vector<T> all((size_t)W * count);
+  SH_HIP(hipMemcpyAsync(all.data(), d_recv, all.size() * sizeof(T), hipMemcpyDeviceToHost, s));
+  SH_HIP(hipStreamSynchronize(s));
+  return all;
+}
+
+}  // namespace
+
+extern "C" void scalce_shard_result_free(scalce_shard_result *r) {
+  if (!r) return;
+  free(r->counts);
+  free(r->name_bytes);
+  r->counts = r->name_bytes = nullptr;
+  for (void *&p : r->keep) { if (p) hipFree(p); p = nullptr; }
+}
+
+extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalce_batch *b, const uint8_t *d_text1, uint64_t n1,
+                                       const uint8_t *d_text2, uint64_t n2, int flags, void *stream, void *coder_stream,
+                                       scalce_shard_result *res) {
+  if (!comm || !ctx || !b || !res) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int W = scalce_comm_world(comm), rank = scalce_comm_rank(comm);
+  if (W > 64) return SCALCE_ERR_ARG;
+  memset(res, 0, sizeof *res);
+  res->world = W;
+  res->rank = rank;
+  static std::string last_error;
+  try {
+    DevMem mem;
+    const uint8_t *text[2] = {d_text1, d_text2};
+    u64 nbytes[2] = {n1, n2};
+    const void *dp = nullptr;
+    uint64_t nb = 0;
+    // ---- 1. first pass over the own piece: rows + quality counters, no tie-break yet
+    uint64_t used[2] = {0, 0};
+    SH_RC(ctx, scalce_batch_reset(b));
+    SH_RC(ctx, scalce_batch_append(b, text[0], nbytes[0], text[1], nbytes[1], SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_TOKENIZE, used, s));
+    const u64 N0 = scalce_batch_reads(b);
+    const uint32_t nb1 = (uint32_t)scalce_patterns_buckets(ctx) + 1;
+    res->nb1 = nb1;
+    const int nm = text[1] ? 2 : 1;
+    int L[2] = {0, 0};
+    {  // read lengths: symbols per row of the q' output
+      for (int m = 0; m < nm; m++) {
+        SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QINPUT, m, &dp, &nb));
+        L[m] = N0 ? (int)(nb / N0) : 0;
+      }
+    }
+    u64 *d_small = mem.alloc<u64>(4096 + 64 * (size_t)W);
+    u64 *d_gather = mem.alloc<u64>((size_t)W * 4096 + (size_t)W * 64 * W);
+    // rows and read lengths of everyone (a rank without reads learns the read length here)
+    std::vector<u64> meta;
+    {
+      u64 mine[4] = {N0, (u64)L[0], (u64)L[1], 0};
+      meta = gather_host<u64>(comm, mine, 4, d_small, d_gather, s);
+      for (int r = 0; r < W; r++)
+        for (int m = 0; m < nm; m++)
+          if (!L[m] && meta[4 * r + 1 + m]) L[m] = (int)meta[4 * r + 1 + m];
+    }
+    std::vector<u64> g(W + 1, 0);  // run-wide index of every rank's first record
+    for (int r = 0; r < W; r++) g[r + 1] = g[r] + meta[4 * r];
+    const u64 total_reads = g[W];
+    res->reads_total = total_reads;
+    // the first two and last two q' symbols of the own piece: trigrams that straddle a rank boundary (step 4)
+    uint8_t edge[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int m = 0; m < nm; m++) {
+      SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QINPUT, m, &dp, &nb));
+      if (nb >= 2) {
+        SH_HIP(hipMemcpy(edge[m], dp, 2, hipMemcpyDeviceToHost));
+        SH_HIP(hipMemcpy(edge[m] + 2, static_cast<const uint8_t *>(dp) + nb - 2, 2, hipMemcpyDeviceToHost));
+      } else if (nb == 1) {
+        SH_HIP(hipMemcpy(edge[m], dp, 1, hipMemcpyDeviceToHost));
+        edge[m][3] = edge[m][0];
+      }
+    }
+    // ---- 2. spill chunks of the run-wide -B rule: a chain of carries, then everybody learns every cut
+    std::vector<u64> cuts_global;  // run-wide rows in front of which a chunk begins
+    {
+      const uint32_t CAP = 4000;
+      std::vector<uint64_t> cuts(CAP);
+      uint32_t nc = 0;
+      uint64_t carry_out = 0;
+      SH_RC(ctx, scalce_batch_chunk_plan(b, 0, cuts.data(), CAP, &nc, &carry_out, s));  // sizes of all rows: every rank at once
+      u64 carry_in = 0;
+      for (int k = 0; k < W; k++) {  // rank k can cut once it knows what rank k - 1 left open
+        if (k == rank) SH_RC(ctx, scalce_batch_chunk_plan(b, carry_in, cuts.data(), CAP, &nc, &carry_out, s));
+        if (W > 1) {
+          u64 mine = k == rank ? carry_out : 0;
+          std::vector<u64> all = gather_host<u64>(comm, &mine, 1, d_small, d_gather, s);
+          if (rank == k + 1) carry_in = all[k];
+        }
+      }
+      if (nc >= CAP) throw Fail{"more than 4000 spill chunks on one rank: -B is too small for this input", SCALCE_ERR_CAPACITY};
+      std::vector<u64> mine(CAP + 1, 0);
+      mine[0] = nc;
+      for (uint32_t i = 0; i < nc; i++) mine[1 + i] = g[rank] + cuts[i];
+      std::vector<u64> all = gather_host<u64>(comm, mine.data(), CAP + 1, d_small, d_gather, s);
+      for (int r = 0; r < W; r++)
+        for (u64 i = 0; i < all[(size_t)r * (CAP + 1)]; i++) cuts_global.push_back(all[(size_t)r * (CAP + 1) + 1 + i]);
+      std::sort(cuts_global.begin(), cuts_global.end());
+      res->chunks_total = (uint32_t)cuts_global.size() + ((cuts_global.empty() || cuts_global.back() < total_reads) ? 1 : 0);
+    }
+    // ---- 3. rank boundaries move to the nearest cut; the records in between change owner as text
+    std::vector<u64> gn = g;
+    for (int r = 1; r < W; r++) {
+      if (cuts_global.empty()) throw Fail{"(ERROR) a sharded run needs -B below a rank's share of the input: no spill chunk ends inside the run, "
+                                          "so the records of a bucket would have to be merged across ranks", SCALCE_ERR_CAPACITY};
+      auto it = std::lower_bound(cuts_global.begin(), cuts_global.end(), g[r]);
+      u64 best = it == cuts_global.end() ? cuts_global.back() : *it;
+      if (it != cuts_global.begin()) { const u64 lo = *(it - 1); if (g[r] - lo <= best - g[r] || best < g[r]) best = lo; }
+      gn[r] = best;
+    }
+    for (int r = 1; r < W; r++) {
+      if (gn[r] < gn[r - 1]) gn[r] = gn[r - 1];
+      if (gn[r] < g[r - 1] || gn[r] > g[r + 1])
+        throw Fail{"(ERROR) a spill chunk spans more than two neighbouring ranks: use a smaller -B or fewer GPUs", SCALCE_ERR_CAPACITY};
+    }
+    const u64 head_out = gn[rank] > g[rank] ? gn[rank] - g[rank] : 0;               // rows that leave for rank - 1
+    const u64 tail_out = gn[rank + 1] < g[rank + 1] ? g[rank + 1] - gn[rank + 1] : 0;  // ... for rank + 1
+    const u64 head_in = gn[rank] < g[rank] ? g[rank] - gn[rank] : 0;
+    const u64 tail_in = gn[rank + 1] > g[rank + 1] ? gn[rank + 1] - g[rank + 1] : 0;
+    res->first_read = gn[rank];
+    res->reads_local = gn[rank + 1] - gn[rank];
+    res->moved_in[0] = head_in;
+    res->moved_in[1] = tail_in;
+    bool anything_moves = false;
+    for (int r = 1; r < W; r++) anything_moves = anything_moves || gn[r] != g[r];
+    if (anything_moves) {
+      if (head_out + tail_out > N0) throw Fail{"internal: more rows leave than the rank holds", SCALCE_ERR_ARG};
+      uint8_t *newtext[2] = {nullptr, nullptr};
+      u64 newbytes[2] = {0, 0};
+      for (int m = 0; m < nm; m++) {
+        uint64_t o_head = 0, o_tail = nbytes[m];
+        SH_RC(ctx, scalce_batch_text_offset(b, m, head_out, &o_head));
+        SH_RC(ctx, scalce_batch_text_offset(b, m, N0 - tail_out, &o_tail));
+        // who sends how much to whom: only neighbours
+        std::vector<uint64_t> sendb(W, 0), recvb(W, 0);
+        if (rank > 0) sendb[rank - 1] = o_head;
+        if (rank + 1 < W) sendb[rank + 1] = nbytes[m] - o_tail;
+        u64 mine[2] = {rank > 0 ? o_head : 0, rank + 1 < W ? nbytes[m] - o_tail : 0};
+        std::vector<u64> all = gather_host<u64>(comm, mine, 2, d_small, d_gather, s);
+        if (rank > 0) recvb[rank - 1] = all[2 * (rank - 1) + 1];   // what rank - 1 sends to the rank behind it
+        if (rank + 1 < W) recvb[rank + 1] = all[2 * (rank + 1)];   // what rank + 1 sends to the rank before it
+        const u64 from_left = rank > 0 ? recvb[rank - 1] : 0, from_right = rank + 1 < W ? recvb[rank + 1] : 0;
+        const u64 kept = o_tail - o_head;
+        newbytes[m] = from_left + kept + from_right;
+        newtext[m] = mem.alloc<uint8_t>(newbytes[m] + 256);
+        uint8_t *d_send = mem.alloc<uint8_t>(sendb[rank > 0 ? rank - 1 : 0] + sendb[rank + 1 < W ? rank + 1 : 0] + 256);
+        uint8_t *d_recv = mem.alloc<uint8_t>(from_left + from_right + 256);
+        u64 so = 0;
+        if (rank > 0 && o_head) { SH_HIP(hipMemcpyAsync(d_send, text[m], o_head, hipMemcpyDeviceToDevice, s)); so = o_head; }
+        if (rank + 1 < W && nbytes[m] > o_tail) SH_HIP(hipMemcpyAsync(d_send + so, text[m] + o_tail, nbytes[m] - o_tail, hipMemcpyDeviceToDevice, s));
+        SH_CM(comm, scalce_comm_all_to_all_v(comm, d_send, sendb.data(), d_recv, recvb.data(), s));
+        if (from_left) SH_HIP(hipMemcpyAsync(newtext[m], d_recv, from_left, hipMemcpyDeviceToDevice, s));
+        if (kept) SH_HIP(hipMemcpyAsync(newtext[m] + from_left, text[m] + o_head, kept, hipMemcpyDeviceToDevice, s));
+        if (from_right) SH_HIP(hipMemcpyAsync(newtext[m] + from_left + kept, d_recv + from_left, from_right, hipMemcpyDeviceToDevice, s));
+      }
+      // the rows of the new range (their quality symbols were counted by whoever held them in the first pass)
+      SH_RC(ctx, scalce_batch_reset(b));
+      SH_RC(ctx, scalce_batch_append(b, newtext[0], newbytes[0], nm == 2 ? newtext[1] : nullptr, newbytes[1],
+                                     SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_QUALITY | SCALCE_APPEND_NO_TOKENIZE, used, s));
+      if (scalce_batch_reads(b) != res->reads_local) throw Fail{"internal: row count after the exchange differs from the plan", SCALCE_ERR_ARG};
+    }
+    const u64 N = scalce_batch_reads(b);
+    // ---- 4. run-wide quality model: trigrams across the ORIGINAL piece boundaries, all-reduce, scaling
+    uint32_t *d_table = nullptr;
+    if (L[0]) {
+      std::vector<uint8_t> ed(8, 0);
+      memcpy(ed.data(), edge, 8);
+      uint8_t *d_e = reinterpret_cast<uint8_t *>(d_small);
+      std::vector<uint8_t> edges = gather_host<uint8_t>(comm, ed.data(), 8, d_e, reinterpret_cast<uint8_t *>(d_gather), s);
+      d_table = mem.alloc<uint32_t>(2 * 512000);
+      for (int m = 0; m < nm; m++) {
+        SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_FREQ4, m, &dp, &nb));
+        u64 *d_f4 = static_cast<u64 *>(const_cast<void *>(dp));
+        // symbols next to the boundary in front of this rank's ORIGINAL piece (pieces before it may be empty or short)
+        std::vector<uint32_t> keys;
+        const u64 own = meta[4 * rank] * (u64)L[m];
+        if (rank > 0 && own) {
+          std::vector<uint32_t> before;  // up to two symbols in front of the piece, nearest last
+          for (int r = rank - 1; r >= 0 && before.size() < 2; r--) {
+            const u64 nsy = meta[4 * r] * (u64)L[m];
+            const uint8_t *e = &edges[(size_t)r * 8 + 4 * m];
+            if (nsy >= 2) { if (before.empty()) { before.push_back(e[3]); before.push_back(e[2]); } else before.push_back(e[3]); }
+            else if (nsy == 1) before.push_back(e[0]);
+          }
+          const uint8_t *me = &edges[(size_t)rank * 8 + 4 * m];
+          const uint32_t s0 = me[0], s1 = own >= 2 ? me[1] : 0xFFFFu;
+          // before[0] = the symbol right in front (p1), before[1] = the one before that (p0)
+          if (before.size() >= 2 && s0 < 80 && before[0] < 80 && before[1] < 80) keys.push_back((before[1] * 80 + before[0]) * 80 + s0);
+          if (before.size() >= 1 && own >= 2 && s0 < 80 && s1 < 80 && before[0] < 80) keys.push_back((before[0] * 80 + s0) * 80 + s1);
+        }
+        if (!keys.empty()) {
+          uint32_t *d_k = reinterpret_cast<uint32_t *>(d_small);
+          SH_HIP(hipMemcpyAsync(d_k, keys.data(), keys.size() * 4, hipMemcpyHostToDevice, s));
+          hipLaunchKernelGGL(add_ones_k, dim3(1), dim3(1), 0, s, d_f4, d_k, (uint32_t)keys.size());
+          SH_HIP(hipStreamSynchronize(s));
+        }
+        SH_CM(comm, scalce_comm_all_reduce_sum_u64(comm, reinterpret_cast<uint64_t *>(d_f4), 512000, s));
+        const u64 symbols = total_reads * (u64)L[m];
+        SH_RC(ctx, scalce_ac_scale(ctx, reinterpret_cast<const uint64_t *>(d_f4), (uint32_t)(1 + symbols / 0xFFFFFFFFull), d_table + 512000 * (size_t)m, s));  // compress.cpp:297-303
+      }
+    }
+    // ---- 5. tie-break across ranks: rounds of (all-gather counts -> prior, a few local sweeps) until nobody moves
+    {
+      SH_RC(ctx, scalce_batch_tokenize_begin(b, s));
+      const uint32_t stride = nb1 + 1;
+      u64 *d_mine = mem.alloc<u64>(stride), *d_all = mem.alloc<u64>((size_t)W * stride), *d_prior = mem.alloc<u64>(nb1);
+      u64 moved = 1;
+      std::vector<u64> flags(W);
+      for (uint32_t round = 0;; round++) {
+        SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dp, &nb));
+        SH_HIP(hipMemcpyAsync(d_mine, dp, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, s));
+        SH_HIP(hipMemcpyAsync(d_mine + nb1, &moved, 8, hipMemcpyHostToDevice, s));
+        SH_HIP(hipStreamSynchronize(s));  // `moved` is a stack variable
+        SH_CM(comm, scalce_comm_all_gather(comm, d_mine, d_all, (size_t)stride * 8, s));
+        for (int r = 0; r < W; r++) SH_HIP(hipMemcpyAsync(&flags[r], d_all + (size_t)r * stride + nb1, 8, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(prior_from_gathered_k, dim3((nb1 + 255) / 256), dim3(256), 0, s, nb1, d_all, stride, rank, d_prior);
+        SH_HIP(hipStreamSynchronize(s));
+        res->rounds = round + 1;
+        bool any = false;
+        for (int r = 0; r < W; r++) any = any || flags[r] != 0;
+        if (round > 0 && !any) break;  // a whole round with current priors on every rank and no decision moved
+        moved = 0;
+        for (int k = 0; k < 4; k++) {
+          int ch = 0;
+          SH_RC(ctx, scalce_batch_tokenize_sweep(b, reinterpret_cast<const uint64_t *>(d_prior), &ch, s));
+          res->sweeps++;
+          if (ch) moved = 1; else break;
+        }
+        if (res->rounds > total_reads + 8) throw Fail{"tie resolution did not converge", SCALCE_ERR_HIP};
+      }
+      SH_RC(ctx, scalce_batch_tokenize_end(b, s));
+    }
+    // ---- 6. order (the run's cuts inside this rank's rows are its chunks) and emit
+    {
+      std::vector<uint64_t> starts(1, 0);
+      for (u64 c : cuts_global)
+        if (c > gn[rank] && c < gn[rank + 1]) starts.push_back(c - gn[rank]);
+      SH_RC(ctx, scalce_batch_set_chunks(b, starts.data(), (uint32_t)starts.size()));
+      SH_RC(ctx, scalce_batch_order(b, s));
+      SH_RC(ctx, scalce_batch_emit(b, s));
+      SH_RC(ctx, scalce_batch_set_chunks(b, nullptr, 0));
+    }
+    // ---- 7. who holds how much of every bucket
+    res->counts = static_cast<uint64_t *>(calloc((size_t)W * nb1, 8));
+    res->name_bytes = static_cast<uint64_t *>(calloc((size_t)W * nb1, 8));
+    {
+      u64 *d_all = mem.alloc<u64>((size_t)W * nb1);
+      SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dp, &nb));
+      SH_CM(comm, scalce_comm_all_gather(comm, dp, d_all, (size_t)nb1 * 8, s));
+      SH_HIP(hipMemcpyAsync(res->counts, d_all, (size_t)W * nb1 * 8, hipMemcpyDeviceToHost, s));
+      SH_HIP(hipStreamSynchronize(s));
+      SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_NAME_BYTES, 0, &dp, &nb));
+      if (nb) {
+        SH_CM(comm, scalce_comm_all_gather(comm, dp, d_all, (size_t)nb1 * 8, s));
+        SH_HIP(hipMemcpyAsync(res->name_bytes, d_all, (size_t)W * nb1 * 8, hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+      }
+    }
+    // ---- 8. the run-wide reordered quality stream in contiguous block ranges, one range per rank; code it
+    int keep_n = 0;
+    if (d_table && L[0]) {
+      const uint64_t *C = res->counts;
+      std::vector<u64> Cg(nb1, 0);
+      for (int r = 0; r < W; r++)
+        for (uint32_t k = 0; k < nb1; k++) Cg[k] += C[(size_t)r * nb1 + k];
+      for (int m = 0; m < nm; m++) {
+        const u64 Lm = (u64)L[m], total = total_reads * Lm;
+        const u64 nblk = (total + AC_BLOCK - 1) / AC_BLOCK;
+        auto lo_of = [&](int d) { return std::min<u64>(total, ((u64)d * nblk / W) * AC_BLOCK); };
+        // run-wide start of every (rank, bucket) piece: buckets in emission order, ranks in order inside a bucket
+        std::vector<u64> g0((size_t)W * nb1);
+        {
+          u64 base = 0;
+          for (uint32_t k = 0; k < nb1; k++) {
+            u64 at = base;
+            for (int r = 0; r < W; r++) { g0[(size_t)r * nb1 + k] = at; at += C[(size_t)r * nb1 + k] * Lm; }
+            base += Cg[k] * Lm;
+          }
+        }
+        auto below = [&](int r, u64 X) {  // bytes of rank r's local stream that lie in front of run-wide offset X
+          u64 sum = 0;
+          for (uint32_t k = 0; k < nb1; k++) {
+            const u64 a = g0[(size_t)r * nb1 + k], len = C[(size_t)r * nb1 + k] * Lm;
+            sum += X <= a ? 0 : (X - a < len ? X - a : len);
+          }
+          return sum;
+        };
+        const u64 lo = lo_of(rank), hi = lo_of(rank + 1);
+        std::vector<uint64_t> sendb(W), recvb(W);
+        for (int d = 0; d < W; d++) sendb[d] = below(rank, lo_of(d + 1)) - below(rank, lo_of(d));
+        for (int src = 0; src < W; src++) recvb[src] = below(src, hi) - below(src, lo);
+        // where the received pieces go: source-major, bucket order = contiguous in the receive buffer
+        std::vector<uint64_t> psrc, pdst;
+        u64 at = 0;
+        for (int src = 0; src < W; src++)
+          for (uint32_t k = 0; k < nb1; k++) {
+            const u64 a0 = g0[(size_t)src * nb1 + k], a1 = a0 + C[(size_t)src * nb1 + k] * Lm;
+            const u64 x = std::max(a0, lo), y = std::min(a1, hi);
+            if (y > x) { psrc.push_back(at); pdst.push_back(x - lo); at += y - x; }
+          }
+        u64 recv_total = 0;
+        for (int r = 0; r < W; r++) recv_total += recvb[r];
+        if (at != recv_total) throw Fail{"internal: block-range plan is inconsistent", SCALCE_ERR_ARG};
+        SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QSTREAM, m, &dp, &nb));
+        if (nb != N * Lm) throw Fail{"internal: reordered stream has an unexpected size", SCALCE_ERR_ARG};
+        uint8_t *d_got = mem.alloc<uint8_t>(recv_total);
+        uint8_t *d_mine = mem.alloc<uint8_t>(hi - lo + 16);
+        SH_CM(comm, scalce_comm_all_to_all_v(comm, dp, sendb.data(), d_got, recvb.data(), s));
+        if (!psrc.empty()) {
+          uint64_t *d_ps = mem.alloc<uint64_t>(psrc.size()), *d_pd = mem.alloc<uint64_t>(psrc.size());
+          SH_HIP(hipMemcpyAsync(d_ps, psrc.data(), psrc.size() * 8, hipMemcpyHostToDevice, s));
+          SH_HIP(hipMemcpyAsync(d_pd, pdst.data(), pdst.size() * 8, hipMemcpyHostToDevice, s));
+          SH_RC(ctx, scalce_copy_pieces(ctx, d_got, d_mine, d_ps, d_pd, (uint32_t)psrc.size(), recv_total, s));
+          SH_HIP(hipStreamSynchronize(s));  // the piece lists are host vectors of this scope
+        }
+        res->sym_lo[m] = lo;
+        res->sym_hi[m] = hi;
+        const uint32_t *tab = d_table + 512000 * (size_t)m;
+        if (flags & SCALCE_SHARD_PREPARE_ONLY) SH_RC(ctx, scalce_batch_entropy_stream_prepare(b, m, tab, d_mine, hi - lo, s));
+        else if (flags & SCALCE_SHARD_CODER_ASYNC) {
+          hipEvent_t ev;
+          SH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          SH_HIP(hipEventRecord(ev, s));
+          SH_HIP(hipStreamWaitEvent((hipStream_t)coder_stream, ev, 0));
+          SH_HIP(hipEventDestroy(ev));
+          SH_RC(ctx, scalce_batch_entropy_stream_begin(b, m, tab, d_mine, hi - lo, coder_stream));
+        } else {
+          SH_RC(ctx, scalce_batch_entropy_stream(b, m, tab, d_mine, hi - lo, s));
+        }
+        res->keep[keep_n++] = mem.release(d_mine);  // the coder may still be reading it
+      }
+      res->keep[keep_n++] = mem.release(d_table);
+      if (!(flags & (SCALCE_SHARD_PREPARE_ONLY | SCALCE_SHARD_CODER_ASYNC))) {
+        SH_RC(ctx, scalce_batch_finish(b, s));
+        u64 mine[2] = {0, 0};
+        for (int m = 0; m < nm; m++) { SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QUAL, m, &dp, &nb)); mine[m] = nb; }
+        std::vector<u64> all = gather_host<u64>(comm, mine, 2, d_small, d_gather, s);
+        for (int r = 0; r < W; r++)
+          for (int m = 0; m < 2; m++) res->coded_bytes[m][r] = all[2 * r + m];
+      }
+    }
+    SH_HIP(hipStreamSynchronize(s));
+    return SCALCE_OK;
+  } catch (const Fail &f) {
+    last_error = f.msg;
+    fprintf(stderr, "scalce_sharded_compress (rank %d of %d): %s\n", rank, W, f.msg.c_str());
+    scalce_shard_result_free(res);
+    return f.rc ? f.rc : SCALCE_ERR_HIP;
+  }
+}

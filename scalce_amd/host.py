@@ -36,6 +36,17 @@ class Params(C.Structure):
                 ("qmap", QMap * 2), ("bucket_set_size", C.c_uint64), ("qprev", (C.c_uint32 * 2) * 2)]
 
 
+class ShardResult(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("nb1", C.c_uint32), ("rounds", C.c_uint32), ("sweeps", C.c_uint32),
+                ("chunks_total", C.c_uint32), ("reads_total", C.c_uint64), ("first_read", C.c_uint64), ("reads_local", C.c_uint64),
+                ("moved_in", C.c_uint64 * 2), ("counts", C.POINTER(C.c_uint64)), ("name_bytes", C.POINTER(C.c_uint64)),
+                ("sym_lo", C.c_uint64 * 2), ("sym_hi", C.c_uint64 * 2), ("coded_bytes", (C.c_uint64 * 64) * 2),
+                ("keep", C.c_void_p * 8)]
+
+
+SHARD_PREPARE_ONLY, SHARD_CODER_ASYNC = 1, 2
+
+
 def lib():
     """Load the HIP library; fail loudly when it has not been built (no fallback exists)."""
     global _LIB
@@ -107,6 +118,21 @@ def lib():
     L.scalce_batch_set_chunks.argtypes = [vp, C.POINTER(u64), C.c_uint32]
     L.scalce_batch_entropy_stream.argtypes = [vp, i32, vp, vp, u64, vp]
     L.scalce_ac_scale.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    L.scalce_batch_chunk_plan.argtypes = [vp, u64, C.POINTER(u64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), vp]
+    L.scalce_batch_text_offset.argtypes = [vp, i32, u64, C.POINTER(u64)]
+    L.scalce_comm_unique_id.argtypes = [C.c_char_p]
+    L.scalce_comm_create_rccl.argtypes = [i32, i32, i32, C.c_char_p, C.POINTER(vp)]
+    L.scalce_comm_create_shm.argtypes = [i32, i32, i32, C.c_char_p, u64, C.POINTER(vp)]
+    L.scalce_comm_destroy.argtypes = [vp]
+    L.scalce_comm_error.argtypes = [vp]
+    L.scalce_comm_error.restype = C.c_char_p
+    L.scalce_comm_barrier.argtypes = [vp, vp]
+    L.scalce_comm_all_gather.argtypes = [vp, vp, vp, u64, vp]
+    L.scalce_comm_all_reduce_sum_u64.argtypes = [vp, vp, u64, vp]
+    L.scalce_comm_all_to_all_v.argtypes = [vp, vp, C.POINTER(u64), vp, C.POINTER(u64), vp]
+    L.scalce_sharded_compress.argtypes = [vp, vp, vp, vp, u64, vp, u64, i32, vp, vp, C.POINTER(ShardResult)]
+    L.scalce_shard_result_free.argtypes = [C.POINTER(ShardResult)]
+    L.scalce_shard_result_free.restype = None
     L.scalce_copy_pieces.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, u64, vp]
     L.scalce_patterns_describe_host.argtypes = [C.c_char_p, C.c_size_t, i32, vp, C.c_size_t, C.POINTER(C.c_int32),
                                                 C.POINTER(C.c_int32)]
@@ -222,6 +248,61 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """Collectives of a sharded run (scalce_comm): RCCL between processes with one GPU each, or the shared-memory
+    rehearsal transport between processes that share a GPU."""
+
+    def __init__(self, device, world, rank, unique_id=None, shm_name=None, slot_bytes=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.world, self.rank = world, rank
+        if shm_name is not None:
+            rc = self.L.scalce_comm_create_shm(device, world, rank, shm_name.encode(), int(slot_bytes), C.byref(self.h))
+        else:
+            rc = self.L.scalce_comm_create_rccl(device, world, rank, unique_id, C.byref(self.h))
+        if rc:
+            raise ScalceError(f"[{rc}] " + (self.L.scalce_comm_error(self.h) or b"").decode())
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        if lib().scalce_comm_unique_id(buf):
+            raise ScalceError("RCCL is not available (ncclGetUniqueId)")
+        return buf.raw
+
+    def _check(self, rc):
+        if rc:
+            raise ScalceError(f"[{rc}] " + self.L.scalce_comm_error(self.h).decode())
+
+    def barrier(self, stream=0):
+        self._check(self.L.scalce_comm_barrier(self.h, stream))
+
+    def all_gather(self, d_send, d_recv, nbytes, stream=0):
+        self._check(self.L.scalce_comm_all_gather(self.h, d_send, d_recv, int(nbytes), stream))
+
+    def all_reduce_sum_u64(self, d_buf, count, stream=0):
+        self._check(self.L.scalce_comm_all_reduce_sum_u64(self.h, d_buf, int(count), stream))
+
+    def close(self):
+        if self.h:
+            self.L.scalce_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def sharded_compress(comm, ctx, batch, d_text1, n1, d_text2=None, n2=0, flags=0, stream=0, coder_stream=0):
+    """SPMD body of a sharded run (scalce_sharded_compress); returns the ShardResult (free it with shard_result_free)."""
+    res = ShardResult()
+    rc = ctx.L.scalce_sharded_compress(comm.h, ctx.h, batch.h, d_text1, int(n1), d_text2, int(n2), int(flags), stream, coder_stream,
+                                       C.byref(res))
+    if rc:
+        raise ScalceError(f"[{rc}] sharded run failed on rank {comm.rank} (message on stderr)")
+    return res
+
+
+def shard_result_free(res):
+    lib().scalce_shard_result_free(C.byref(res))
 
 
 def entropy_begin_group(batches, prep_stream=0, stream=0):
