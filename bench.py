@@ -4,8 +4,10 @@
 A step = one pass of the whole hot path (ingest -> quality statistics -> tokenize with exact tie-break
 -> bucket/reorder -> emit -> arithmetic coder) over one synthetic shard that is already resident in HBM.
 N = 1 runs BASELINE.json configs[1]: 50 M x 100 bp single-end, arithmetic-coded qualities.  N > 1 is weak
-scaling: every rank holds a shard of the same size (one process per GPU, torch.distributed / RCCL) and the
-ranks produce ONE archive (scalce_amd/dist.py: run-wide tie-break, quality model and block cutting).
+scaling: every rank holds a shard of the same size (one process per GPU) and the ranks produce ONE archive --
+scalce_sharded_compress, the C++ host of scalce_amd/csrc/sharded.cpp over RCCL (comm.cpp): run-wide -B chunks,
+tie-break, quality model and 10 MiB block cutting, byte-identical with the one-GPU archive of the same input.
+torch.distributed is only used to hand RCCL's unique id to the ranks and for the timing barrier.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- dominant kernel (ac_encode_k): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
@@ -47,7 +49,6 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from scalce_amd import dist as sdist
     from scalce_amd import host, synth_gpu
     from scalce_amd.pipeline import ShardPipeline
 
@@ -56,8 +57,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL over xGMI on a real node; SCALCE_DIST_BACKEND=gloo rehearses the same code on fewer GPUs
-        dist.init_process_group(os.environ.get("SCALCE_DIST_BACKEND", "nccl"))
+        # torch.distributed is the control plane only (RCCL's unique id, the timing barrier): gloo.  The data path is the
+        # library's own RCCL communicator (scalce_amd/csrc/comm.cpp).
+        dist.init_process_group("gloo")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -78,23 +80,35 @@ def main():
     # buffers.  Measured with the 2-rank rehearsal (tools/mem_probe.sh; 20 M and 28 M reads, 4 and 6 in flight), per rank:
     # 8 GB + 0.4 GB per million reads + 0.73 GB per million reads and shard in flight (x L / 100) = 246 GB at 50 M reads
     # and six in flight.  A rank keeps 3 / 6 when that estimate plus a margin fits what is free now, else 2 / 4 (174 GB).
-    comm = sdist.TorchComm() if world > 1 else None
-
-    def sharded_need_gb(inflight):
-        nm = n / 1e6 * L / 100.0
-        return 8 + 0.4 * nm + 0.76 * nm * inflight  # (+ 33 bytes per read and slot since the rehearsal: (key, read) pairs of the order stage, name cells)
+    # A sharded run goes through scalce_sharded_compress (C++ host, RCCL).  SCALCE_BENCH_FORCE_SHARDED=1 takes that path at
+    # world 1 as well (every collective is then a real RCCL call of one rank); SCALCE_COMM=shm rehearses several ranks on
+    # ONE GPU through the shared-memory transport.
+    sharded = world > 1 or bool(os.environ.get("SCALCE_BENCH_FORCE_SHARDED"))
+    comm = None
+    if sharded:
+        if os.environ.get("SCALCE_COMM") == "shm":
+            name = [("/scalce_bench_%d" % os.getpid()) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(name, src=0)
+            comm = host.Comm(local, world, rank, shm_name=name[0], slot_bytes=int(os.environ.get("SCALCE_SHM_SLOT", str(8 << 30))))
+        else:
+            uid = [host.Comm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            comm = host.Comm(local, world, rank, unique_id=uid[0])
+    # shards per coder launch / shards in flight: 3 / 6 on one GPU (210 GB of the 288 GB HBM at 50 M reads per shard).  A
+    # sharded run also holds every in-flight shard's block range of the run-wide quality stream, and while a shard is being
+    # worked on the text it received from its neighbours and the all-to-all buffers (about 25 GB at 50 M reads): 2 / 4.
     G = args.group
     if G is None:
-        G = 3
-        if world > 1:
-            free_gb = torch.cuda.mem_get_info()[0] / 1e9 + nbytes / 1e9  # the shard's text is already there
-            fits = sharded_need_gb(6) * 1.06 + 8 <= free_gb
-            G = 3 if comm.all_reduce_max(0 if fits else 1) == 0 else 2  # every rank takes the same decision
+        G = 2 if sharded else 3
     G = max(1, G)
     D = max(1, args.inflight) if args.inflight is not None else 2 * G
     if G > 1:
         D = max(D, 2 * G)
-    batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)]) for _ in range(D)]
+    # -B: the reference's default, 4 GiB of record bytes per spill chunk (main.cpp:68) -- 50 M reads of 100 bp are 3 chunks
+    B = int(os.environ.get("SCALCE_BENCH_BUCKET_SET", str(4 << 30)))
+    batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B) for _ in range(D)]
     batch = batches[0]
     state = {}
 
@@ -113,7 +127,7 @@ def main():
 
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
-    pipe = ShardPipeline(batches, group=G, sharded=world > 1, trace=mark if trace else None)
+    pipe = ShardPipeline(batches, group=G, sharded=sharded, trace=mark if trace else None)
     front = pipe.front
 
     def run(k):
@@ -121,14 +135,15 @@ def main():
             slot, b = pipe.acquire()
             mark(f"shard {j}: front (slot {slot})")
             with torch.cuda.stream(pipe.front):
-                if world == 1:
+                if not sharded:
                     b.front(text.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream)
                 elif G == 1:
-                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=pipe.front.cuda_stream,
-                                                       ent_stream=pipe.coder)
+                    state[slot] = host.sharded_compress(comm, ctx, b, text.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
+                                                        stream=pipe.front.cuda_stream, coder_stream=pipe.coder.cuda_stream,
+                                                        result=state.get(slot))
                 else:
-                    state[slot] = sdist.compress_shard(comm, ctx, b, text.data_ptr(), nbytes, stream=pipe.front.cuda_stream,
-                                                       prepare_only=True)
+                    state[slot] = host.sharded_compress(comm, ctx, b, text.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
+                                                        stream=pipe.front.cuda_stream, result=state.get(slot))
             mark(f"shard {j}: front done")
             pipe.submit(slot, tag=j, flush=j + 1 == k)
         pipe.drain()
@@ -149,7 +164,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     free_b, total_b = torch.cuda.mem_get_info()
@@ -213,7 +228,8 @@ def main():
             "config": {"workload": f"{n} x {L} bp single-end synthetic FASTQ per GPU, arithmetic-coded qualities "
                                    "(BASELINE.json configs[1])", "reads_per_gpu": n, "read_length": L,
                        "input_bytes_per_gpu": nbytes, "output_bytes_per_gpu": int(out_bytes),
-                       "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if world == 1 else ": read ranges per rank, run-wide tie-break / quality model / 10 MiB blocks (RCCL all-gather, all-reduce, all-to-all)"),
+                       "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if not sharded else f": read ranges per rank, ONE archive; run-wide -B chunks / tie-break / quality model / 10 MiB blocks over {comm.world} rank(s) of " + ("shared memory (rehearsal)" if os.environ.get("SCALCE_COMM") == "shm" else "RCCL (all-gather, all-reduce, send/recv)")),
+                       "bucket_set_size": B, "spill_chunks": stats["chunks"],
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
                        "shards_in_flight": D, "shards_per_coder_launch": G, "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,

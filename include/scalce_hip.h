@@ -315,6 +315,8 @@ typedef struct {
   uint64_t sym_lo[2], sym_hi[2];  /* per mate: this rank's range of the run-wide reordered quality stream (whole 10 MiB blocks) */
   uint64_t coded_bytes[2][64];    /* per mate and rank: bytes of framed blocks (0 with SCALCE_SHARD_PREPARE_ONLY) */
   void *keep[8];             /* device buffers the coder still reads (freed by scalce_shard_result_free) */
+  uint64_t keep_bytes[8];
+  uint32_t magic;            /* set by the library: a result handed back in keeps its buffers */
 } scalce_shard_result;
 #define SCALCE_SHARD_PREPARE_ONLY 1  /* hand the rank's block range to the batch (scalce_batch_entropy_stream_prepare): the
                                         caller codes several shards with one scalce_batch_entropy_begin_group */
@@ -323,7 +325,9 @@ typedef struct {
  * HBM.  On return the batch holds this rank's pieces of the archive: SCALCE_OUT_READS / _NAMES = its records per bucket
  * (bucket b of the archive = header, then rank 0's records of b, rank 1's, ...: result->counts / name_bytes say where),
  * SCALCE_OUT_QUAL = the framed blocks of sym_lo .. sym_hi, SCALCE_OUT_TABLE = the run-wide table.  `b` must have been
- * created with bucket_set_size != 0 and default qprev. */
+ * created with bucket_set_size != 0 and default qprev.  `result` must be zeroed before its first use; handing the result
+ * of an earlier call on the same batch back in reuses its device buffers (no allocation, hence no device-wide
+ * synchronisation, in the steady state of a pipeline). */
 int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalce_batch *b, const uint8_t *d_text1, uint64_t n1,
                             const uint8_t *d_text2, uint64_t n2, int flags, void *stream, void *coder_stream,
                             scalce_shard_result *result);

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -68,20 +69,44 @@ struct Fail {
 
 namespace {
 
-struct DevMem {  // freed on scope exit unless released
-  std::vector<void *> ptrs;
-  ~DevMem() { for (void *p : ptrs) if (p) hipFree(p); }
+// Scratch of a call: grow-only device buffers that persist in the process (one rank = one process), handed out in call
+// order -- hipMalloc / hipFree synchronise the whole device, and a sharded call usually runs beside the coder of the
+// previous shards on another stream: an allocation per call made every call wait for that coder.
+struct Arena {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+static std::vector<Arena> g_scratch;
+struct DevMem {
+  size_t next = 0;
   template <typename T> T *alloc(size_t n) {
-    void *p = nullptr;
-    SH_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T) + 64));
-    ptrs.push_back(p);
-    return static_cast<T *>(p);
-  }
-  void *release(void *p) {
-    for (auto &q : ptrs) if (q == p) q = nullptr;
-    return p;
+    const size_t bytes = (n ? n : 1) * sizeof(T) + 64;
+    if (next == g_scratch.size()) g_scratch.emplace_back();
+    Arena &a = g_scratch[next++];
+    if (a.cap < bytes) {
+      if (a.p) hipFree(a.p);
+      a.p = nullptr;
+      a.cap = 0;
+      const size_t want = bytes + bytes / 8;
+      SH_HIP(hipMalloc(&a.p, want));
+      a.cap = want;
+    }
+    return static_cast<T *>(a.p);
   }
 };
+// what the coder still reads when the call has returned lives in the RESULT (reused when the caller passes the result of
+// an earlier call on the same batch slot back in)
+template <typename T> T *keep_alloc(scalce_shard_result *res, int slot, size_t n) {
+  const size_t bytes = (n ? n : 1) * sizeof(T) + 64;
+  if (res->keep[slot] && res->keep_bytes[slot] >= bytes) return static_cast<T *>(res->keep[slot]);
+  if (res->keep[slot]) hipFree(res->keep[slot]);
+  res->keep[slot] = nullptr;
+  res->keep_bytes[slot] = 0;
+  const size_t want = bytes + bytes / 8;
+  SH_HIP(hipMalloc(&res->keep[slot], want));
+  res->keep_bytes[slot] = want;
+  return static_cast<T *>(res->keep[slot]);
+}
 
 template <typename T> std::vector<T> gather_host(scalce_comm *comm, const T *mine, size_t count, T *d_send, T *d_recv, hipStream_t s) {
   const int W = scalce_comm_world(comm);
@@ -96,11 +121,12 @@ template <typename T> std::vector<T> gather_host(scalce_comm *comm, const T *min
 }  // namespace
 
 extern "C" void scalce_shard_result_free(scalce_shard_result *r) {
-  if (!r) return;
+  if (!r || r->magic != 0x5CA1CE5Du) return;
   free(r->counts);
   free(r->name_bytes);
   r->counts = r->name_bytes = nullptr;
-  for (void *&p : r->keep) { if (p) hipFree(p); p = nullptr; }
+  for (int i = 0; i < 8; i++) { if (r->keep[i]) hipFree(r->keep[i]); r->keep[i] = nullptr; r->keep_bytes[i] = 0; }
+  r->magic = 0;
 }
 
 extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalce_batch *b, const uint8_t *d_text1, uint64_t n1,
@@ -110,10 +136,33 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
   hipStream_t s = (hipStream_t)stream;
   const int W = scalce_comm_world(comm), rank = scalce_comm_rank(comm);
   if (W > 64) return SCALCE_ERR_ARG;
-  memset(res, 0, sizeof *res);
+  {  // a result of an earlier call on this slot keeps its buffers; everything else starts from zero
+    scalce_shard_result keep = *res;
+    const bool reuse = res->magic == 0x5CA1CE5Du && res->world == W && res->nb1 == (uint32_t)scalce_patterns_buckets(ctx) + 1;
+    memset(res, 0, sizeof *res);
+    if (reuse) {
+      res->counts = keep.counts;
+      res->name_bytes = keep.name_bytes;
+      memcpy(res->keep, keep.keep, sizeof keep.keep);
+      memcpy(res->keep_bytes, keep.keep_bytes, sizeof keep.keep_bytes);
+    }
+    res->magic = 0x5CA1CE5Du;
+  }
   res->world = W;
   res->rank = rank;
   static std::string last_error;
+  // SCALCE_SHARD_TRACE=1: where a rank's time goes (the stream is drained at every mark: for looking, not for timing runs)
+  const bool trace = getenv("SCALCE_SHARD_TRACE") != nullptr;
+  double t_last = 0;
+  auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+  auto mark = [&](const char *what) {
+    if (!trace) return;
+    hipStreamSynchronize(s);
+    const double t = now();
+    if (t_last > 0) fprintf(stderr, "  [rank %d] %-28s %8.2f ms\n", rank, what, (t - t_last) * 1e3);
+    t_last = t;
+  };
+  mark("start");
   try {
     DevMem mem;
     const uint8_t *text[2] = {d_text1, d_text2};
@@ -125,6 +174,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     SH_RC(ctx, scalce_batch_reset(b));
     SH_RC(ctx, scalce_batch_append(b, text[0], nbytes[0], text[1], nbytes[1], SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_TOKENIZE, used, s));
     const u64 N0 = scalce_batch_reads(b);
+    mark("first pass (ingest+quality)");
     const uint32_t nb1 = (uint32_t)scalce_patterns_buckets(ctx) + 1;
     res->nb1 = nb1;
     const int nm = text[1] ? 2 : 1;
@@ -189,6 +239,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       std::sort(cuts_global.begin(), cuts_global.end());
       res->chunks_total = (uint32_t)cuts_global.size() + ((cuts_global.empty() || cuts_global.back() < total_reads) ? 1 : 0);
     }
+    mark("record sizes + cuts");
     // ---- 3. rank boundaries move to the nearest cut; the records in between change owner as text
     std::vector<u64> gn = g;
     for (int r = 1; r < W; r++) {
@@ -250,6 +301,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
                                      SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_QUALITY | SCALCE_APPEND_NO_TOKENIZE, used, s));
       if (scalce_batch_reads(b) != res->reads_local) throw Fail{"internal: row count after the exchange differs from the plan", SCALCE_ERR_ARG};
     }
+    mark("exchange + re-ingest");
     const u64 N = scalce_batch_reads(b);
     // ---- 4. run-wide quality model: trigrams across the ORIGINAL piece boundaries, all-reduce, scaling
     uint32_t *d_table = nullptr;
@@ -258,7 +310,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       memcpy(ed.data(), edge, 8);
       uint8_t *d_e = reinterpret_cast<uint8_t *>(d_small);
       std::vector<uint8_t> edges = gather_host<uint8_t>(comm, ed.data(), 8, d_e, reinterpret_cast<uint8_t *>(d_gather), s);
-      d_table = mem.alloc<uint32_t>(2 * 512000);
+      d_table = keep_alloc<uint32_t>(res, 2, 2 * 512000);
       for (int m = 0; m < nm; m++) {
         SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_FREQ4, m, &dp, &nb));
         u64 *d_f4 = static_cast<u64 *>(const_cast<void *>(dp));
@@ -290,6 +342,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         SH_RC(ctx, scalce_ac_scale(ctx, reinterpret_cast<const uint64_t *>(d_f4), (uint32_t)(1 + symbols / 0xFFFFFFFFull), d_table + 512000 * (size_t)m, s));  // compress.cpp:297-303
       }
     }
+    mark("quality model");
     // ---- 5. tie-break across ranks: rounds of (all-gather counts -> prior, a few local sweeps) until nobody moves
     {
       SH_RC(ctx, scalce_batch_tokenize_begin(b, s));
@@ -321,6 +374,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       }
       SH_RC(ctx, scalce_batch_tokenize_end(b, s));
     }
+    mark("tie-break");
     // ---- 6. order (the run's cuts inside this rank's rows are its chunks) and emit
     {
       std::vector<uint64_t> starts(1, 0);
@@ -331,9 +385,11 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       SH_RC(ctx, scalce_batch_emit(b, s));
       SH_RC(ctx, scalce_batch_set_chunks(b, nullptr, 0));
     }
+    mark("order + emit");
     // ---- 7. who holds how much of every bucket
-    res->counts = static_cast<uint64_t *>(calloc((size_t)W * nb1, 8));
-    res->name_bytes = static_cast<uint64_t *>(calloc((size_t)W * nb1, 8));
+    if (!res->counts) res->counts = static_cast<uint64_t *>(calloc((size_t)W * nb1, 8));
+    if (!res->name_bytes) res->name_bytes = static_cast<uint64_t *>(calloc((size_t)W * nb1, 8));
+    memset(res->name_bytes, 0, (size_t)W * nb1 * 8);
     {
       u64 *d_all = mem.alloc<u64>((size_t)W * nb1);
       SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dp, &nb));
@@ -347,8 +403,8 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         SH_HIP(hipStreamSynchronize(s));
       }
     }
+    mark("bucket layout");
     // ---- 8. the run-wide reordered quality stream in contiguous block ranges, one range per rank; code it
-    int keep_n = 0;
     if (d_table && L[0]) {
       const uint64_t *C = res->counts;
       std::vector<u64> Cg(nb1, 0);
@@ -395,7 +451,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QSTREAM, m, &dp, &nb));
         if (nb != N * Lm) throw Fail{"internal: reordered stream has an unexpected size", SCALCE_ERR_ARG};
         uint8_t *d_got = mem.alloc<uint8_t>(recv_total);
-        uint8_t *d_mine = mem.alloc<uint8_t>(hi - lo + 16);
+        uint8_t *d_mine = keep_alloc<uint8_t>(res, m, hi - lo + 16);
         SH_CM(comm, scalce_comm_all_to_all_v(comm, dp, sendb.data(), d_got, recvb.data(), s));
         if (!psrc.empty()) {
           uint64_t *d_ps = mem.alloc<uint64_t>(psrc.size()), *d_pd = mem.alloc<uint64_t>(psrc.size());
@@ -418,9 +474,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         } else {
           SH_RC(ctx, scalce_batch_entropy_stream(b, m, tab, d_mine, hi - lo, s));
         }
-        res->keep[keep_n++] = mem.release(d_mine);  // the coder may still be reading it
       }
-      res->keep[keep_n++] = mem.release(d_table);
       if (!(flags & (SCALCE_SHARD_PREPARE_ONLY | SCALCE_SHARD_CODER_ASYNC))) {
         SH_RC(ctx, scalce_batch_finish(b, s));
         u64 mine[2] = {0, 0};
@@ -430,6 +484,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
           for (int m = 0; m < 2; m++) res->coded_bytes[m][r] = all[2 * r + m];
       }
     }
+    mark("block ranges + coder");
     SH_HIP(hipStreamSynchronize(s));
     return SCALCE_OK;
   } catch (const Fail &f) {

@@ -41,7 +41,7 @@ class ShardResult(C.Structure):
                 ("chunks_total", C.c_uint32), ("reads_total", C.c_uint64), ("first_read", C.c_uint64), ("reads_local", C.c_uint64),
                 ("moved_in", C.c_uint64 * 2), ("counts", C.POINTER(C.c_uint64)), ("name_bytes", C.POINTER(C.c_uint64)),
                 ("sym_lo", C.c_uint64 * 2), ("sym_hi", C.c_uint64 * 2), ("coded_bytes", (C.c_uint64 * 64) * 2),
-                ("keep", C.c_void_p * 8)]
+                ("keep", C.c_void_p * 8), ("keep_bytes", C.c_uint64 * 8), ("magic", C.c_uint32)]
 
 
 SHARD_PREPARE_ONLY, SHARD_CODER_ASYNC = 1, 2
@@ -291,9 +291,10 @@ class Comm:
             self.h = C.c_void_p()
 
 
-def sharded_compress(comm, ctx, batch, d_text1, n1, d_text2=None, n2=0, flags=0, stream=0, coder_stream=0):
-    """SPMD body of a sharded run (scalce_sharded_compress); returns the ShardResult (free it with shard_result_free)."""
-    res = ShardResult()
+def sharded_compress(comm, ctx, batch, d_text1, n1, d_text2=None, n2=0, flags=0, stream=0, coder_stream=0, result=None):
+    """SPMD body of a sharded run (scalce_sharded_compress); returns the ShardResult (free it with shard_result_free).
+    `result`: the result of an earlier call on the same batch -- its device buffers are reused."""
+    res = result if result is not None else ShardResult()
     rc = ctx.L.scalce_sharded_compress(comm.h, ctx.h, batch.h, d_text1, int(n1), d_text2, int(n2), int(flags), stream, coder_stream,
                                        C.byref(res))
     if rc:
