@@ -332,6 +332,13 @@ int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalce_batch *b,
                             const uint8_t *d_text2, uint64_t n2, int flags, void *stream, void *coder_stream,
                             scalce_shard_result *result);
 void scalce_shard_result_free(scalce_shard_result *r);
+/* The host-side plan math of a sharded run on its own (no device needed; see sharded.cpp): rank boundaries g[0..world]
+ * moved to the nearest cut of the run-wide -B rule, and the deal of the run-wide reordered quality stream in contiguous
+ * ranges of whole 10 MiB blocks. */
+int scalce_shard_plan_boundaries(int world, const uint64_t *g, const uint64_t *cuts_sorted, uint64_t ncuts, uint64_t *gn);
+int scalce_shard_plan_blocks(int world, int rank, uint32_t nb1, const uint64_t *counts /*[world][nb1]*/, uint64_t read_len,
+                             uint64_t *send_bytes, uint64_t *recv_bytes, uint64_t *lo, uint64_t *hi, uint64_t *piece_src,
+                             uint64_t *piece_dst, uint64_t *npieces);
 
 #ifdef __cplusplus
 }

@@ -100,11 +100,20 @@ struct scalce_comm {
     hipError_t e_ = (expr);                                                                               \
     if (e_ != hipSuccess) { (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return SCALCE_ERR_HIP; } \
   } while (0)
+// the rehearsal transport also runs without any GPU (device < 0: the "device" buffers are host memory) -- CPU tests of the
+// collectives' semantics across processes
+static hipError_t cm_copy(const scalce_comm *c, void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s);
 #define CM_NCCL(c, expr)                                                                                               \
   do {                                                                                                                 \
     int r_ = (expr);                                                                                                   \
     if (r_ != ncclSuccess) { (c)->err = std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); return SCALCE_ERR_HIP; } \
   } while (0)
+
+static hipError_t cm_copy(const scalce_comm *c, void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+  if (c->device < 0) { memcpy(dst, src, n); return hipSuccess; }
+  return hipMemcpyAsync(dst, src, n, kind, s);
+}
+static hipError_t cm_sync(const scalce_comm *c, hipStream_t s) { return c->device < 0 ? hipSuccess : hipStreamSynchronize(s); }
 
 extern "C" const char *scalce_comm_error(const scalce_comm *c) { return c ? c->err.c_str() : "null communicator"; }
 extern "C" int scalce_comm_world(const scalce_comm *c) { return c ? c->world : 1; }
@@ -204,7 +213,7 @@ extern "C" int scalce_comm_all_gather(scalce_comm *c, const void *d_send, void *
   hipStream_t s = (hipStream_t)stream;
   if (!bytes) return SCALCE_OK;
   if (c->world == 1 && !c->nccl) {
-    if (d_send != d_recv) CM_HIP(c, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s));
+    if (d_send != d_recv) CM_HIP(c, cm_copy(c, d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s));
     return SCALCE_OK;
   }
   if (!c->shm) {
@@ -212,12 +221,12 @@ extern "C" int scalce_comm_all_gather(scalce_comm *c, const void *d_send, void *
     return SCALCE_OK;
   }
   if (bytes > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
-  CM_HIP(c, hipMemcpyAsync(c->slots + (size_t)c->rank * c->slot_bytes, d_send, bytes, hipMemcpyDeviceToHost, s));
-  CM_HIP(c, hipStreamSynchronize(s));
+  CM_HIP(c, cm_copy(c, c->slots + (size_t)c->rank * c->slot_bytes, d_send, bytes, hipMemcpyDeviceToHost, s));
+  CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);
   for (int r = 0; r < c->world; r++)
-    CM_HIP(c, hipMemcpyAsync(static_cast<uint8_t *>(d_recv) + (size_t)r * bytes, c->slots + (size_t)r * c->slot_bytes, bytes, hipMemcpyHostToDevice, s));
-  CM_HIP(c, hipStreamSynchronize(s));
+    CM_HIP(c, cm_copy(c, static_cast<uint8_t *>(d_recv) + (size_t)r * bytes, c->slots + (size_t)r * c->slot_bytes, bytes, hipMemcpyHostToDevice, s));
+  CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);
   return SCALCE_OK;
 }
@@ -233,8 +242,8 @@ extern "C" int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, u
   const uint64_t bytes = count * 8;
   if (bytes > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
   uint64_t *mine = reinterpret_cast<uint64_t *>(c->slots + (size_t)c->rank * c->slot_bytes);
-  CM_HIP(c, hipMemcpyAsync(mine, d_buf, bytes, hipMemcpyDeviceToHost, s));
-  CM_HIP(c, hipStreamSynchronize(s));
+  CM_HIP(c, cm_copy(c, mine, d_buf, bytes, hipMemcpyDeviceToHost, s));
+  CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);
   c->stage.resize(bytes);
   uint64_t *acc = reinterpret_cast<uint64_t *>(c->stage.data());
@@ -244,8 +253,8 @@ extern "C" int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, u
     for (uint64_t i = 0; i < count; i++) acc[i] += x[i];
   }
   pthread_barrier_wait(&c->hdr->barrier);
-  CM_HIP(c, hipMemcpyAsync(d_buf, acc, bytes, hipMemcpyHostToDevice, s));
-  CM_HIP(c, hipStreamSynchronize(s));
+  CM_HIP(c, cm_copy(c, d_buf, acc, bytes, hipMemcpyHostToDevice, s));
+  CM_HIP(c, cm_sync(c, s));
   return SCALCE_OK;
 }
 
@@ -259,7 +268,7 @@ extern "C" int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, cons
   uint8_t *dst = static_cast<uint8_t *>(d_recv);
   if (c->world == 1 && !c->nccl) {
     if (send_bytes[0] != recv_bytes[0]) { c->err = "all_to_all_v: sizes disagree"; return SCALCE_ERR_ARG; }
-    if (send_bytes[0]) CM_HIP(c, hipMemcpyAsync(dst, src, send_bytes[0], hipMemcpyDeviceToDevice, s));
+    if (send_bytes[0]) CM_HIP(c, cm_copy(c, dst, src, send_bytes[0], hipMemcpyDeviceToDevice, s));
     return SCALCE_OK;
   }
   if (!c->shm) {
@@ -278,19 +287,19 @@ extern "C" int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, cons
   uint64_t total = 0;
   for (int r = 0; r < c->world; r++) total += send_bytes[r];
   if (total > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
-  if (total) CM_HIP(c, hipMemcpyAsync(c->slots + (size_t)c->rank * c->slot_bytes, src, total, hipMemcpyDeviceToHost, s));
+  if (total) CM_HIP(c, cm_copy(c, c->slots + (size_t)c->rank * c->slot_bytes, src, total, hipMemcpyDeviceToHost, s));
   for (int r = 0; r < c->world; r++) c->hdr->sizes[c->rank][r] = send_bytes[r];
-  CM_HIP(c, hipStreamSynchronize(s));
+  CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);
   uint64_t ro = 0;
   for (int r = 0; r < c->world; r++) {
     if (c->hdr->sizes[r][c->rank] != recv_bytes[r]) { c->err = "all_to_all_v: a sender's size differs from what the receiver expects"; pthread_barrier_wait(&c->hdr->barrier); return SCALCE_ERR_ARG; }
     uint64_t off = 0;
     for (int d = 0; d < c->rank; d++) off += c->hdr->sizes[r][d];
-    if (recv_bytes[r]) CM_HIP(c, hipMemcpyAsync(dst + ro, c->slots + (size_t)r * c->slot_bytes + off, recv_bytes[r], hipMemcpyHostToDevice, s));
+    if (recv_bytes[r]) CM_HIP(c, cm_copy(c, dst + ro, c->slots + (size_t)r * c->slot_bytes + off, recv_bytes[r], hipMemcpyHostToDevice, s));
     ro += recv_bytes[r];
   }
-  CM_HIP(c, hipStreamSynchronize(s));
+  CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);
   return SCALCE_OK;
 }

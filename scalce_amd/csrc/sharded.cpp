@@ -28,7 +28,7 @@
 
 namespace {
 
-typedef unsigned long long u64;
+typedef uint64_t u64;
 constexpr u64 AC_BLOCK = 10ull * 1024 * 1024;
 
 // prior[b] = reads of bucket b held by the ranks before `rank`; gathered = [world][stride] u64
@@ -119,6 +119,80 @@ template <typename T> std::vector<T> gather_host(scalce_comm *comm, const T *min
 }
 
 }  // namespace
+
+// Host-only plan math, exported so that it can be checked without a GPU -------------------------------------------------
+// Rank boundaries g[0..world] (run-wide row of every rank's first record, g[world] = rows of the run) move to the nearest
+// cut of the run-wide -B rule; gn[] = the moved boundaries.  Returns SCALCE_ERR_CAPACITY when the run has no cut to move to
+// or a chunk spans more than two neighbouring ranks.
+extern "C" int scalce_shard_plan_boundaries(int world, const uint64_t *g, const uint64_t *cuts_sorted, uint64_t ncuts, uint64_t *gn) {
+  if (world < 1 || !g || !gn || (ncuts && !cuts_sorted)) return SCALCE_ERR_ARG;
+  for (int r = 0; r <= world; r++) gn[r] = g[r];
+  for (int r = 1; r < world; r++) {
+    if (!ncuts) return SCALCE_ERR_CAPACITY;
+    const uint64_t *end = cuts_sorted + ncuts, *it = std::lower_bound(cuts_sorted, end, g[r]);
+    uint64_t best = it == end ? cuts_sorted[ncuts - 1] : *it;
+    if (it != cuts_sorted) { const uint64_t lo = *(it - 1); if (best < g[r] || g[r] - lo <= best - g[r]) best = lo; }
+    gn[r] = best;
+  }
+  for (int r = 1; r < world; r++) {
+    if (gn[r] < gn[r - 1]) gn[r] = gn[r - 1];
+    if (gn[r] < g[r - 1] || gn[r] > g[r + 1]) return SCALCE_ERR_CAPACITY;
+  }
+  return SCALCE_OK;
+}
+// The run-wide reordered quality stream of one mate (buckets in emission order, ranks in order inside a bucket; C[r][k] reads
+// of L symbols) dealt out in contiguous ranges of whole 10 MiB blocks, range d to rank d: what `rank` sends to / receives from
+// everyone (bytes), its own range [lo, hi), and the pieces of what it receives (source-major, bucket order: contiguous in
+// the receive buffer; piece_dst relative to lo).  Piece arrays hold up to world * nb1 entries.
+extern "C" int scalce_shard_plan_blocks(int world, int rank, uint32_t nb1, const uint64_t *C, uint64_t L, uint64_t *send_bytes,
+                                        uint64_t *recv_bytes, uint64_t *lo_out, uint64_t *hi_out, uint64_t *piece_src, uint64_t *piece_dst,
+                                        uint64_t *npieces) {
+  if (world < 1 || rank < 0 || rank >= world || !C || !send_bytes || !recv_bytes || !lo_out || !hi_out) return SCALCE_ERR_ARG;
+  std::vector<u64> Cg(nb1, 0);
+  u64 total_reads = 0;
+  for (int r = 0; r < world; r++)
+    for (uint32_t k = 0; k < nb1; k++) { Cg[k] += C[(size_t)r * nb1 + k]; total_reads += C[(size_t)r * nb1 + k]; }
+  const u64 total = total_reads * L, nblk = (total + AC_BLOCK - 1) / AC_BLOCK;
+  auto lo_of = [&](int d) { return std::min<u64>(total, ((u64)d * nblk / world) * AC_BLOCK); };
+  std::vector<u64> g0((size_t)world * nb1);  // run-wide start of every (rank, bucket) piece
+  {
+    u64 base = 0;
+    for (uint32_t k = 0; k < nb1; k++) {
+      u64 at = base;
+      for (int r = 0; r < world; r++) { g0[(size_t)r * nb1 + k] = at; at += C[(size_t)r * nb1 + k] * L; }
+      base += Cg[k] * L;
+    }
+  }
+  auto below = [&](int r, u64 X) {  // bytes of rank r's local stream that lie in front of run-wide offset X
+    u64 sum = 0;
+    for (uint32_t k = 0; k < nb1; k++) {
+      const u64 a = g0[(size_t)r * nb1 + k], len = C[(size_t)r * nb1 + k] * L;
+      sum += X <= a ? 0 : (X - a < len ? X - a : len);
+    }
+    return sum;
+  };
+  const u64 lo = lo_of(rank), hi = lo_of(rank + 1);
+  for (int d = 0; d < world; d++) send_bytes[d] = below(rank, lo_of(d + 1)) - below(rank, lo_of(d));
+  for (int src = 0; src < world; src++) recv_bytes[src] = below(src, hi) - below(src, lo);
+  u64 at = 0, np = 0;
+  for (int src = 0; src < world; src++)
+    for (uint32_t k = 0; k < nb1; k++) {
+      const u64 a0 = g0[(size_t)src * nb1 + k], a1 = a0 + C[(size_t)src * nb1 + k] * L;
+      const u64 x = std::max(a0, lo), y = std::min(a1, hi);
+      if (y > x) {
+        if (piece_src) { piece_src[np] = at; piece_dst[np] = x - lo; }
+        np++;
+        at += y - x;
+      }
+    }
+  u64 recv_total = 0;
+  for (int r = 0; r < world; r++) recv_total += recv_bytes[r];
+  if (at != recv_total) return SCALCE_ERR_ARG;
+  *lo_out = lo;
+  *hi_out = hi;
+  if (npieces) *npieces = np;
+  return SCALCE_OK;
+}
 
 extern "C" void scalce_shard_result_free(scalce_shard_result *r) {
   if (!r || r->magic != 0x5CA1CE5Du) return;
@@ -241,19 +315,13 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     }
     mark("record sizes + cuts");
     // ---- 3. rank boundaries move to the nearest cut; the records in between change owner as text
-    std::vector<u64> gn = g;
-    for (int r = 1; r < W; r++) {
-      if (cuts_global.empty()) throw Fail{"(ERROR) a sharded run needs -B below a rank's share of the input: no spill chunk ends inside the run, "
-                                          "so the records of a bucket would have to be merged across ranks", SCALCE_ERR_CAPACITY};
-      auto it = std::lower_bound(cuts_global.begin(), cuts_global.end(), g[r]);
-      u64 best = it == cuts_global.end() ? cuts_global.back() : *it;
-      if (it != cuts_global.begin()) { const u64 lo = *(it - 1); if (g[r] - lo <= best - g[r] || best < g[r]) best = lo; }
-      gn[r] = best;
-    }
-    for (int r = 1; r < W; r++) {
-      if (gn[r] < gn[r - 1]) gn[r] = gn[r - 1];
-      if (gn[r] < g[r - 1] || gn[r] > g[r + 1])
-        throw Fail{"(ERROR) a spill chunk spans more than two neighbouring ranks: use a smaller -B or fewer GPUs", SCALCE_ERR_CAPACITY};
+    std::vector<u64> gn(W + 1);
+    {
+      const int prc = scalce_shard_plan_boundaries(W, g.data(), cuts_global.data(), cuts_global.size(), gn.data());
+      if (prc) throw Fail{cuts_global.empty() && W > 1
+                              ? "(ERROR) a sharded run needs -B below a rank's share of the input: no spill chunk ends inside the run, so the "
+                                "records of a bucket would have to be merged across ranks"
+                              : "(ERROR) a spill chunk spans more than two neighbouring ranks: use a smaller -B or fewer GPUs", prc};
     }
     const u64 head_out = gn[rank] > g[rank] ? gn[rank] - g[rank] : 0;               // rows that leave for rank - 1
     const u64 tail_out = gn[rank + 1] < g[rank + 1] ? g[rank + 1] - gn[rank + 1] : 0;  // ... for rank + 1
@@ -407,47 +475,16 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     // ---- 8. the run-wide reordered quality stream in contiguous block ranges, one range per rank; code it
     if (d_table && L[0]) {
       const uint64_t *C = res->counts;
-      std::vector<u64> Cg(nb1, 0);
-      for (int r = 0; r < W; r++)
-        for (uint32_t k = 0; k < nb1; k++) Cg[k] += C[(size_t)r * nb1 + k];
       for (int m = 0; m < nm; m++) {
-        const u64 Lm = (u64)L[m], total = total_reads * Lm;
-        const u64 nblk = (total + AC_BLOCK - 1) / AC_BLOCK;
-        auto lo_of = [&](int d) { return std::min<u64>(total, ((u64)d * nblk / W) * AC_BLOCK); };
-        // run-wide start of every (rank, bucket) piece: buckets in emission order, ranks in order inside a bucket
-        std::vector<u64> g0((size_t)W * nb1);
-        {
-          u64 base = 0;
-          for (uint32_t k = 0; k < nb1; k++) {
-            u64 at = base;
-            for (int r = 0; r < W; r++) { g0[(size_t)r * nb1 + k] = at; at += C[(size_t)r * nb1 + k] * Lm; }
-            base += Cg[k] * Lm;
-          }
-        }
-        auto below = [&](int r, u64 X) {  // bytes of rank r's local stream that lie in front of run-wide offset X
-          u64 sum = 0;
-          for (uint32_t k = 0; k < nb1; k++) {
-            const u64 a = g0[(size_t)r * nb1 + k], len = C[(size_t)r * nb1 + k] * Lm;
-            sum += X <= a ? 0 : (X - a < len ? X - a : len);
-          }
-          return sum;
-        };
-        const u64 lo = lo_of(rank), hi = lo_of(rank + 1);
-        std::vector<uint64_t> sendb(W), recvb(W);
-        for (int d = 0; d < W; d++) sendb[d] = below(rank, lo_of(d + 1)) - below(rank, lo_of(d));
-        for (int src = 0; src < W; src++) recvb[src] = below(src, hi) - below(src, lo);
-        // where the received pieces go: source-major, bucket order = contiguous in the receive buffer
-        std::vector<uint64_t> psrc, pdst;
-        u64 at = 0;
-        for (int src = 0; src < W; src++)
-          for (uint32_t k = 0; k < nb1; k++) {
-            const u64 a0 = g0[(size_t)src * nb1 + k], a1 = a0 + C[(size_t)src * nb1 + k] * Lm;
-            const u64 x = std::max(a0, lo), y = std::min(a1, hi);
-            if (y > x) { psrc.push_back(at); pdst.push_back(x - lo); at += y - x; }
-          }
+        const u64 Lm = (u64)L[m];
+        std::vector<uint64_t> sendb(W), recvb(W), psrc((size_t)W * nb1), pdst((size_t)W * nb1);
+        uint64_t lo = 0, hi = 0, np = 0;
+        if (scalce_shard_plan_blocks(W, rank, nb1, C, Lm, sendb.data(), recvb.data(), &lo, &hi, psrc.data(), pdst.data(), &np))
+          throw Fail{"internal: block-range plan is inconsistent", SCALCE_ERR_ARG};
+        psrc.resize(np);
+        pdst.resize(np);
         u64 recv_total = 0;
         for (int r = 0; r < W; r++) recv_total += recvb[r];
-        if (at != recv_total) throw Fail{"internal: block-range plan is inconsistent", SCALCE_ERR_ARG};
         SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QSTREAM, m, &dp, &nb));
         if (nb != N * Lm) throw Fail{"internal: reordered stream has an unexpected size", SCALCE_ERR_ARG};
         uint8_t *d_got = mem.alloc<uint8_t>(recv_total);

@@ -37,7 +37,7 @@ class ShardPipeline:
         self.front = torch.cuda.Stream()
         self.coder = torch.cuda.Stream()
         self.on_retire = on_retire
-        self.sharded = sharded          # shards arrive prepared (dist.compress_shard(prepare_only=True) / ent_stream)
+        self.sharded = sharded          # shards arrive prepared (scalce_sharded_compress with SCALCE_SHARD_PREPARE_ONLY / _CODER_ASYNC)
         self.trace = trace
         self._busy = [None] * self.D    # event behind the slot's coder launch
         self._tag = [None] * self.D
