@@ -96,19 +96,25 @@ def main():
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
             comm = host.Comm(local, world, rank, unique_id=uid[0])
-    # shards per coder launch / shards in flight: 3 / 6 on one GPU (210 GB of the 288 GB HBM at 50 M reads per shard).  A
-    # sharded run also holds every in-flight shard's block range of the run-wide quality stream, and while a shard is being
-    # worked on the text it received from its neighbours and the all-to-all buffers (about 25 GB at 50 M reads): 2 / 4.
+    # shards per coder launch / shards in flight: 3 / 6 (135 GB of the 288 GB HBM at 50 M reads per shard with the shared
+    # front-stage buffers).  A sharded run also holds every in-flight shard's block range of the run-wide quality stream
+    # (5 GB each) and, while a shard is worked on, the text it received from its neighbours and the all-to-all buffers
+    # (about 25 GB): 190 GB.  Larger groups do not pay yet: from four shards per launch on the front stages, not the coder,
+    # bound the pipeline.
     G = args.group
     if G is None:
-        G = 2 if sharded else 3
+        G = 3
     G = max(1, G)
     D = max(1, args.inflight) if args.inflight is not None else 2 * G
     if G > 1:
         D = max(D, 2 * G)
     # -B: the reference's default, 4 GiB of record bytes per spill chunk (main.cpp:68) -- 50 M reads of 100 bp are 3 chunks
     B = int(os.environ.get("SCALCE_BENCH_BUCKET_SET", str(4 << 30)))
-    batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B) for _ in range(D)]
+    # the shards in flight share ONE set of front-stage buffers (rows, tokens, events, sort scratch: dead once a shard is
+    # emitted, and front stages run one at a time on the front stream): 15 GB instead of 35 GB of HBM per shard in flight
+    shared_ws = None if os.environ.get("SCALCE_BENCH_OWN_WORKSPACES") else host.Workspace(ctx)
+    batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B,
+                          workspace=shared_ws) for _ in range(D)]
     batch = batches[0]
     state = {}
 

@@ -82,6 +82,16 @@ void scalce_params_default(scalce_params *p);
 int scalce_batch_create(scalce_ctx *ctx, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
                         scalce_batch **out);
 void scalce_batch_destroy(scalce_batch *b);
+/* Batches that share their front-stage buffers.  Rows, tokens, tie-break events and sort scratch are dead once a shard is
+ * emitted -- the coder reads the reordered stream and writes the coded one -- so batches whose front stages (ingest .. emit)
+ * run one after the other on ONE stream can share a single set: 15 GB instead of 35 GB of HBM per shard in flight at
+ * 50 M x 100 bp.  Outputs 5, 6, 9, 10 of a batch (tokens, permutation, q' and name lengths in input order) are only valid
+ * until the next batch of the workspace starts its front stages.  Destroy the batches before the workspace. */
+typedef struct scalce_workspace scalce_workspace;
+int scalce_workspace_create(scalce_ctx *ctx, scalce_workspace **out);
+void scalce_workspace_destroy(scalce_workspace *w);
+int scalce_batch_create_shared(scalce_ctx *ctx, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
+                               scalce_workspace *w, scalce_batch **out);
 
 /* record reader of thread() (compress.cpp:614-666): newline index of the FASTQ text of one
  * mate, validation of the fixed read length, 2-bit packing of the bases (getval, const.cpp:47),

@@ -227,7 +227,47 @@ struct DBuf {  // grow-only device buffer
 
 enum { ST_INGEST = 0, ST_QUALITY, ST_TOKENIZE, ST_ORDER, ST_EMIT, ST_ENTROPY, ST_COUNT };
 
+// Device buffers of the FRONT stages (ingest .. emit): rows, tokens, tie-break events, sort scratch.  Nothing behind the
+// emit stage reads them -- the coder works on the reordered stream and writes the coded one -- so batches whose front stages
+// run one after the other on one stream can share a single set (scalce_workspace): with six shards in flight that is the
+// difference between 35 GB and 15 GB of HBM per shard (50 M reads x 100 bp).
+struct scalce_workspace {
+  scalce_ctx *ctx = nullptr;
+  u64 row_cap = 0;           // rows the run-wide arrays hold
+  u64 piece_rows_cap = 0;    // records one piece may bring (size of the line index)
+  DBuf line_end[2], tile[2], packed[2], q[2], namelen, namecell, outlen, names_in, name_in_off, prior_buf;
+  DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
+  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
+  DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
+  DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
+  DBuf name_off;
+  void free_all() {
+    DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
+                   &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
+                   &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
+                   &cand_place, &Gseg, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
+                   &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
+                   &run_pos, &name_off};
+    for (DBuf *d : all)
+      if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
+    row_cap = piece_rows_cap = 0;
+  }
+};
+
 struct scalce_batch {
+  scalce_workspace *ws;   // front-stage buffers: the batch's own, or shared with other batches (scalce_batch_create_shared)
+  bool owns_ws;
+  explicit scalce_batch(scalce_workspace *w, bool owns)
+      : ws(w), owns_ws(owns), row_cap(w->row_cap), piece_rows_cap(w->piece_rows_cap), line_end(w->line_end), tile(w->tile),
+        packed(w->packed), q(w->q), namelen(w->namelen), namecell(w->namecell), outlen(w->outlen), names_in(w->names_in),
+        name_in_off(w->name_in_off), prior_buf(w->prior_buf), tok_bucket(w->tok_bucket), tok_pos(w->tok_pos), tie_index(w->tie_index),
+        tie_read(w->tie_read), tie_off(w->tie_off), tie_ncand(w->tie_ncand), cand_bucket(w->cand_bucket), cand_pos(w->cand_pos),
+        choice(w->choice), ev_off(w->ev_off), ev_bucket(w->ev_bucket), ev_init(w->ev_init), ev_sorted(w->ev_sorted), ev_tmp(w->ev_tmp),
+        ev_place(w->ev_place), chosen(w->chosen), G(w->G), seg(w->seg), dirty(w->dirty), cand_place(w->cand_place), Gseg(w->Gseg),
+        bucket(w->bucket), endv(w->endv), tokens(w->tokens), counts(w->counts), bucket_first(w->bucket_first), bucket_off(w->bucket_off),
+        chunk(w->chunk), chunk_start(w->chunk_start), perm_a(w->perm_a), perm_b(w->perm_b), key_a(w->key_a), key_b(w->key_b), hist(w->hist),
+        scan_ws(w->scan_ws), S(w->S), run_head(w->run_head), run_hcount(w->run_hcount), run_rank(w->run_rank), runid(w->runid),
+        run_items_a(w->run_items_a), run_items_b(w->run_items_b), run_pos(w->run_pos), name_off(w->name_off) {}
   scalce_ctx *ctx = nullptr;
   scalce_params p;
   u64 max_reads = 0, max_text = 0;
@@ -238,8 +278,8 @@ struct scalce_batch {
   // bases, q', names and tokens are run-wide arrays indexed by row; the text of a piece is dead once it is ingested.
   u64 N = 0, base = 0, NP = 0;
   u64 tok_done = 0, tok_base = 0, tok_n = 0;  // rows tokenized so far / the rows of the tokenization in progress
-  u64 row_cap = 0;           // rows the run-wide arrays hold
-  u64 piece_rows_cap = 0;    // records one piece may bring (size of the line index)
+  u64 &row_cap;              // (of the workspace) rows the run-wide arrays hold
+  u64 &piece_rows_cap;       // (of the workspace) records one piece may bring
   bool appending = false;    // the pieces came through scalce_batch_append
   bool lean = false;         // release what a stage no longer needs (runs sized for most of HBM)
   u64 tri_expected[2] = {0, 0};  // trigrams counted so far (tri_check_k)
@@ -253,16 +293,20 @@ struct scalce_batch {
   u64 *d_small64 = nullptr;
   u8 *d_qlut[2] = {nullptr, nullptr};
   int q_affine[2] = {-1, -1};  // the quality map is q - offset for every character: no table lookups in the ingest kernel
-  DBuf line_end[2], tile[2], packed[2], q[2], namelen, namecell, outlen, freq4[2], table[2], qs[2];
-  DBuf names_in, name_in_off, counts_total, prior_buf, bucket_name_bytes;  // names longer than a cell, input order; reads per bucket over all pieces
-  DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
-  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
-  DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
+  // front-stage buffers (of the workspace)
+  DBuf (&line_end)[2], (&tile)[2], (&packed)[2], (&q)[2], &namelen, &namecell, &outlen;
+  DBuf &names_in, &name_in_off, &prior_buf;  // names longer than a cell, input order
+  DBuf &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket, &cand_pos, &choice;
+  DBuf &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty, &cand_place, &Gseg;
+  DBuf &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start;
+  // what the coder and the caller read behind the emit stage: the batch's own
+  DBuf freq4[2], table[2], qs[2], counts_total, bucket_name_bytes, ac_scan;
   const u64 *sorted_keys = nullptr;  // phase-1 keys in output order (order stage), consumed by the emit stage
   u32 key_end_bits = 0, key_bucket_shift = 0, key_bucket_mask = 0;
-  DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
+  DBuf &perm_a, &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b, &run_pos;
+  DBuf &name_off;
   u32 order_run_members = 0;
-  DBuf out_reads[2], out_names, name_off, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
+  DBuf out_reads[2], out_names, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
   AcBlockDesc *ac_desc_host = nullptr;  // block descriptors of the last coder launch this shard led: pinned, so that the
   u32 ac_desc_cap = 0;                  // asynchronous upload never reads memory the next launch is already rewriting
   u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
@@ -338,19 +382,13 @@ static void release(DBuf &d) {
 }
 
 static void free_all(scalce_batch *b) {
-  DBuf *all[] = {&b->bucket_name_bytes, &b->tile[0], &b->tile[1], &b->names_in, &b->name_in_off, &b->counts_total, &b->prior_buf,
-                 &b->line_end[0], &b->line_end[1], &b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen, &b->namecell, &b->outlen,
-                 &b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->tok_bucket,
-                 &b->tok_pos, &b->tie_index, &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos,
-                 &b->choice, &b->ev_off, &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place,
-                 &b->chosen, &b->G, &b->seg, &b->dirty, &b->cand_place, &b->Gseg, &b->bucket, &b->endv, &b->tokens, &b->counts, &b->bucket_first,
-                 &b->bucket_off, &b->chunk, &b->chunk_start, &b->perm_a, &b->perm_b, &b->key_a, &b->key_b, &b->hist, &b->scan_ws, &b->S, &b->run_head, &b->run_hcount, &b->run_rank, &b->runid,
-                 &b->run_items_a, &b->run_items_b, &b->run_pos,
-                 &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->name_off, &b->ac_tab[0], &b->ac_cum[0],
-                 &b->ac_blocks[0], &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1],
-                 &b->ac_sizes[1], &b->ac_off[1], &b->ac_desc, &b->out_qual[0], &b->out_qual[1]};
+  DBuf *all[] = {&b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->counts_total, &b->bucket_name_bytes,
+                 &b->ac_scan, &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->ac_tab[0], &b->ac_cum[0], &b->ac_blocks[0],
+                 &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1], &b->ac_sizes[1], &b->ac_off[1],
+                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1]};
   for (DBuf *d : all)
     if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
+  if (b->owns_ws) { b->ws->free_all(); delete b->ws; }
   if (b->d_err) hipFree(b->d_err);
   if (b->d_small) hipFree(b->d_small);
   if (b->d_small64) hipFree(b->d_small64);
@@ -383,8 +421,32 @@ static int reserve_rows(scalce_batch *b, u64 rows, u64 used, hipStream_t s) {
   return SCALCE_OK;
 }
 
+extern "C" int scalce_workspace_create(scalce_ctx *c, scalce_workspace **out) {
+  if (!c || !out) return SCALCE_ERR_ARG;
+  *out = new scalce_workspace();
+  (*out)->ctx = c;
+  return SCALCE_OK;
+}
+extern "C" void scalce_workspace_destroy(scalce_workspace *w) {
+  if (!w) return;
+  hipSetDevice(w->ctx->device);
+  w->free_all();
+  delete w;
+}
+
+static int batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_reads, uint64_t max_text, scalce_workspace *shared,
+                        scalce_batch **out);
 extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
                                    scalce_batch **out) {
+  return batch_create(c, p, max_reads, max_text, nullptr, out);
+}
+extern "C" int scalce_batch_create_shared(scalce_ctx *c, const scalce_params *p, uint64_t max_reads, uint64_t max_text,
+                                          scalce_workspace *w, scalce_batch **out) {
+  if (!w || w->ctx != c) return SCALCE_ERR_ARG;
+  return batch_create(c, p, max_reads, max_text, w, out);
+}
+static int batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_reads, uint64_t max_text, scalce_workspace *shared,
+                        scalce_batch **out) {
   if (!c || !p || !out) return SCALCE_ERR_ARG;
   if (!c->have_patterns) { set_err(c, "load a core table first"); return SCALCE_ERR_ARG; }
   if (p->read_len[0] <= 0 || p->read_len[0] > 2498 || (p->paired && (p->read_len[1] <= 0 || p->read_len[1] > 2498))) {
@@ -393,7 +455,9 @@ extern "C" int scalce_batch_create(scalce_ctx *c, const scalce_params *p, uint64
   }
   if (max_reads >= (1ull << 32) - 64) { set_err(c, "a shard holds fewer than 2^32 reads"); return SCALCE_ERR_CAPACITY; }
   HIP_TRY(c, hipSetDevice(c->device));
-  scalce_batch *b = new scalce_batch();
+  scalce_workspace *w = shared;
+  if (!w) { w = new scalce_workspace(); w->ctx = c; }
+  scalce_batch *b = new scalce_batch(w, shared == nullptr);
   b->ctx = c;
   b->p = *p;
   b->max_reads = max_reads;
@@ -1269,8 +1333,8 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true) {
   // the framed stream is sized for the worst case (every block at its cap): no size has to come back from the
   // device before the frame kernel can be enqueued
   if (framed_output) ENSURE(b, b->out_qual[m], (size_t)j.nblk * (AC_STRIDE + 4) + 64);
-  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(j.nblk ? j.nblk : 1) + 64));
-  if (!j.nblk) b->out_qual_bytes[m] = 0;
+  ENSURE(b, b->ac_scan, sizeof(u64) * (scan_ws_elems(j.nblk ? j.nblk : 1) + 64));  // (the batch's own: framing runs at collect time,
+  if (!j.nblk) b->out_qual_bytes[m] = 0;                                            //  beside another batch's front stages)
   return SCALCE_OK;
 }
 
@@ -1395,7 +1459,7 @@ static int ac_frame(AcJob &j, hipStream_t s) {
   scalce_batch *b = j.b;
   const int m = j.m;
   if (!j.nblk) return SCALCE_OK;
-  exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, j.nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->scan_ws.as<u64>(),
+  exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, j.nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->ac_scan.as<u64>(),
                       b->d_small64 + 8 + m, s);
   LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), j.nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), AC_STRIDE,
          b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
@@ -1501,7 +1565,7 @@ static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, h
     if (rc) return rc;
     for (int i = 0; i < nj; i++) {
       const int m = jobs[i].m;
-      exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, jobs[i].nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->scan_ws.as<u64>(),
+      exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, jobs[i].nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->ac_scan.as<u64>(),
                           b->d_small64 + 8 + m, s);
       u64 total = 0;
       if ((rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s))) return rc;

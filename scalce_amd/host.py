@@ -82,6 +82,10 @@ def lib():
     L.scalce_params_default.restype = None
     L.scalce_batch_create.argtypes = [vp, C.POINTER(Params), u64, u64, C.POINTER(vp)]
     L.scalce_batch_destroy.argtypes = [vp]
+    L.scalce_workspace_create.argtypes = [vp, C.POINTER(vp)]
+    L.scalce_workspace_destroy.argtypes = [vp]
+    L.scalce_workspace_destroy.restype = None
+    L.scalce_batch_create_shared.argtypes = [vp, C.POINTER(Params), u64, u64, vp, C.POINTER(vp)]
     L.scalce_batch_ingest.argtypes = [vp, i32, vp, u64, vp]
     L.scalce_batch_append.argtypes = [vp, vp, u64, vp, u64, i32, C.POINTER(u64), vp]
     L.scalce_batch_reset.argtypes = [vp]
@@ -313,11 +317,25 @@ def entropy_begin_group(batches, prep_stream=0, stream=0):
     batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group(arr, len(batches), prep_stream, stream))
 
 
+class Workspace:
+    """Front-stage device buffers shared by several batches (scalce_workspace): see include/scalce_hip.h."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._check(ctx.L.scalce_workspace_create(ctx.h, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.scalce_workspace_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Batch:
     """One FASTQ shard in HBM (scalce_batch)."""
 
     def __init__(self, ctx, read_len, max_reads, max_text, paired=False, use_names=True, no_ac=False, qmap=None,
-                 bucket_set_size=0, read_len2=0, qprev=None):
+                 bucket_set_size=0, read_len2=0, qprev=None, workspace=None):
         self.ctx = ctx
         self.L = ctx.L
         p = Params()
@@ -337,7 +355,11 @@ class Batch:
                     p.qprev[m][i] = int(qprev[m][i])
         self.params = p
         self.h = C.c_void_p()
-        rc = self.L.scalce_batch_create(ctx.h, C.byref(p), int(max_reads), int(max_text), C.byref(self.h))
+        self.workspace = workspace  # keeps it alive
+        if workspace is not None:
+            rc = self.L.scalce_batch_create_shared(ctx.h, C.byref(p), int(max_reads), int(max_text), workspace.h, C.byref(self.h))
+        else:
+            rc = self.L.scalce_batch_create(ctx.h, C.byref(p), int(max_reads), int(max_text), C.byref(self.h))
         if rc:
             raise ScalceError(f"[{rc}] " + self.L.scalce_last_error(ctx.h).decode())
 

@@ -10,8 +10,8 @@ from scalce_amd.pipeline import ShardPipeline
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("group,slots", [(1, 1), (1, 2), (2, 4), (3, 6)])
-def test_pipelined_shards_equal_one_shot_compress(group, slots, patterns_blob):
+@pytest.mark.parametrize("group,slots,shared", [(1, 1, False), (1, 2, False), (2, 4, False), (3, 6, False), (2, 4, True), (3, 6, True), (4, 8, True)])
+def test_pipelined_shards_equal_one_shot_compress(group, slots, shared, patterns_blob):
     import torch
     from gpu_util import device_bytes
     ctx = host.Context(0, patterns_bin=patterns_blob)
@@ -29,7 +29,10 @@ def test_pipelined_shards_equal_one_shot_compress(group, slots, patterns_blob):
         b.finish()
         want.append({w: b.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)})
     nmax, bmax = max(sizes), max(s[1] for s in shards)
-    batches = [host.Batch(ctx, L, nmax + 8, bmax + 64) for _ in range(slots)]
+    # shared: ONE set of front-stage buffers for all slots (scalce_workspace): a shard's rows are overwritten by the next
+    # shard's front stages while its own coder is still running
+    ws = host.Workspace(ctx) if shared else None
+    batches = [host.Batch(ctx, L, nmax + 8, bmax + 64, workspace=ws) for _ in range(slots)]
     got = {}
 
     def on_retire(slot, batch, tag):
