@@ -236,7 +236,7 @@ struct EventArgs {
   const u32 *ev_off;
   u32 *ev_bucket;
   u8 *ev_init;           // initial "chosen" flag: fixed reads 1, first candidate 1, others 0
-  u64 *ev_key;           // bucket << 1 | initial flag: what the sort by bucket carries along (or null)
+  u64 *ev_key;           // bucket << 2 | candidate of a tie read << 1 | initial flag: what the sort by bucket carries along
 };
 __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
   const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,13 +248,13 @@ __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
       const u32 bk = a.cand_bucket[off + j];
       a.ev_bucket[e + j] = bk;
       a.ev_init[e + j] = j == 0;
-      if (a.ev_key) a.ev_key[e + j] = ((u64)bk << 1) | (j == 0 ? 1u : 0u);
+      if (a.ev_key) a.ev_key[e + j] = ((u64)bk << 2) | 2u | (j == 0 ? 1u : 0u);
     }
   } else {
     const u32 bk = a.tok_bucket[r];
     a.ev_bucket[e] = bk;
     a.ev_init[e] = 1;
-    if (a.ev_key) a.ev_key[e] = ((u64)bk << 1) | 1u;
+    if (a.ev_key) a.ev_key[e] = ((u64)bk << 2) | 1u;
   }
 }
 
@@ -310,18 +310,40 @@ __global__ __launch_bounds__(256) void events_segments_k(u32 nev, const u32 *sor
   }
 }
 
-// the same two from the sorted (bucket << 1 | initial flag) keys: sequential reads instead of gathers through `sorted`
-__global__ __launch_bounds__(256) void events_place_keys_k(u32 nev, const u32 *sorted, const u64 *keys, u32 *ev_place, u8 *chosen) {
+// The sweeps only ever need the events of TIE candidates: a fixed read is in its bucket in every sweep, so what the fixed
+// reads in front of a candidate contribute is a constant (fixed_before).  Of the 61 M events of a 50 M-read shard 20 M are
+// tie candidates: the flags and prefix sums the sweeps gather from shrink from 246 MB to 80 MB (inside the 256 MB of
+// Infinity Cache instead of HBM) and a bucket's rescan walks a third of the events.
+//   cidx[p]       compact index of sorted position p (exclusive scan of the tie bit)
+//   ev_place[e]   sorted position of event e
+struct TieBitOfKey {
+  const u64 *keys;
+  __device__ u32 operator()(u64 i) const { return (u32)(keys[i] >> 1) & 1u; }
+};
+__global__ __launch_bounds__(256) void events_place_keys_k(u32 nev, const u32 *sorted, const u64 *keys, const u32 *cidx, u32 *ev_place,
+                                                          u8 *chosen_t) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nev) return;
   ev_place[sorted[i]] = i;
-  chosen[i] = (u8)(keys[i] & 1u);
+  if (keys[i] & 2u) chosen_t[cidx[i]] = (u8)(keys[i] & 1u);
+}
+// seg[b] = first sorted position of bucket b, seg_t[b] = first compact position, fixed_total[b] = its fixed reads
+__global__ __launch_bounds__(256) void events_compact_segments_k(u32 nb1, const u32 *seg, const u32 *cidx, u32 nev, u32 ntev, u32 *seg_t,
+                                                                u32 *fixed_total) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb1) return;
+  const u32 s0 = seg[b], c0 = s0 < nev ? cidx[s0] : ntev;
+  seg_t[b] = c0;
+  if (b < nb1) {
+    const u32 s1 = seg[b + 1], c1 = s1 < nev ? cidx[s1] : ntev;
+    fixed_total[b] = (s1 - s0) - (c1 - c0);
+  }
 }
 __global__ __launch_bounds__(256) void events_segments_keys_k(u32 nev, const u64 *keys, u32 nb, u32 *seg) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > nev) return;
-  const u32 cur = i < nev ? (u32)(keys[i] >> 1) : nb;
-  const u32 prev = i ? (u32)(keys[i - 1] >> 1) : 0xFFFFFFFFu;
+  const u32 cur = i < nev ? (u32)(keys[i] >> 2) : nb;
+  const u32 prev = i ? (u32)(keys[i - 1] >> 2) : 0xFFFFFFFFu;
   if (i == 0) {
     for (u32 b = 0; b <= cur && b <= nb; b++) seg[b] = 0;
   } else if (cur != prev) {
@@ -331,19 +353,24 @@ __global__ __launch_bounds__(256) void events_segments_keys_k(u32 nev, const u64
 
 // position of every candidate in the sorted event array, in CSR order (read once per sweep, coalesced)
 __global__ __launch_bounds__(256) void tie_place_k(u32 ntie, const u32 *tie_read, const u32 *tie_off, const u32 *tie_ncand,
-                                                  const u32 *ev_off, const u32 *ev_place, u32 *cand_place) {
+                                                  const u32 *ev_off, const u32 *ev_place, const u32 *cidx, const u32 *cand_bucket,
+                                                  const u32 *seg, const u32 *seg_t, u32 *cand_place, u32 *fixed_before) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntie) return;
   const u32 off = tie_off[t], k = tie_ncand[t], e0 = ev_off[tie_read[t]];
-  for (u32 j = 0; j < k; j++) cand_place[off + j] = ev_place[e0 + j];
+  for (u32 j = 0; j < k; j++) {
+    const u32 p = ev_place[e0 + j], c = cidx[p], b = cand_bucket[off + j];
+    cand_place[off + j] = c;                                   // compact position of the candidate's event
+    fixed_before[off + j] = (p - seg[b]) - (c - seg_t[b]);     // fixed reads of its bucket in front of it
+  }
 }
 
 struct JacobiArgs {
   u32 ntie;
   const u32 *tie_read, *tie_off, *tie_ncand, *cand_bucket;
   const u32 *cand_place;  // sorted-event position of every candidate (CSR order)
-  const u32 *G;         // exclusive prefix of `chosen` over the sorted events (G[nev] = total)
-  const u32 *Gseg;      // G at the start of every bucket's segment (small, cache resident)
+  const u32 *G;         // exclusive prefix of `chosen` over the compact (tie-candidate) events, restarted in every bucket
+  const u32 *fixed_before;  // per candidate: fixed reads of its bucket in front of it
   const u64 *prior;     // reads already in each bucket before this shard, or null
   u32 *choice;          // tie index -> chosen candidate ordinal
   u8 *chosen;
@@ -352,7 +379,11 @@ struct JacobiArgs {
   // 0 = all, 0xFFFFFFFF = none).  A decision only depends on counts BEFORE its read, so later changes cannot move it.
   const u32 *dirty_in;
   u32 *dirty_out;       // ... in this sweep (reset by the host before the launch)
+  u32 coarse;           // mark whole buckets (see jacobi_k)
 };
+// (Staging the per-bucket thresholds in LDS with workgroups striding over the ties was measured and is slower, 0.40 against
+// 0.33 ms per sweep: the sweeps are bound by the evaluations of the reads that ARE woken up -- three million decisions move
+// in the first sweep -- not by looking at the others, which costs 50 us.)
 __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.ntie) return;
@@ -366,8 +397,9 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   u32 best = 0;
   u64 bestc = 0;
   for (u32 j = 0; j < k; j++) {
-    const u32 b = a.cand_bucket[off + j];
-    const u64 c = (a.prior ? a.prior[b] : 0ull) + (u64)(a.G[a.cand_place[off + j]] - a.Gseg[b]);
+    // reads of the bucket in front of this one: earlier shards + fixed reads + tie reads that currently choose it (G is the
+    // prefix of the `chosen` flags INSIDE the bucket's segment: one gather per candidate)
+    const u64 c = (a.prior ? a.prior[a.cand_bucket[off + j]] : 0ull) + (u64)a.fixed_before[off + j] + (u64)a.G[a.cand_place[off + j]];
     if (j == 0 || c > bestc) {  // strict: an earlier candidate keeps the bucket on equal counts
       best = j;
       bestc = c;
@@ -378,8 +410,14 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
     a.chosen[a.cand_place[off + old]] = 0;
     a.chosen[a.cand_place[off + best]] = 1;
     a.choice[t] = best;
-    atomicMin(&a.dirty_out[a.cand_bucket[off + old]], r + 1);
-    atomicMin(&a.dirty_out[a.cand_bucket[off + best]], r + 1);
+    if (a.coarse) {  // early sweeps, millions of decisions move: "somewhere in this bucket" (a plain store) instead of
+                     // "from read r + 1 on" (an atomic minimum on a table of a few thousand hot words)
+      a.dirty_out[a.cand_bucket[off + old]] = 0;
+      a.dirty_out[a.cand_bucket[off + best]] = 0;
+    } else {
+      atomicMin(&a.dirty_out[a.cand_bucket[off + old]], r + 1);
+      atomicMin(&a.dirty_out[a.cand_bucket[off + best]], r + 1);
+    }
     a.changed[0] = 1;  // plain store: every writer stores the same value
   }
 }
@@ -423,12 +461,12 @@ __global__ __launch_bounds__(256) void finalize_k(FinalizeArgs a) {
 // (G[pos] = Gseg[b] + flags before pos inside the segment) and the bucket's read count, all others return at once.  The
 // 61 M-event global scan per sweep (47 sweeps) this replaces cost as much as the sweeps themselves.
 __global__ __launch_bounds__(256) void seg_rescan_k(u32 nb1, const u32 *seg, const u32 *dirty, const u8 *chosen, u32 *G,
-                                                   const u32 *Gseg, u64 *counts) {
+                                                   const u32 *fixed_total, u64 *counts) {
   __shared__ u32 sm[4];
   const u32 b = blockIdx.x;
   if (b >= nb1 || dirty[b] == 0xFFFFFFFFu) return;
   const u32 start = seg[b], end = seg[b + 1];
-  u32 running = Gseg[b];
+  u32 running = 0;
   for (u32 base = start; base < end; base += 256 * 16) {
     const u32 p0 = base + threadIdx.x * 16;
     u32 f[16], mine = 0;
@@ -440,21 +478,12 @@ __global__ __launch_bounds__(256) void seg_rescan_k(u32 nb1, const u32 *seg, con
     for (int i = 0; i < 16; i++) { if (p0 + i < end) G[p0 + i] = ex; ex += f[i]; }
     running += tot;
   }
-  if (threadIdx.x == 0) counts[b] = (u64)(running - Gseg[b]);
+  if (threadIdx.x == 0) counts[b] = (u64)fixed_total[b] + (u64)running;
 }
 
 __global__ __launch_bounds__(256) void add_counts_k(u32 n, const u64 *x, const u64 *y, u64 *out) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = x[i] + y[i];
-}
-
-// reads per bucket from the converged prefix sums
-__global__ __launch_bounds__(256) void bucket_counts_k(u32 nb1, const u32 *G, const u32 *seg, u64 *counts, u32 *Gseg) {
-  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb1) return;
-  const u32 g0 = G[seg[b]];
-  counts[b] = (u64)(G[seg[b + 1]] - g0);
-  Gseg[b] = g0;
 }
 
 }  // namespace scalce

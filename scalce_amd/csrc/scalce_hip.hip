@@ -237,7 +237,7 @@ struct scalce_workspace {
   u64 piece_rows_cap = 0;    // records one piece may bring (size of the line index)
   DBuf line_end[2], tile[2], packed[2], q[2], namelen, namecell, outlen, names_in, name_in_off, prior_buf;
   DBuf tok_bucket, tok_pos, tie_index, tie_read, tie_off, tie_ncand, cand_bucket, cand_pos, choice;
-  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg;
+  DBuf ev_off, ev_bucket, ev_init, ev_sorted, ev_tmp, ev_place, chosen, G, seg, dirty, cand_place, Gseg, cand_fixed;
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
   DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   DBuf name_off;
@@ -245,7 +245,7 @@ struct scalce_workspace {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
                    &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
                    &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
-                   &cand_place, &Gseg, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
+                   &cand_place, &Gseg, &cand_fixed, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
                    &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
                    &run_pos, &name_off};
     for (DBuf *d : all)
@@ -263,7 +263,7 @@ struct scalce_batch {
         name_in_off(w->name_in_off), prior_buf(w->prior_buf), tok_bucket(w->tok_bucket), tok_pos(w->tok_pos), tie_index(w->tie_index),
         tie_read(w->tie_read), tie_off(w->tie_off), tie_ncand(w->tie_ncand), cand_bucket(w->cand_bucket), cand_pos(w->cand_pos),
         choice(w->choice), ev_off(w->ev_off), ev_bucket(w->ev_bucket), ev_init(w->ev_init), ev_sorted(w->ev_sorted), ev_tmp(w->ev_tmp),
-        ev_place(w->ev_place), chosen(w->chosen), G(w->G), seg(w->seg), dirty(w->dirty), cand_place(w->cand_place), Gseg(w->Gseg),
+        ev_place(w->ev_place), chosen(w->chosen), G(w->G), seg(w->seg), dirty(w->dirty), cand_place(w->cand_place), Gseg(w->Gseg), cand_fixed(w->cand_fixed),
         bucket(w->bucket), endv(w->endv), tokens(w->tokens), counts(w->counts), bucket_first(w->bucket_first), bucket_off(w->bucket_off),
         chunk(w->chunk), chunk_start(w->chunk_start), perm_a(w->perm_a), perm_b(w->perm_b), key_a(w->key_a), key_b(w->key_b), hist(w->hist),
         scan_ws(w->scan_ws), S(w->S), run_head(w->run_head), run_hcount(w->run_hcount), run_rank(w->run_rank), runid(w->runid),
@@ -297,7 +297,7 @@ struct scalce_batch {
   DBuf (&line_end)[2], (&tile)[2], (&packed)[2], (&q)[2], &namelen, &namecell, &outlen;
   DBuf &names_in, &name_in_off, &prior_buf;  // names longer than a cell, input order
   DBuf &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket, &cand_pos, &choice;
-  DBuf &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty, &cand_place, &Gseg;
+  DBuf &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty, &cand_place, &Gseg, &cand_fixed;
   DBuf &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start;
   // what the coder and the caller read behind the emit stage: the batch's own
   DBuf freq4[2], table[2], qs[2], counts_total, bucket_name_bytes, ac_scan;
@@ -312,7 +312,7 @@ struct scalce_batch {
   u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
   // host-side results
   u64 out_reads_bytes[2] = {0, 0}, out_names_bytes = 0, out_qual_bytes[2] = {0, 0};
-  u32 ntie = 0, nev = 0, ncand_cap = 0, jacobi_iters = 0, nchunks = 1;
+  u32 ntie = 0, nev = 0, ntev = 0, ncand_cap = 0, jacobi_iters = 0, nchunks = 1, sweep_no = 0;
   bool tok_open = false;
   int dirty_cur = 0;
   std::vector<uint64_t> explicit_chunks;  // spill-chunk starts given by the caller (sharded runs), else -B rule
@@ -798,6 +798,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   const u64 N = b->tok_n;
   const u8 *packed0 = b->packed[0].as<u8>() + b->tok_base * (u64)b->stride[0];
   b->jacobi_iters = 0;
+  b->sweep_no = 0;
   b->tok_open = true;
   const u32 nb1 = (u32)c->A.n_buckets + 1;  // buckets incl. root
   ENSURE(b, b->tok_bucket, sizeof(u32) * (N + 1));
@@ -810,7 +811,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     ENSURE(b, b->prior_buf, sizeof(u64) * (nb1 + 1));
   }
   if (b->tok_base == 0) HIP_TRY(c, hipMemsetAsync(b->counts_total.p, 0, sizeof(u64) * (nb1 + 1), s));
-  ENSURE(b, b->seg, sizeof(u32) * (nb1 + 2));
+  ENSURE(b, b->seg, 3 * sizeof(u32) * (nb1 + 2));  // segment starts over all events, over the tie events, fixed reads per bucket
   ENSURE(b, b->Gseg, sizeof(u32) * (nb1 + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(2 * N + 1024) + 1024));
   u32 *ws32 = b->scan_ws.as<u32>();
@@ -901,25 +902,33 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   const u32 *src = nullptr;  // identity
   u32 *dst = b->ev_sorted.as<u32>(), *alt = b->ev_tmp.as<u32>();
   u64 *ka = b->key_a.as<u64>(), *kb = b->key_b.as<u64>();
-  for (int sh = 1; sh < 1 + bits; sh += 8) {  // bit 0 is the initial flag riding along
+  for (int sh = 2; sh < 2 + bits; sh += 8) {  // bits 0, 1 (initial flag, tie bit) ride along
     radix_pass_kv(ka, src, kb, dst, nev, (u32)sh, b->hist.as<u32>(), ws32, s);
     src = dst;
     u32 *t = dst; dst = alt; alt = t;
     u64 *tk = ka; ka = kb; kb = tk;
   }
   const u32 *sorted = src;
-  LAUNCH(events_place_keys_k, cdiv(nev, 256), 256, 0, s, nev, sorted, ka, b->ev_place.as<u32>(), b->chosen.as<u8>());
-  LAUNCH(events_segments_keys_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, ka, nb1, b->seg.as<u32>());
+  // compact view of the tie-candidate events (see events_place_keys_k): what the sweeps work on
+  u32 *cidx = dst;  // the ping-pong buffer the sort no longer needs
+  exclusive_scan<u32>(TieBitOfKey{ka}, nev, StoreTo<u32>{cidx}, ws32, b->d_small + 3, s);
+  u32 ntev = 0;
+  { int rc = read_u32(b, b->d_small + 3, &ntev, 1, s); if (rc) return rc; }
+  b->ntev = ntev;
+  ENSURE(b, b->cand_fixed, sizeof(u32) * (ncap + 2));
+  u32 *seg_all = b->seg.as<u32>(), *seg_t = seg_all + (nb1 + 2), *fixed_total = seg_t + (nb1 + 2);
+  LAUNCH(events_place_keys_k, cdiv(nev, 256), 256, 0, s, nev, sorted, ka, cidx, b->ev_place.as<u32>(), b->chosen.as<u8>());
+  LAUNCH(events_segments_keys_k, cdiv((u64)nev + 1, 256), 256, 0, s, nev, ka, nb1, seg_all);
+  LAUNCH(events_compact_segments_k, cdiv(nb1 + 1, 256), 256, 0, s, nb1, seg_all, cidx, nev, ntev, seg_t, fixed_total);
   if (ntie)
     LAUNCH(tie_place_k, cdiv(ntie, 256), 256, 0, s, ntie, b->tie_read.as<u32>(), b->tie_off.as<u32>(), b->tie_ncand.as<u32>(),
-           b->ev_off.as<u32>(), b->ev_place.as<u32>(), b->cand_place.as<u32>());
-  // first prefix sums; the sweeps follow (scalce_batch_tokenize_sweep)
-  u32 *G = b->G.as<u32>();
-  exclusive_scan<u32>(LoadAs<u8, u32>{b->chosen.as<u8>()}, nev, StoreTo<u32>{G}, ws32, G + nev, s);
+           b->ev_off.as<u32>(), b->ev_place.as<u32>(), cidx, b->cand_bucket.as<u32>(), seg_all, seg_t, b->cand_place.as<u32>(),
+           b->cand_fixed.as<u32>());
+  // first prefix sums (per bucket) and counts; the sweeps follow (scalce_batch_tokenize_sweep)
   b->dirty_cur = 0;
   HIP_TRY(c, hipMemsetAsync(b->dirty.p, 0, sizeof(u32) * nb1, s));  // first sweep: every bucket moved "before read 0"
   HIP_TRY(c, hipMemsetAsync(b->dirty.as<u32>() + 2 * (size_t)(nb1 + 64), 0, sizeof(u64) * nb1, s));  // prior seen so far
-  LAUNCH(bucket_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, G, b->seg.as<u32>(), b->counts.as<u64>(), b->Gseg.as<u32>());
+  LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, seg_t, b->dirty.as<u32>(), b->chosen.as<u8>(), b->G.as<u32>(), fixed_total, b->counts.as<u64>());
   return SCALCE_OK;
 }
 
@@ -945,14 +954,20 @@ static int tokenize_sweep_enqueue(scalce_batch *b, const uint64_t *d_prior, u32 
   u32 *G = b->G.as<u32>();
   JacobiArgs a;
   a.ntie = ntie; a.tie_read = b->tie_read.as<u32>(); a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>();
-  a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_place = b->cand_place.as<u32>(); a.G = G;
-  a.Gseg = b->Gseg.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
+  a.cand_bucket = b->cand_bucket.as<u32>(); a.cand_place = b->cand_place.as<u32>(); a.G = G; a.fixed_before = b->cand_fixed.as<u32>();
+  a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>(); a.chosen = b->chosen.as<u8>();
   a.changed = flag;
   a.dirty_in = dirty_in; a.dirty_out = dirty_out;
+  {
+    static const u32 coarse_sweeps = getenv("SCALCE_JACOBI_COARSE") ? (u32)atoi(getenv("SCALCE_JACOBI_COARSE")) : 8u;
+    a.coarse = b->sweep_no < coarse_sweeps ? 1u : 0u;
+    b->sweep_no++;
+  }
   HIP_TRY(c, hipMemsetAsync(dirty_out, 0xFF, sizeof(u32) * nb1, s));
   LAUNCH(jacobi_k, cdiv(ntie, 256), 256, 0, s, a);
   b->dirty_cur ^= 1;
-  LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, b->seg.as<u32>(), dirty_out, b->chosen.as<u8>(), G, b->Gseg.as<u32>(), b->counts.as<u64>());
+  LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, b->seg.as<u32>() + (nb1 + 2), dirty_out, b->chosen.as<u8>(), G, b->seg.as<u32>() + 2 * (nb1 + 2),
+         b->counts.as<u64>());
   return SCALCE_OK;
 }
 
