@@ -237,6 +237,7 @@ enum {
 };
 int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes);
 uint64_t scalce_batch_reads(const scalce_batch *b);
+int scalce_batch_params(const scalce_batch *b, scalce_params *out);  /* the parameters it was created with */
 /* measurement hook for bench.py: accumulated device time (ms, hipEvent) and launch count of
  * stage `which` (0 ingest,1 quality,2 tokenize,3 order,4 emit,5 entropy) since the last reset */
 int scalce_batch_stage_ms(scalce_batch *b, int which, float *ms, int *launches);

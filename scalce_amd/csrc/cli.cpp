@@ -13,6 +13,7 @@
 #include <hip/hip_runtime_api.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <sys/time.h>
 #include <zlib.h>
@@ -59,6 +60,7 @@ struct Options {
   bool paired = false, use_names = true, no_ac = false, decompress = false;
   uint64_t bucket_set_size = 4ull << 30;  // main.cpp:68
   std::string out, library, patterns, temp = "__temp__", patterns_bin;
+  int gpus = 1;                           // --gpus N: one process per GPU, ONE archive (plain-text input, -c no)
   int container = 1;                      // 0 plain, 1 gzip (main.cpp:181-184 at -T 1)
 };
 
@@ -81,6 +83,8 @@ static const char *HELP_TEXT =
     "  -t, --temp-directory STR    accepted for compatibility (nothing is spilled)\n"
     "  -S, --split-reads INT       decompression: reads per output part\n"
     "  -d, --decompress    -v, --version    -h, --help\n"
+    "      --gpus N                compress on N GPUs, one process each, into ONE archive that is byte for byte the archive of\n"
+    "                              one GPU (and of the reference at -T 1 with the same -B); input: one plain FASTQ file (pair), -c no\n"
     "core table: --patterns-bin FILE or $SCALCE_PATTERNS or patterns.bin next to the executable\n";
 
 // ---- small I/O helpers ------------------------------------------------------------------------------
@@ -513,6 +517,345 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   return 0;
 }
 
+// ---- compress on several GPUs ---------------------------------------------------------------------------------
+// One process per GPU (forked before anything touches a GPU), rank r takes the r-th part of the input file, the ranks talk
+// RCCL (scalce_sharded_compress) and every rank writes its pieces of the ONE archive with pwrite at the offsets the
+// run-wide bucket counts give.  SCALCE_COMM=shm makes all ranks share GPU 0 over the shared-memory rehearsal transport.
+static uint64_t count_newlines(int fd, uint64_t a, uint64_t b, int threads) {
+  std::atomic<uint64_t> total{0};
+  const uint64_t step = 64u << 20;
+  std::atomic<uint64_t> next{a};
+  auto work = [&]() {
+    std::vector<char> buf(8u << 20);
+    for (uint64_t at; (at = next.fetch_add(step)) < b;) {
+      const uint64_t end = std::min(b, at + step);
+      uint64_t n = 0;
+      for (uint64_t p = at; p < end;) {
+        const ssize_t k = ::pread(fd, buf.data(), (size_t)std::min<uint64_t>(buf.size(), end - p), (off_t)p);
+        if (k <= 0) FAIL("Read error\n");
+        const char *q = buf.data(), *e = q + k;
+        while ((q = static_cast<const char *>(memchr(q, '\n', (size_t)(e - q))))) { n++; q++; }
+        p += (uint64_t)k;
+      }
+      total += n;
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; t++) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+  return total;
+}
+// byte offset behind the `skip`-th newline at or after `from`
+static uint64_t skip_lines(int fd, uint64_t from, uint64_t size, uint64_t skip) {
+  std::vector<char> buf(8u << 20);
+  uint64_t p = from;
+  while (skip && p < size) {
+    const ssize_t k = ::pread(fd, buf.data(), (size_t)std::min<uint64_t>(buf.size(), size - p), (off_t)p);
+    if (k <= 0) FAIL("Read error\n");
+    const char *q = buf.data(), *e = q + k;
+    while (skip && (q = static_cast<const char *>(memchr(q, '\n', (size_t)(e - q))))) { skip--; q++; }
+    if (!skip) return p + (uint64_t)(q - buf.data());
+    p += (uint64_t)k;
+  }
+  return p;
+}
+static void pwrite_all(int fd, const void *src, size_t n, uint64_t off) {
+  const uint8_t *p = static_cast<const uint8_t *>(src);
+  while (n) {
+    const ssize_t k = ::pwrite(fd, p, n, (off_t)off);
+    if (k <= 0) FAIL("write failed\n");
+    p += k; n -= (size_t)k; off += (uint64_t)k;
+  }
+}
+
+static int rank_main(const Options &o, const std::vector<std::string> &files, const char *argv0, int rank, int world, const std::string &tag) {
+  const bool shm = getenv("SCALCE_COMM") && !strcmp(getenv("SCALCE_COMM"), "shm");
+  const int device = shm ? 0 : rank;
+  const int nm = o.paired ? 2 : 1;
+  const double t0 = now();
+  scalce_ctx *ctx = nullptr;
+  if (scalce_ctx_create(device, &ctx)) FAIL("%s\n", scalce_last_error(ctx));
+  bool is_text = false;
+  std::vector<uint8_t> table = load_core_table(o, argv0, is_text);
+  if (is_text) SCOK(ctx, scalce_patterns_load_text(ctx, (const char *)table.data(), table.size()));
+  else SCOK(ctx, scalce_patterns_load_bin(ctx, table.data(), table.size()));
+  // communicator
+  scalce_comm *comm = nullptr;
+  if (shm) {
+    if (scalce_comm_create_shm(device, world, rank, ("/scalce_cli_" + tag).c_str(), 1ull << 30, &comm)) FAIL("%s\n", scalce_comm_error(comm));
+  } else {
+    const std::string idfile = o.out + ".rcclid." + tag;
+    uint8_t id[SCALCE_COMM_ID_BYTES];
+    if (rank == 0) {
+      if (scalce_comm_unique_id(id)) FAIL("RCCL is not available\n");
+      FILE *f = fopen((idfile + ".tmp").c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) FAIL("Cannot write %s\n", idfile.c_str());
+      fclose(f);
+      rename((idfile + ".tmp").c_str(), idfile.c_str());
+    } else {
+      FILE *f = nullptr;
+      for (int tries = 0; tries < 60000 && !(f = fopen(idfile.c_str(), "rb")); tries++) usleep(1000);
+      if (!f || fread(id, 1, sizeof id, f) != sizeof id) FAIL("rank 0 did not publish the RCCL id\n");
+      fclose(f);
+    }
+    if (scalce_comm_create_rccl(device, world, rank, id, &comm)) FAIL("%s\n", scalce_comm_error(comm));
+    scalce_comm_barrier(comm, nullptr);
+    if (rank == 0) unlink(idfile.c_str());
+  }
+  // quality model: the first records of the FILE, the same on every rank (get_quality_stats, compress.cpp:761)
+  scalce_params p;
+  scalce_params_default(&p);
+  p.paired = o.paired; p.use_names = o.use_names; p.no_ac = o.no_ac; p.bucket_set_size = o.bucket_set_size;
+  std::string path[2] = {files[0], files[0]};
+  if (o.paired && !second_file(files[0], path[1])) FAIL("Cannot get file name for paired end for file %s. File should contain character 1.\n", files[0].c_str());
+  int fd[2] = {-1, -1};
+  uint64_t fsize[2] = {0, 0};
+  for (int m = 0; m < nm; m++) {
+    MateSource src;
+    src.files.push_back(path[m]);
+    src.fill_peek(o.sample);
+    if (!src.all_plain) FAIL("--gpus needs plain (not gzip) input: the file is split by byte ranges\n");
+    int32_t qhist[128];
+    int rl = 0;
+    sample_stats(src.peek, o.sample, qhist, rl);
+    scalce_qmap_init(&p.qmap[m], qhist, o.lossy);
+    p.read_len[m] = rl;
+    fd[m] = ::open(path[m].c_str(), O_RDONLY);
+    struct stat st;
+    if (fd[m] < 0 || fstat(fd[m], &st) != 0) FAIL("Cannot read file %s\n", path[m].c_str());
+    fsize[m] = (uint64_t)st.st_size;
+    if (rank == 0) LOG("\tPaired end #%d, quality offset: %d\n\t               read length: %d\n", m + 1, p.qmap[m].offset, rl);
+  }
+  if (p.read_len[0] <= 0) FAIL("Cannot determine the read length of %s\n", files[0].c_str());
+  // ---- this rank's records: line-aligned byte ranges, line counts of everybody, then cuts at multiples of four lines
+  hipStream_t s = nullptr;
+  HIPOK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  uint64_t *d_io = nullptr;
+  HIPOK(hipMalloc(reinterpret_cast<void **>(&d_io), sizeof(uint64_t) * (64 + 64 * 4)));
+  uint64_t lo[2], hi[2];
+  std::vector<uint64_t> K;  // rank r starts at record K[r], in every mate
+  for (int m = 0; m < nm; m++) {
+    auto line_start = [&](int r) -> uint64_t {  // first line start at or behind the r-th N-th of the file
+      if (r <= 0) return 0;
+      if (r >= world) return fsize[m];
+      const uint64_t at = fsize[m] / (uint64_t)world * (uint64_t)r;
+      return at ? skip_lines(fd[m], at - 1, fsize[m], 1) : 0;
+    };
+    const uint64_t a = line_start(rank), b = line_start(rank + 1);
+    uint64_t mine[2] = {count_newlines(fd[m], a, b, std::max(1, std::min(g_threads, 16))), a};
+    std::vector<uint64_t> all((size_t)world * 2);
+    HIPOK(hipMemcpy(d_io, mine, sizeof mine, hipMemcpyHostToDevice));
+    if (scalce_comm_all_gather(comm, d_io, d_io + 64, sizeof mine, s)) FAIL("%s\n", scalce_comm_error(comm));
+    HIPOK(hipStreamSynchronize(s));
+    HIPOK(hipMemcpy(all.data(), d_io + 64, all.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> first_line(world + 1, 0);  // run-wide line number at which every tentative range begins
+    for (int r = 0; r < world; r++) first_line[r + 1] = first_line[r] + all[2 * r];
+    if (first_line[world] % 4) FAIL("%s has %llu lines: not a multiple of 4\n", path[m].c_str(), (unsigned long long)first_line[world]);
+    if (m == 1 && first_line[world] != 4 * K[world]) FAIL("mates have different record counts\n");
+    // rank r starts at record K_r = ceil(first line of mate 1's r-th range / 4): the same record in every mate
+    if (m == 0) { K.assign(world + 1, 0); for (int r = 0; r <= world; r++) K[r] = (first_line[r] + 3) / 4; }
+    auto offset_of_line = [&](uint64_t line) -> uint64_t {
+      if (line >= first_line[world]) return fsize[m];
+      int r = 0;
+      while (r + 1 < world && first_line[r + 1] <= line) r++;
+      return skip_lines(fd[m], all[2 * r + 1], fsize[m], line - first_line[r]);
+    };
+    lo[m] = offset_of_line(4 * K[rank]);
+    hi[m] = offset_of_line(4 * K[rank + 1]);
+  }
+  // ---- the piece into HBM
+  uint8_t *d_text[2] = {nullptr, nullptr};
+  {
+    const size_t CH = 256u << 20;
+    uint8_t *pin[2];
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; i++) { HIPOK(hipHostMalloc(reinterpret_cast<void **>(&pin[i]), CH, hipHostMallocDefault)); HIPOK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)); }
+    for (int m = 0; m < nm; m++) {
+      const uint64_t n = hi[m] - lo[m];
+      HIPOK(hipMalloc(reinterpret_cast<void **>(&d_text[m]), n + 256));
+      MateSource src;  // (parallel pread into the pinned chunk)
+      src.fd = fd[m];
+      src.fpos = lo[m];
+      uint64_t done = 0;
+      for (int i = 0; done < n; i ^= 1) {
+        HIPOK(hipEventSynchronize(ev[i]));
+        const uint64_t k = std::min<uint64_t>(CH, n - done);
+        uint64_t got = 0;
+        while (got < k) { const int64_t r = src.read_plain(pin[i] + got, k - got); if (r <= 0) FAIL("Read error\n"); got += (uint64_t)r; }
+        HIPOK(hipMemcpyAsync(d_text[m] + done, pin[i], k, hipMemcpyHostToDevice, s));
+        HIPOK(hipEventRecord(ev[i], s));
+        done += k;
+      }
+      src.fd = -1;
+    }
+    HIPOK(hipStreamSynchronize(s));
+    for (int i = 0; i < 2; i++) { hipHostFree(pin[i]); hipEventDestroy(ev[i]); }
+  }
+  const double t1 = now();
+  // ---- the sharded run
+  scalce_batch *b = nullptr;
+  const uint64_t rows = (hi[0] - lo[0]) / (2 * (uint64_t)p.read_len[0] + 7) + 64;
+  SCOK(ctx, scalce_batch_create(ctx, &p, rows + rows / 3, std::max(hi[0] - lo[0], nm == 2 ? hi[1] - lo[1] : 0) + 256, &b));
+  scalce_shard_result res;
+  memset(&res, 0, sizeof res);
+  if (scalce_sharded_compress(comm, ctx, b, d_text[0], hi[0] - lo[0], nm == 2 ? d_text[1] : nullptr, nm == 2 ? hi[1] - lo[1] : 0, 0, s, nullptr, &res))
+    exit(1);
+  for (int m = 0; m < nm; m++) hipFree(d_text[m]);
+  const double t2 = now();
+  // ---- every rank writes its pieces of the archive
+  const uint32_t nb1 = res.nb1;
+  std::vector<int32_t> bucket_pattern(nb1);
+  int32_t nst = 0, nbk = 0;
+  scalce_patterns_describe_host(table.data(), table.size(), is_text ? 1 : 0, bucket_pattern.data(), nb1, &nst, &nbk);
+  std::vector<uint64_t> recsz(nb1), Cg(nb1, 0);
+  const int L0 = p.read_len[0], sz_meta = L0 > 255 ? 2 : 1;
+  for (uint32_t k = 0; k < nb1; k++) {
+    const int lv = bucket_pattern[k] == SCALCE_ROOT_CORE ? 0 : scalce_pattern_length(ctx, bucket_pattern[k]);
+    recsz[k] = (uint64_t)((L0 - lv + 3) / 4 + sz_meta);
+    for (int r = 0; r < world; r++) Cg[k] += res.counts[(size_t)r * nb1 + k];
+  }
+  const uint8_t magic[8] = {'s', 'c', 'a', 'l', 'c', 'e', '2', '2'};
+  const uint64_t N = res.reads_total;
+  char fn[4096];
+  auto open_out = [&](const char *ext, int m) {
+    snprintf(fn, sizeof fn, "%s_%d.scalce%s", o.out.c_str(), m + 1, ext);
+    if (rank == 0) { const int f = ::open(fn, O_CREAT | O_TRUNC | O_WRONLY, 0644); if (f < 0) FAIL("Cannot create %s\n", fn); ::close(f); }
+    scalce_comm_barrier(comm, s);
+    const int f = ::open(fn, O_WRONLY);
+    if (f < 0) FAIL("Cannot open %s\n", fn);
+    return f;
+  };
+  auto host_copy = [&](int which, int m) { return fetch(ctx, b, which, m); };
+  for (int m = 0; m < nm; m++) {
+    {  // .scalcer
+      const int f = open_out("r", m);
+      if (rank == 0) { const int32_t noac = o.no_ac, len32 = p.read_len[m]; uint8_t h[16]; memcpy(h, magic, 8); memcpy(h + 8, &noac, 4); memcpy(h + 12, &len32, 4); pwrite_all(f, h, 16, 0); }
+      std::vector<uint8_t> mine = host_copy(SCALCE_OUT_READS, m);
+      if (m == 0) {
+        uint64_t base = 16, local = 0;
+        for (uint32_t k = 0; k < nb1; k++) {
+          if (!Cg[k]) continue;
+          if (rank == 0) { uint8_t h[12]; const int32_t core = bucket_pattern[k]; memcpy(h, &core, 4); memcpy(h + 4, &Cg[k], 8); pwrite_all(f, h, 12, base); }
+          uint64_t before = 0;
+          for (int r = 0; r < rank; r++) before += res.counts[(size_t)r * nb1 + k];
+          const uint64_t c = res.counts[(size_t)rank * nb1 + k];
+          if (c) { pwrite_all(f, mine.data() + local + 12, c * recsz[k], base + 12 + before * recsz[k]); local += 12 + c * recsz[k]; }
+          base += 12 + Cg[k] * recsz[k];
+        }
+      } else {  // mate 2: bare rows in mate 1's order
+        const uint64_t w = (uint64_t)(p.read_len[1] + 3) / 4;
+        uint64_t first = 0, local = 0;
+        for (uint32_t k = 0; k < nb1; k++) {
+          uint64_t before = 0;
+          for (int r = 0; r < rank; r++) before += res.counts[(size_t)r * nb1 + k];
+          const uint64_t c = res.counts[(size_t)rank * nb1 + k];
+          if (c) { pwrite_all(f, mine.data() + local * w, c * w, 16 + (first + before) * w); local += c; }
+          first += Cg[k];
+        }
+      }
+      ::close(f);
+    }
+    {  // .scalcen (mate 2 repeats mate 1's names, compress.cpp:450-454)
+      const int f = open_out("n", m);
+      const uint8_t un = o.use_names ? 1 : 0;
+      if (rank == 0) { uint8_t h[9]; memcpy(h, magic, 8); h[8] = un; pwrite_all(f, h, 9, 0); }
+      if (o.use_names) {
+        std::vector<uint8_t> mine = host_copy(SCALCE_OUT_NAMES, 0);
+        uint64_t base = 9, local = 0;
+        for (uint32_t k = 0; k < nb1; k++) {
+          uint64_t before = 0, all = 0;
+          for (int r = 0; r < world; r++) { if (r < rank) before += res.name_bytes[(size_t)r * nb1 + k]; all += res.name_bytes[(size_t)r * nb1 + k]; }
+          const uint64_t c = res.name_bytes[(size_t)rank * nb1 + k];
+          if (c) { pwrite_all(f, mine.data() + local, c, base + before); local += c; }
+          base += all;
+        }
+      } else if (rank == 0) {
+        const int64_t z = 0;
+        pwrite_all(f, &z, 8, 9);
+        pwrite_all(f, o.library.data(), o.library.size(), 17);
+      }
+      ::close(f);
+    }
+    {  // .scalceq
+      const int f = open_out("q", m);
+      uint64_t base = 16;
+      if (rank == 0) { const int64_t phred = p.qmap[0].offset; uint8_t h[16]; memcpy(h, magic, 8); memcpy(h + 8, &phred, 8); pwrite_all(f, h, 16, 0); }
+      if (!o.no_ac) {
+        if (rank == 0) {
+          std::vector<uint8_t> tb = host_copy(SCALCE_OUT_TABLE, m);
+          pwrite_all(f, tb.data(), tb.size(), 16);
+          const uint64_t total = N * (uint64_t)p.read_len[m];
+          pwrite_all(f, &total, 8, 16 + tb.size());
+        }
+        base = 16 + 2048000 + 8;
+        uint64_t before = 0;
+        for (int r = 0; r < rank; r++) before += res.coded_bytes[m][r];
+        std::vector<uint8_t> mine = host_copy(SCALCE_OUT_QUAL, m);
+        pwrite_all(f, mine.data(), mine.size(), base + before);
+      } else {  // -A: the raw q' rows, bucket by bucket in rank order (compress.cpp:389-390)
+        std::vector<uint8_t> mine = host_copy(SCALCE_OUT_QSTREAM, m);
+        const uint64_t w = (uint64_t)p.read_len[m];
+        uint64_t first = 0, local = 0;
+        for (uint32_t k = 0; k < nb1; k++) {
+          uint64_t before = 0;
+          for (int r = 0; r < rank; r++) before += res.counts[(size_t)r * nb1 + k];
+          const uint64_t c = res.counts[(size_t)rank * nb1 + k];
+          if (c) { pwrite_all(f, mine.data() + local * w, c * w, 16 + (first + before) * w); local += c; }
+          first += Cg[k];
+        }
+      }
+      ::close(f);
+    }
+  }
+  scalce_comm_barrier(comm, s);
+  const double t3 = now();
+  if (rank == 0) {
+    LOG("\tDone with file %s, %llu reads found\n", files[0].c_str(), (unsigned long long)N);
+    LOG("Statistics:\n\tTotal number of reads: %llu\n\tRead length: first end %d\n", (unsigned long long)N, p.read_len[0]);
+    if (o.paired) LOG("\t             second end %d\n", p.read_len[1]);
+    uint64_t unb = Cg[nb1 - 1];
+    LOG("\tUnbucketed reads count: %llu, bucketed percentage %.2lf\n", (unsigned long long)unb, N ? 100.0 * (double)(N - unb) / (double)N : 0.0);
+    LOG("\tLossy percentage: %d\n", o.lossy);
+    LOG("\tGPUs: %d, spill chunks: %u, tie-break rounds: %u\n", world, res.chunks_total, res.rounds);
+    LOG("\tTime elapsed: %.2f s (split + read + upload %.2f, sharded hot path %.2f, download + write %.2f)\n", t3 - t0, t1 - t0, t2 - t1, t3 - t2);
+  }
+  scalce_shard_result_free(&res);
+  scalce_batch_destroy(b);
+  scalce_comm_destroy(comm);
+  scalce_ctx_destroy(ctx);
+  return 0;
+}
+
+static int multi_gpu_compress(const Options &o, const std::vector<std::string> &files, const char *argv0) {
+  if (o.container != 0) FAIL("--gpus writes the archive in pieces at computed offsets: use -c no\n");
+  if (files.size() != 1) FAIL("--gpus takes one input file (and its mate with -r)\n");
+  if (o.gpus > 64) FAIL("--gpus: at most 64\n");
+  LOG("Preprocessing FASTQ files ...\n");
+  char tag[64];
+  snprintf(tag, sizeof tag, "%d_%ld", (int)getpid(), (long)time(nullptr));
+  {
+    const int hw = (int)std::thread::hardware_concurrency();
+    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(32, hw / std::max(1, o.gpus)));
+  }
+  std::vector<pid_t> kids;
+  for (int r = 0; r < o.gpus; r++) {
+    const pid_t pid = fork();
+    if (pid < 0) FAIL("fork failed\n");
+    if (pid == 0) _exit(rank_main(o, files, argv0, r, o.gpus, tag));
+    kids.push_back(pid);
+  }
+  int bad = 0;
+  for (pid_t k : kids) {
+    int st = 0;
+    waitpid(k, &st, 0);
+    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+  }
+  if (bad) { fprintf(stderr, "(ERROR) a rank failed\n"); return 1; }
+  LOG("Done!\n");
+  return 0;
+}
+
 // ---- decompress ------------------------------------------------------------------------------------------
 static std::string scalce_name(std::string path, char c) {  // get_file_name, decompress.cpp:72-77
   size_t p = path.rfind(".scalce");
@@ -636,7 +979,7 @@ int main(int argc, char **argv) {
                                      {"bucket-set-size", 1, 0, 'B'}, {"paired-end", 0, 0, 'r'}, {"skip-names", 1, 0, 'n'},
                                      {"split-reads", 1, 0, 'S'}, {"fasta", 0, 0, 'f'}, {"threads", 1, 0, 'T'},
                                      {"version", 0, 0, 'v'}, {"no-arithmetic", 0, 0, 'A'}, {"patterns-bin", 1, 0, 1000},
-                                     {0, 0, 0, 0}};
+                                     {"gpus", 1, 0, 1001}, {0, 0, 0, 0}};
   int opt;
   while ((opt = getopt_long(argc, argv, "vhp:T:dc:o:fs:t:B:rQAn:P:S:", long_opt, 0)) != -1) {
     switch (opt) {
@@ -669,6 +1012,7 @@ int main(int argc, char **argv) {
       case 'o': o.out = optarg; break;
       case 'n': o.use_names = false; o.library = optarg; break;
       case 1000: o.patterns_bin = optarg; break;
+      case 1001: o.gpus = atoi(optarg); break;
       default: fputs(HELP_TEXT, stdout); return 0;
     }
   }
@@ -689,6 +1033,7 @@ int main(int argc, char **argv) {
       if (stat(f2.c_str(), &st) != 0) FAIL("File %s does not exist or it is not accessible.\n", f2.c_str());
     }
   }
+  if (o.gpus > 1 && !o.decompress) return multi_gpu_compress(o, files, argv[0]);  // forks before anything touches a GPU
   scalce_ctx *ctx = nullptr;
   if (scalce_ctx_create(0, &ctx)) FAIL("%s\n", scalce_last_error(ctx));
   bool is_text = false;

@@ -1778,6 +1778,11 @@ extern "C" int scalce_batch_finish(scalce_batch *b, void *stream) {
 }
 
 extern "C" uint64_t scalce_batch_reads(const scalce_batch *b) { return b ? b->N : 0; }
+extern "C" int scalce_batch_params(const scalce_batch *b, scalce_params *out) {
+  if (!b || !out) return SCALCE_ERR_ARG;
+  *out = b->p;
+  return SCALCE_OK;
+}
 
 extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes) {
   if (!b || !d_ptr || !nbytes || mate < 0 || mate >= b->nm) return SCALCE_ERR_ARG;

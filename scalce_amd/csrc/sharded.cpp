@@ -373,7 +373,9 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     const u64 N = scalce_batch_reads(b);
     // ---- 4. run-wide quality model: trigrams across the ORIGINAL piece boundaries, all-reduce, scaling
     uint32_t *d_table = nullptr;
-    if (L[0]) {
+    scalce_params bp;
+    SH_RC(ctx, scalce_batch_params(b, &bp));
+    if (L[0] && !bp.no_ac) {  // (-A: no statistics, the q' rows are stored as they are)
       std::vector<uint8_t> ed(8, 0);
       memcpy(ed.data(), edge, 8);
       uint8_t *d_e = reinterpret_cast<uint8_t *>(d_small);

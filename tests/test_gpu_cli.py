@@ -209,3 +209,33 @@ def test_cli_stream_errors(tmp_path, monkeypatch):
     r = subprocess.run([CLI, "-c", "no", "-o", str(tmp_path / "o"), str(tmp_path / "cut_1.fq"), "--patterns-bin", PBIN],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "(ERROR)" in r.stderr, r.stderr[-300:]
+
+
+@pytest.mark.parametrize("case", ["se_3", "pe_2_uneven_names", "noac_nonames_4"])
+def test_cli_gpus_writes_the_archive_of_one_gpu(case, tmp_path, monkeypatch):
+    """scalce --gpus N: N processes (here sharing the one GPU over the shared-memory transport), each takes a byte range of
+    the input, the ranks write ONE archive with pwrite at computed offsets -- the oracle's archive for the same -B."""
+    monkeypatch.setenv("SCALCE_COMM", "shm")
+    paired = case.startswith("pe")
+    world = int(case.split("_")[1]) if not case.startswith("noac") else 4
+    n, L = 60000, 100
+    b1, q1 = synth.reads_and_quals(n, L, seed=71, n_frac=0.003, dup_frac=0.1)
+    flags = ["-B", "1M"]
+    if paired:
+        b2, q2 = synth.reads_and_quals(n, L, seed=72)
+        open(tmp_path / "in_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1, prefix="p.", suffix="/1"))
+        recs = [b"@p.%d/2 " % i + b"c" * (i % 37) + b"\n" + b2[i].tobytes() + b"\n+\n" + q2[i].tobytes() + b"\n" for i in range(n)]
+        open(tmp_path / "in_2.fq", "wb").write(b"".join(recs))
+        flags.append("-r")
+    else:
+        open(tmp_path / "in_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1))
+    if case.startswith("noac"):
+        flags += ["-A", "-n", "lib"]
+    r = run_cli(*flags, "-c", "no", "--gpus", world, "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    assert f"GPUs: {world}" in r.stderr
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc", *[("1048576" if f == "1M" else f) for f in flags])
+    for m in ((1, 2) if paired else (1,)):
+        for ext in "nrq":
+            a = open(tmp_path / f"orc_{m}.scalce{ext}", "rb").read()
+            h = open(tmp_path / f"hip_{m}.scalce{ext}", "rb").read()
+            assert a == h, f"{case} .scalce{ext} mate {m}: {len(h)} vs {len(a)} bytes"
