@@ -105,6 +105,38 @@ static std::vector<uint8_t> read_maybe_gz(const std::string &path) {  // IO_GZIP
   gzclose(f);
   return out;
 }
+static int g_threads_io();
+// plain files with several threads (pread), gzip through zlib
+static std::vector<uint8_t> read_file_fast(const std::string &path) {
+  int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) FAIL("Cannot read file %s\n", path.c_str());
+  uint8_t mg[2] = {0, 0};
+  struct stat st;
+  if (::pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1F && mg[1] == 0x8B) { ::close(fd); return read_maybe_gz(path); }
+  if (fstat(fd, &st) != 0) FAIL("Cannot read file %s\n", path.c_str());
+  std::vector<uint8_t> out((size_t)st.st_size);
+  const uint64_t n = out.size(), SL = 64u << 20;
+  std::atomic<uint64_t> next{0};
+  std::atomic<bool> bad{false};
+  auto work = [&]() {
+    for (uint64_t a; (a = next.fetch_add(SL)) < n;) {
+      uint64_t done = a;
+      const uint64_t b = std::min(n, a + SL);
+      while (done < b) {
+        const ssize_t k = ::pread(fd, out.data() + done, (size_t)(b - done), (off_t)done);
+        if (k <= 0) { bad = true; return; }
+        done += (uint64_t)k;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < g_threads_io(); t++) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+  ::close(fd);
+  if (bad) FAIL("Read error on %s\n", path.c_str());
+  return out;
+}
 static bool second_file(const std::string &p, std::string &out) {  // get_second_file, const.cpp:51-64
   out = p;
   for (int i = (int)out.size() - 1; i >= 0; i--)
@@ -117,6 +149,7 @@ static bool second_file(const std::string &p, std::string &out) {  // get_second
 // reference's reader (gzread, decompress.cpp:99-113) and ours accept alike (once the hot path is on
 // the GPU, single-threaded deflate of .scalcer/.scalcen is what the wall clock of a run is made of).
 static int g_threads = 1;
+static int g_threads_io() { return std::max(1, std::min(g_threads, 8)); }
 struct OutFile {
   bool gz = false;
   FILE *f = nullptr;
@@ -216,7 +249,9 @@ struct Downloader {
     const void *d = nullptr;
     uint64_t n = 0;
     SCOK(ctx, scalce_batch_output(b, which, mate, &d, &n));
-    const uint8_t *src = static_cast<const uint8_t *>(d);
+    range_to_file(static_cast<const uint8_t *>(d), n, f);
+  }
+  void range_to_file(const uint8_t *src, uint64_t n, OutFile &f) {
     const uint64_t nslices = (n + SLICE - 1) / SLICE;
     auto start = [&](uint64_t i) {
       const uint64_t off = i * SLICE, k = std::min<uint64_t>(SLICE, n - off);
@@ -882,9 +917,9 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
   int32_t len[2] = {0, 0}, no_ac = 0;
   int64_t phred[2] = {0, 0};
   for (int m = 0; m < nm; m++) {
-    R[m].v = read_maybe_gz(scalce_name(base[m], 'r'));  // container sniffing: zlib reads plain and gzip alike
-    Nn[m].v = read_maybe_gz(scalce_name(base[m], 'n'));
-    Q[m].v = read_maybe_gz(scalce_name(base[m], 'q'));
+    R[m].v = read_file_fast(scalce_name(base[m], 'r'));  // container sniffing (decompress.cpp:99-113): gzip magic or plain
+    Nn[m].v = read_file_fast(scalce_name(base[m], 'n'));
+    Q[m].v = read_file_fast(scalce_name(base[m], 'q'));
     uint8_t mg[8];
     if (R[m].read(mg, 8) != 8 || memcmp(mg, "scalce2", 7)) FAIL("%s is not a scalce archive\n", base[m].c_str());
     no_ac = 0;
@@ -943,9 +978,8 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
                                    phred[m], npay, nbytes_names, library.c_str(), o.paired ? '1' + m : 0, (uint8_t *)d_text, cap,
                                    &text_bytes, o.split ? roff.data() : nullptr, nullptr));
     hipFree(d_q);
-    std::vector<char> text((size_t)text_bytes);
-    HIPOK(hipMemcpy(text.data(), d_text, text_bytes, hipMemcpyDeviceToHost));
-    hipFree(d_text);
+    // the text comes down in slices through two pinned buffers while the previous slice is being written
+    Downloader down;
     char fn[4096];
     int part = 1;
     auto part_name = [&](int F) {
@@ -960,11 +994,12 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
       OutFile fo;
       part_name(m);
       fo.open(fn, false);
-      fo.write(text.data() + b0, (size_t)(b1 - b0));
+      down.range_to_file(static_cast<const uint8_t *>(d_text) + b0, b1 - b0, fo);
       fo.close();
       LOG("Created %s with %lld reads\n", fn, (long long)(k1 - k0));
       if (!nrec) break;
     }
+    hipFree(d_text);
   }
   LOG("\tTime elapsed: %.2f s\n", now() - t0);
   return 0;

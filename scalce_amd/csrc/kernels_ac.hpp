@@ -1081,6 +1081,23 @@ __global__ __launch_bounds__(256) void ac_frame_k(const u8 *blocks, u64 stride, 
   for (u64 i = i0; i < i0 + 16 && i < sz; i++) dst[4 + i] = src[i];
 }
 
+// follows the [u32 size][bytes] chain of a framed stream: out[2i] = byte offset of block i's data, out[2i+1] = its size;
+// out[2 nblk] != 0 when the stream ends before `nblk` frames do
+__global__ void ac_frame_walk_k(const u8 *in, u64 nbytes, u32 nblk, u64 *out) {
+  if (threadIdx.x || blockIdx.x) return;
+  u64 pos = 0;
+  u64 bad = 0;
+  for (u32 i = 0; i < nblk; i++) {
+    if (bad || pos + 4 > nbytes) { bad = 1; out[2 * (u64)i] = 0; out[2 * (u64)i + 1] = 0; continue; }
+    const u32 sz = (u32)in[pos] | ((u32)in[pos + 1] << 8) | ((u32)in[pos + 2] << 16) | ((u32)in[pos + 3] << 24);
+    out[2 * (u64)i] = pos + 4;
+    out[2 * (u64)i + 1] = sz;
+    pos += 4 + (u64)sz;
+    if (pos > nbytes) bad = 1;
+  }
+  out[2 * (u64)nblk] = bad;
+}
+
 // ---- decoder (next row): ac_decoder::read_single, arithmetic.cpp:196-244 -------------------
 // One wavefront per block.  The reference divides by the current range to get `count` and then searches the
 // symbol linearly (:199-209).  Here the 64 lanes evaluate the encoder's own interval bounds of all 80 symbols
