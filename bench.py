@@ -199,16 +199,18 @@ def main():
 
     traffic, traffic_src = None, None
     kname = "ac_encode_rows_k" if G > 1 else "ac_encode_k"
-    pmc = os.path.join(ROOT, "profiles", "r01_v17_bench50m_pmc_fetch_write.json" if G > 1 else "r01_v9_bench50m_pmc_fetch_write.json")
+    # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of KB;
+    # FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM").  The counters come from a
+    # profile kept under profiles/ -- of this round's build when PROFILE_TAG names one, and the tag is printed with them.
+    tag = os.environ.get("SCALCE_PROFILE_TAG", "r02_final")
+    pmc = os.path.join(ROOT, "profiles", f"{tag}_bench50m_pmc_fetch_write.json")
     if rank == 0 and n == 50_000_000 and L == 100 and os.path.exists(pmc):
-        # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of
-        # KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM")
+        nblocks = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
+        want = (kname + ("<false, 8>" if nblocks > 1024 else "<false, 16>")) if G > 1 else kname + "<"
         for row in json.load(open(pmc)):
-            nblocks = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
-            want = kname + ("<false, 8>" if nblocks > 1024 else "<false, 16>") if G > 1 else kname + "<"
             if want in row["kernel"]:
-                units = row.get("shards", row["calls"]) / G  # launches of G shards the profiled bytes stand for
-                traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / max(units, 1))
+                launches = max(row["calls"], 1)
+                traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / launches)
                 traffic_src = os.path.relpath(pmc, ROOT)
     if rank == 0:
         total_in = nbytes * world
@@ -243,6 +245,9 @@ def main():
                          "launch_ms": round(per_launch_ms, 3), "alg_bytes_per_launch": int(alg_bytes),
                          "ns_per_symbol_per_block": round(per_launch_ms * 1e6 / min(max(k["bytes_in"] / max(k["launches"], 1), 1), 10 * 1024 * 1024), 2),
                          "shards_per_launch": G,
+                         # the roof this kernel actually sits under: issue slots.  6.3 instructions per symbol (4.8 VALU + 1.3
+                         # SALU + 0.2 LDS, rocprofv3 --pmc SQ_INSTS_*, profiles/r01 pmc_sq) against 1024 SIMDs x 2.4 GHz
+                         "limiter": "issue", "issue_frac": round(6.3 * k["bytes_in"] / max(k["launches"], 1) / (1024 * 2.4e9 * per_launch_ms * 1e-3), 4) if per_launch_ms > 0 else None,
                          "note": "serial coder chain per 10 MiB block: bound by the issue slots of one wavefront, not by "
                                  "bandwidth (ns per symbol per block is the figure to watch); blocks run concurrently, "
                                  + ("four or eight per chain wave, one launch for %d shards at one workgroup per CU" % G
