@@ -1071,14 +1071,38 @@ struct AcFrameLen {
 };
 __global__ __launch_bounds__(256) void ac_frame_k(const u8 *blocks, u64 stride, const u32 *sizes, const u64 *dst_off,
                                                  u8 *out) {
+  // Block b's bytes go behind its size word at out + dst_off[b] + 4: any alignment.  Output words are produced aligned to
+  // 4 bytes from two neighbouring source words (funnel shift); the few bytes in front of the first aligned word, the size
+  // word and the tail are written byte by byte.  (One byte per store, as this kernel first was, ran at 1 TB/s.)
   const u32 b = blockIdx.y;
   const u32 sz = sizes[b];
   u8 *dst = out + dst_off[b];
-  const u8 *src = blocks + (u64)b * stride;
-  const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-  if (i0 == 0)
+  const u32 *src = reinterpret_cast<const u32 *>(blocks + (u64)b * stride);  // 16-byte aligned (stride is a multiple of 16)
+  u8 *data = dst + 4;
+  const u32 head = (u32)((4 - ((u64)data & 3)) & 3);       // data bytes in front of the first aligned output word
+  const u32 lead = head < sz ? head : sz;
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
     for (int k = 0; k < 4; k++) dst[k] = (u8)(sz >> (8 * k));
-  for (u64 i = i0; i < i0 + 16 && i < sz; i++) dst[4 + i] = src[i];
+    const u8 *sb = reinterpret_cast<const u8 *>(src);
+    for (u32 i = 0; i < lead; i++) data[i] = sb[i];
+  }
+  const u32 nwords = (sz - lead) >> 2;                      // aligned output words, word w holds source bytes lead + 4 w ..
+  const u32 sh = (lead & 3) * 8;
+  u32 *dw = reinterpret_cast<u32 *>(data + lead);
+  for (u32 w0 = (u32)(t * 4); w0 < nwords; w0 += gridDim.x * blockDim.x * 4) {
+    const u32 j = (lead >> 2) + w0;                         // source word that holds byte lead + 4 w0 (lead < 4: j = w0)
+    u32 sv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) sv[k] = src[j + k];         // the block buffer is padded beyond its 10 MiB
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (w0 + k < nwords) dw[w0 + k] = sh ? ((sv[k] >> sh) | (sv[k + 1] << (32 - sh))) : sv[k];
+  }
+  if (t == 1) {                                             // the tail behind the last aligned word
+    const u8 *sb = reinterpret_cast<const u8 *>(src);
+    for (u32 i = lead + 4 * nwords; i < sz; i++) data[i] = sb[i];
+  }
 }
 
 // follows the [u32 size][bytes] chain of a framed stream: out[2i] = byte offset of block i's data, out[2i+1] = its size;

@@ -136,6 +136,9 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8 *t, u64 at, u64 n) {
   return (lo >> sh) | (hi << (32 - sh));
 }
 
+template <int PART, typename WordAt, typename ByteAt>
+__device__ __forceinline__ void unpack_record_at(const UnpackArgs &a, u64 r, u64 ns, u64 p0, u64 p1, u64 p2, u64 p3, const u8 *lut,
+                                                 WordAt word, ByteAt byte_at, u8 *qrow, bool qrow_aligned);
 // One record: bases -> 2-bit row (global), qualities -> q' (through `qrow`, LDS or global), name length.
 // `word(at)` returns the aligned little-endian 32-bit word that contains text byte `at & ~3`.
 // PART: 3 = the whole record; 1 = bases + name only, 2 = qualities only (unpack_tiled_k gives a record to two threads of
@@ -144,7 +147,13 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8 *t, u64 at, u64 n) {
 template <int PART = 3, typename WordAt, typename ByteAt>
 __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const u8 *lut, WordAt word, ByteAt byte_at, u8 *qrow,
                                               bool qrow_aligned) {
-  const u64 p0 = a.line_end[4 * r], p1 = a.line_end[4 * r + 1], p2 = a.line_end[4 * r + 2], p3 = a.line_end[4 * r + 3];
+  unpack_record_at<PART>(a, r, r ? a.line_end[4 * r - 1] + 1 : 0, a.line_end[4 * r], a.line_end[4 * r + 1], a.line_end[4 * r + 2],
+                         a.line_end[4 * r + 3], lut, word, byte_at, qrow, qrow_aligned);
+}
+// ns = where the record's name line starts, p0 .. p3 = the newlines that end its four lines (text offsets)
+template <int PART, typename WordAt, typename ByteAt>
+__device__ __forceinline__ void unpack_record_at(const UnpackArgs &a, u64 r, u64 ns, u64 p0, u64 p1, u64 p2, u64 p3, const u8 *lut,
+                                                 WordAt word, ByteAt byte_at, u8 *qrow, bool qrow_aligned) {
   if (p1 - p0 - 1 != (u64)a.L || p3 - p2 - 1 != (u64)a.L) {
     if (PART & 1) {
       dev_fail(a.err, E_READLEN, r, (u32)(p1 - p0 - 1));
@@ -219,7 +228,6 @@ __device__ __forceinline__ void unpack_record(const UnpackArgs &a, u64 r, const 
   }
   if (a.mate == 0) {
     // output_name, names.cpp:55-57: characters after '@' up to the first space or the newline
-    const u64 ns = r ? a.line_end[4 * r - 1] + 1 : 0;
     u32 len = 0;
     if (a.use_names) {
       u64 i = ns + 1;
@@ -254,6 +262,10 @@ __global__ __launch_bounds__(256) void long_names_k(u64 nrec, const u8 *text, co
   if (n <= 15) return;
   const u64 src = (r ? line_end[4 * r - 1] + 1 : 0) + 1;  // behind the '@'
   for (u32 i = 0; i < n; i++) store[at + i] = text[src + i];
+}
+
+__global__ void last_record_end_k(const u64 *line_end, u64 nrec, u64 *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out = nrec ? line_end[4 * nrec - 1] + 1 : 0;
 }
 
 // direct form: every thread reads its record straight from global memory (fallback for long reads / huge names)
@@ -338,6 +350,128 @@ __global__ __launch_bounds__(2 * UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
   }
 }
 
+// ---- one pass over the text behind the count: line index, record structure and unpack fused ------------------------
+// index_write_k + unpack_tiled_k read the text twice more and keep a 32-byte line index per record in between.  For reads
+// of 16 .. 160 bases a workgroup instead takes a 32 KB tile of text (plus 1 KB: the records that start in the tile end
+// there) into LDS, finds the newlines in it, knows from the tile's line base (index_count_k + scan) which of them end name
+// lines, and unpacks the records that START in the tile straight from LDS.  Text read twice instead of three times, no
+// line index.  A record that does not end inside the overlap sets `slow` and the host falls back to the indexed kernels.
+constexpr u32 ING_TILE = 2 * IDX_TILE;   // 32 KB
+constexpr u32 ING_OVER = 1024;
+constexpr u32 ING_NLMAX = 4096;
+constexpr u32 ING_QCAP = ING_TILE / 2 + 2 * 160 + 64;
+constexpr int ING_THREADS = 512;
+struct IngestArgs {
+  UnpackArgs u;              // text, nbytes, nrec (records to take), L, stride, outputs (already offset to the piece's rows)
+  const u64 *tile_base;      // newlines in front of every IDX_TILE (exclusive scan of index_count_k)
+  u64 *consumed;             // text offset behind the last record taken
+  u32 *slow;                 // set when a record does not fit the overlap
+};
+__global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
+  __shared__ __attribute__((aligned(16))) u8 text[ING_TILE + ING_OVER + 32];
+  __shared__ u16 nl[ING_NLMAX];
+  __shared__ __attribute__((aligned(16))) u8 qt[ING_QCAP];
+  __shared__ u8 lut[128];
+  __shared__ u32 sm[8];
+  __shared__ u32 s_count[2];
+  const int tid = threadIdx.x;
+  const u64 t0 = (u64)blockIdx.x * ING_TILE;                       // text offset of the tile
+  const u64 avail = a.u.nbytes - t0;
+  const u32 len = (u32)(avail < ING_TILE + ING_OVER ? avail : ING_TILE + ING_OVER);
+  if (tid < 128) lut[tid] = a.u.qlut[tid];
+  for (u32 i = (u32)tid * 16; i < len + 8; i += ING_THREADS * 16) {
+    uint4 v;
+    if (t0 + i + 16 <= a.u.nbytes) v = *reinterpret_cast<const uint4 *>(a.u.text + t0 + i);
+    else {
+      u32 w[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 16; k++)
+        if (t0 + i + k < a.u.nbytes) w[k >> 2] |= (u32)a.u.text[t0 + i + k] << (8 * (k & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4 *>(text + i) = v;
+  }
+  __syncthreads();
+  // newline positions, in order: the tile proper (chunk = 64 bytes per thread), then the overlap (first 16 threads)
+  u32 base = 0;
+  for (int part = 0; part < 2; part++) {
+    const u32 off = part ? ING_TILE + (u32)tid * 64 : (u32)tid * 64;
+    u64 m = 0;
+    if ((part == 0 || tid < (int)(ING_OVER / 64)) && off < len) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(text + off);
+#pragma unroll
+      for (int c = 0; c < 4; c++) m |= (u64)newline_mask16(p[c]) << (16 * c);
+      if (off + 64 > len) m &= (len - off >= 64) ? ~0ull : ((1ull << (len - off)) - 1);
+    }
+    u32 tot;
+    u32 at = base + block_exclusive_sum<u32, 8>((u32)__popcll(m), &tot, sm);
+    while (m) {
+      const int bpos = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (at < ING_NLMAX) nl[at] = (u16)(off + bpos);
+      at++;
+    }
+    base += tot;
+  }
+  if (tid == 0) { s_count[0] = base; }
+  __syncthreads();
+  const u32 count = s_count[0];
+  if (count > ING_NLMAX) { if (tid == 0) atomicExch(a.slow, 1u); return; }
+  // lines: the line that ends at nl[j] is line G0 + j of the text; it starts in this tile iff j > 0 or the tile begins a line
+  const u64 G0 = a.tile_base[2 * (u64)blockIdx.x];
+  const bool starts_line = t0 == 0 || a.u.text[t0 - 1] == '\n';
+  const u32 jmin = starts_line ? 0u : 1u;
+  u32 j0 = jmin + (u32)((4 - ((G0 + jmin) & 3)) & 3);               // first name line that starts here
+  const u64 rid0 = (G0 + j0) >> 2;
+  // candidates: name lines that END in tile + overlap; kept below only if they START in the tile proper and are whole
+  const u32 nloc = j0 < count ? (count - j0 + 3) / 4 : 0u;
+  // every thread filters its own record; the q tile needs the number of records taken: count them with a ballot scan
+  const int lane_rec = tid & 255;
+  const bool second = tid >= 256;
+  for (u32 k0 = 0; k0 < nloc; k0 += 256) {
+    const u32 k = k0 + (u32)lane_rec;
+    const u32 j = j0 + 4 * k;
+    const u64 rid = rid0 + k;
+    bool take = k < nloc && rid < a.u.nrec;
+    u32 ns = 0;
+    if (take) {
+      ns = j ? (u32)nl[j - 1] + 1 : 0u;
+      if (j && j - 1 >= count) take = false;
+      else if (ns >= ING_TILE) take = false;                        // starts in the next tile: that workgroup's record
+    }
+    if (take && j + 3 >= count) {                                   // its four lines must end inside tile + overlap
+      take = false;
+      if (!second) atomicExch(a.slow, 1u);
+    }
+    if (take) {
+      u8 *qrow = qt + (size_t)(k - k0) * a.u.L;
+      const bool al = ((a.u.L & 3) == 0);
+      auto w_lds = [&](u64 at) { return *reinterpret_cast<const u32 *>(text + ((at & ~3ull) - t0)); };
+      auto b_lds = [&](u64 at) { return text[at - t0]; };
+      const u64 p0 = t0 + nl[j], p1 = t0 + nl[j + 1], p2 = t0 + nl[j + 2], p3 = t0 + nl[j + 3];
+      if (second) unpack_record_at<2>(a.u, rid, t0 + ns, p0, p1, p2, p3, lut, w_lds, b_lds, qrow, al);
+      else {
+        unpack_record_at<1>(a.u, rid, t0 + ns, p0, p1, p2, p3, lut, w_lds, b_lds, qrow, al);
+        if (rid + 1 == a.u.nrec) *a.consumed = p3 + 1;
+      }
+    }
+    // records taken in this round are consecutive from k0 on: their q' rows are one contiguous range of the output
+    const u32 ntaken = __syncthreads_count(take && !second);
+    if (ntaken) {
+      const u64 qbytes = (u64)ntaken * a.u.L;
+      u8 *qdst = a.u.q + (rid0 + k0) * (u64)a.u.L;
+      if ((((u64)qdst) & 15) == 0) {
+        for (u64 i = (u64)tid * 16; i < qbytes; i += (u64)ING_THREADS * 16) {
+          if (i + 16 <= qbytes) *reinterpret_cast<uint4 *>(qdst + i) = *reinterpret_cast<const uint4 *>(qt + i);
+          else for (u64 x = i; x < qbytes; x++) qdst[x] = qt[x];
+        }
+      } else {
+        for (u64 i = tid; i < qbytes; i += ING_THREADS) qdst[i] = qt[i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- trigram counters -------------------------------------------------------------------------
 // freq4[(p0*80+p1)*80+s] += 1 for every symbol of the flat input-order stream that has two
 // predecessors (cross-read predecessors included: the reference's prev[] is static,
@@ -356,23 +490,30 @@ constexpr int TRI_THREADS = 512;
 constexpr int TRI_CAP = 30500;      // u32 counters in LDS (122 000 B of the CU's 160 KB)
 constexpr int TRI_MAX_PASSES = 20;  // A = 80: 4 leading symbols per pass
 
-__global__ __launch_bounds__(256) void sym_hist_k(const u8 *q, u64 n, u64 *hist /*[256]*/) {
-  __shared__ u32 h[256];
-  h[threadIdx.x] = 0;
-  __syncthreads();
+// smallest and largest q' symbol of the piece: all the layout of the trigram slices needs (a full histogram with an LDS
+// atomic per byte ran at a third of this kernel's rate)
+__global__ __launch_bounds__(256) void sym_range_k(const u8 *q, u64 n, u32 *minmax /* [0] = min, [1] = max; preset to 255, 0 */) {
+  u32 lo = 255, hi = 0;
   const u64 stride = (u64)gridDim.x * blockDim.x * 16;
   for (u64 t = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16; t < n; t += stride) {
     if (t + 16 <= n) {
       const uint4 v = *reinterpret_cast<const uint4 *>(q + t);
       const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int k = 0; k < 16; k++) atomicAdd(&h[(w[k >> 2] >> (8 * (k & 3))) & 255u], 1u);
+      for (int k = 0; k < 4; k++) {
+        const u32 a = w[k] & 0xFFu, b = (w[k] >> 8) & 0xFFu, c = (w[k] >> 16) & 0xFFu, d = w[k] >> 24;
+        lo = min(lo, min(min(a, b), min(c, d)));
+        hi = max(hi, max(max(a, b), max(c, d)));
+      }
     } else {
-      for (u64 i = t; i < n; i++) atomicAdd(&h[q[i]], 1u);
+      for (u64 i = t; i < n; i++) { lo = min(lo, (u32)q[i]); hi = max(hi, (u32)q[i]); }
     }
   }
-  __syncthreads();
-  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)h[threadIdx.x]);
+  for (int o = 32; o; o >>= 1) {
+    lo = min(lo, (u32)__shfl_xor((int)lo, o));
+    hi = max(hi, (u32)__shfl_xor((int)hi, o));
+  }
+  if (lane_id() == 0) { atomicMin(&minmax[0], lo); atomicMax(&minmax[1], hi); }
 }
 
 // range[0] = smallest symbol < 80 that occurs, range[1] = A = span of the occurring symbols (0: none)
@@ -385,24 +526,20 @@ __global__ void tri_prev_k(const u8 *q_piece, u64 symbols_before, u32 carried0, 
   else { prev[0] = carried0; prev[1] = carried1; }
 }
 
-__global__ __launch_bounds__(64) void tri_range_k(const u64 *sym_hist, const u32 *prev, u32 *range) {
-  const u32 prev0 = prev[0], prev1 = prev[1];
-  const u32 l = threadIdx.x;
-  const bool live0 = sym_hist[l] != 0 || prev0 == l || prev1 == l;
-  const bool live1 = l + 64 < 80 && (sym_hist[l + 64] != 0 || prev0 == l + 64 || prev1 == l + 64);
-  const u64 m0 = __ballot(live0), m1 = __ballot(live1);
-  if (l == 0) {
-    u32 lo = 0, hi = 0;
-    if (m0 | m1) {
-      lo = m0 ? (u32)__ffsll((long long)m0) - 1 : 64 + (u32)__ffsll((long long)m1) - 1;
-      hi = m1 ? 64 + 63 - (u32)__clzll((long long)m1) : 63 - (u32)__clzll((long long)m0);
-      range[0] = lo;
-      range[1] = hi - lo + 1;
-    } else {
-      range[0] = 0;
-      range[1] = 0;
+// range[0] = smallest symbol < 80 to lay out, range[1] = A = span (0: none): the symbols of the piece and the two in front
+__global__ void tri_range_k(const u32 *minmax, const u32 *prev, u32 *range) {
+  if (threadIdx.x || blockIdx.x) return;
+  u32 lo = minmax[0], hi = minmax[1];
+  bool any = lo <= hi && lo < 80;
+  if (hi >= 80) hi = 79;  // (symbols >= 80 are an input error reported by the ingest stage)
+  for (int k = 0; k < 2; k++)
+    if (prev[k] < 80) {
+      lo = any ? min(lo, prev[k]) : prev[k];
+      hi = any ? max(hi, prev[k]) : prev[k];
+      any = true;
     }
-  }
+  range[0] = any ? lo : 0;
+  range[1] = any ? hi - lo + 1 : 0;
 }
 
 // Work is handed out in 64 KB tiles per WAVE through a global counter (one per pass), not by a fixed stride: while

@@ -286,6 +286,9 @@ struct scalce_batch {
   u64 names_in_used = 0;     // bytes of the long-name store in use
   u64 S_rows = ~0ull;        // rows the record-size prefix sums in S cover (scalce_batch_chunk_plan), ~0 = stale
   u64 text_bytes[2] = {0, 0};
+  const u8 *piece_text[2] = {nullptr, nullptr};  // the piece ingested last (its line index is built on demand)
+  bool line_index_ok[2] = {false, false};
+  u64 piece_consumed[2] = {0, 0};               // text offset behind the last record taken from it
   bool ingested[2] = {false, false};
   // device state
   DevErr *d_err = nullptr;
@@ -492,7 +495,7 @@ static int batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_read
   // a record is at least "@x", L bases, "+", L qualities and four newlines: what one piece of max_text bytes can bring
   const u64 per_piece = max_text / (2 * (u64)b->L[0] + 7) + 2;
   b->piece_rows_cap = per_piece < max_reads ? per_piece : max_reads;
-  for (int m = 0; m < b->nm; m++) ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (b->piece_rows_cap + 1));
+  // (the line index of a piece, 32 bytes per record, is only built when something asks for it: ensure_line_index)
   { int rc = reserve_rows(b, max_reads, 0, nullptr); if (rc) return rc; }
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(4 * b->piece_rows_cap + 1024) + 4096));
   return SCALCE_OK;
@@ -601,18 +604,30 @@ static int piece_count(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, 
   return SCALCE_OK;
 }
 
-// line index of the first `nrec` records of the text, then their rows [base, base + nrec): 2-bit bases, q', names
-static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s) {
-  scalce_ctx *c = b->ctx;
-  if (!nrec) return SCALCE_OK;
-  if (nrec > b->piece_rows_cap) {
-    b->piece_rows_cap = nrec;
-    for (int m = 0; m < b->nm; m++) ENSURE(b, b->line_end[m], sizeof(u64) * 4 * (nrec + 1));
+// the line index of the piece (index_write_k), built when something needs it: the indexed unpack kernels, names longer
+// than a cell, scalce_batch_text_offset
+static int ensure_line_index(scalce_batch *b, int mate, hipStream_t s) {
+  if (b->line_index_ok[mate]) return SCALCE_OK;
+  const u64 nrec = b->NP, nbytes = b->text_bytes[mate];
+  if (nrec > b->piece_rows_cap || !b->line_end[mate].p) {
+    if (nrec > b->piece_rows_cap) b->piece_rows_cap = nrec;
+    ENSURE(b, b->line_end[mate], sizeof(u64) * 4 * (b->piece_rows_cap + 1));
   }
   const u32 ntiles = cdiv(nbytes, IDX_TILE);
-  LAUNCH(index_write_k, ntiles, IDX_THREADS, 0, s, d_text, nbytes, b->tile[mate].as<u64>(), b->line_end[mate].as<u64>(), 4 * nrec);
+  if (ntiles) LAUNCH(index_write_k, ntiles, IDX_THREADS, 0, s, b->piece_text[mate], nbytes, b->tile[mate].as<u64>(), b->line_end[mate].as<u64>(), 4 * nrec);
+  b->line_index_ok[mate] = true;
+  return SCALCE_OK;
+}
+
+// the first `nrec` records of the text -> rows [base, base + nrec): 2-bit bases, q', names
+static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  b->piece_text[mate] = d_text;
+  b->line_index_ok[mate] = false;
+  b->piece_consumed[mate] = 0;
+  if (!nrec) return SCALCE_OK;
   UnpackArgs a;
-  a.text = d_text; a.nbytes = nbytes; a.line_end = b->line_end[mate].as<u64>(); a.nrec = nrec;
+  a.text = d_text; a.nbytes = nbytes; a.line_end = nullptr; a.nrec = nrec;
   a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
   a.packed = b->packed[mate].as<u8>() + b->base * (u64)b->stride[mate];
   a.q = b->q[mate].as<u8>() + b->base * (u64)b->L[mate];
@@ -621,15 +636,40 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
   a.qlut = b->d_qlut[mate]; a.err = b->d_err;
   a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
   a.max_namelen = b->d_small + 16;
-  if (mate == 0) HIP_TRY(c, hipMemsetAsync(b->d_small + 16, 0, sizeof(u32), s));
-  if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
-    LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
-  else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
+  u32 *slow = b->d_small + 17;
+  u64 *d_consumed = b->d_small64 + 2 + mate;  // (slots 1..3 are the emit stage's, long after this)
+  if (mate == 0) HIP_TRY(c, hipMemsetAsync(b->d_small + 16, 0, 2 * sizeof(u32), s));
+  else HIP_TRY(c, hipMemsetAsync(slow, 0, sizeof(u32), s));
+  // one pass behind the count for the usual read lengths (ingest_tiles_k); the indexed kernels otherwise, and when a
+  // record turns out not to fit the tile overlap
+  bool fused = a.L >= 16 && a.L <= 160 && !getenv("SCALCE_INGEST_INDEXED");
+  u32 flags[2] = {0, 0};
+  if (fused) {
+    IngestArgs ia;
+    ia.u = a;
+    ia.tile_base = b->tile[mate].as<u64>();
+    ia.consumed = d_consumed;
+    ia.slow = slow;
+    LAUNCH(ingest_tiles_k, cdiv(nbytes, ING_TILE), ING_THREADS, 0, s, ia);
+    { int rc = read_u32(b, b->d_small + 16, flags, 2, s); if (rc) return rc; }
+    if (flags[1]) fused = false;  // a record longer than the overlap: redo the piece the indexed way
+  }
+  if (!fused) {
+    { int rc = ensure_line_index(b, mate, s); if (rc) return rc; }
+    a.line_end = b->line_end[mate].as<u64>();
+    if (mate == 0) HIP_TRY(c, hipMemsetAsync(b->d_small + 16, 0, sizeof(u32), s));
+    if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
+      LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
+    else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
+    LAUNCH(last_record_end_k, 1, 1, 0, s, a.line_end, nrec, d_consumed);
+    { int rc = read_u32(b, b->d_small + 16, flags, 1, s); if (rc) return rc; }
+  }
+  { u64 v = 0; int rc = read_u64(b, d_consumed, &v, 1, s); if (rc) return rc; b->piece_consumed[mate] = v; }
   if (mate == 0 && b->p.use_names) {
     // names that do not fit their 16-byte cell go to the long-name store (input order): the text is not needed again
-    u32 maxlen = 0;
-    { int rc = read_u32(b, b->d_small + 16, &maxlen, 1, s); if (rc) return rc; }
+    const u32 maxlen = flags[0];
     if (maxlen > 15) {
+      { int rc = ensure_line_index(b, mate, s); if (rc) return rc; }
       if (!b->name_in_off.p) {
         ENSURE(b, b->name_in_off, sizeof(u64) * (b->row_cap + 2));
         HIP_TRY(c, hipMemsetAsync(b->name_in_off.p, 0, sizeof(u64) * (b->row_cap + 2), s));
@@ -640,7 +680,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
       u64 total = 0;
       { int rc = read_u64(b, b->d_small64 + 6, &total, 1, s); if (rc) return rc; }
       { int rc = ensure_keep(b, b->names_in, b->names_in_used + total + 64, b->names_in_used, s); if (rc) return rc; }
-      LAUNCH(long_names_k, cdiv(nrec, 256), 256, 0, s, nrec, d_text, a.line_end, a.namelen, off, b->names_in_used, b->names_in.as<u8>());
+      LAUNCH(long_names_k, cdiv(nrec, 256), 256, 0, s, nrec, d_text, b->line_end[mate].as<u64>(), a.namelen, off, b->names_in_used, b->names_in.as<u8>());
       b->names_in_used += total;
     }
   }
@@ -728,10 +768,9 @@ extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint
       int rc = piece_unpack(b, m, text[m], nbytes[m], nrec, s);
       if (rc) return rc;
       b->ingested[m] = true;
-      if (nrec) HIP_TRY(c, hipMemcpyAsync(&consumed[m], b->line_end[m].as<u64>() + 4 * nrec - 1, sizeof(u64), hipMemcpyDeviceToHost, s));
+      consumed[m] = nrec ? b->piece_consumed[m] : 0;  // behind the newline that ends the last record taken
     }
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (nrec) for (int m = 0; m < b->nm; m++) consumed[m] += 1;  // behind the newline that ends the last record taken
   }
   b->N = b->base + nrec;
   int rc;
@@ -761,13 +800,14 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     const u64 n = b->NP * (u64)b->L[m], before = b->base * (u64)b->L[m];
     if (!n) continue;
     const u8 *q = b->q[m].as<u8>() + before;
-    u64 *hist = b->d_small64 + 16;  // 256 symbol counters live behind the scalar scratch
-    HIP_TRY(c, hipMemsetAsync(hist, 0, sizeof(u64) * 256, s));
-    LAUNCH(sym_hist_k, 2048, 256, 0, s, q, n, hist);
+    u32 *minmax = b->d_small + 24;  // smallest / largest symbol of the piece
+    HIP_TRY(c, hipMemsetAsync(minmax, 0xFF, sizeof(u32), s));
+    HIP_TRY(c, hipMemsetAsync(minmax + 1, 0, sizeof(u32), s));
+    LAUNCH(sym_range_k, 2048, 256, 0, s, q, n, minmax);
     u32 *prev = b->d_small + 20 + 2 * m;  // the two symbols in front of this piece
     LAUNCH(tri_prev_k, 1, 1, 0, s, q, before, b->p.qprev[m][0], b->p.qprev[m][1], prev);
     u32 *range = b->d_small + 14;  // {lo, A}: span of the symbols that occur
-    LAUNCH(tri_range_k, 1, 64, 0, s, hist, prev, range);
+    LAUNCH(tri_range_k, 1, 1, 0, s, minmax, prev, range);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(b->d_small64 + 300);  // one tile counter per pass
     HIP_TRY(c, hipMemsetAsync(tiles, 0, sizeof(u64) * TRI_MAX_PASSES, s));
     for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
@@ -1084,6 +1124,7 @@ extern "C" int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row,
   *offset = 0;
   if (!row) return SCALCE_OK;
   HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  { int rc = ensure_line_index(b, mate, nullptr); if (rc) return rc; }  // (the piece's text must still be where it was)
   u64 v = 0;
   HIP_TRY(b->ctx, hipMemcpy(&v, b->line_end[mate].as<u64>() + 4 * row - 1, sizeof(u64), hipMemcpyDeviceToHost));
   *offset = v + 1;

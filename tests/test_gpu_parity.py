@@ -614,3 +614,47 @@ def test_coder_general_step_through_inverted_intervals(blocks_per_wave, ctx, mon
     assert len(enc) == len(want), f"{len(enc)} vs {len(want)} bytes"
     bad = np.flatnonzero(enc != want)
     assert len(bad) == 0, f"coder bytes differ from the oracle's first at byte {bad[:3]} of {len(want)}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["indexed_kernels", "records_longer_than_the_overlap", "short_reads_L16", "tile_edges"])
+def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
+    """The ingest stage reads the text once behind the newline count (ingest_tiles_k: 32 KB tiles + 1 KB overlap in LDS) and
+    falls back to the indexed kernels (index_write_k + unpack_tiled_k) for read lengths outside 16..160 or when a record
+    does not fit the overlap.  Both paths, the fallback trigger, the shortest fused read length and records that straddle
+    tile boundaries in every phase against the oracle."""
+    from gpu_util import hip_compress, oracle_streams
+    rng = np.random.default_rng(17)
+    L, n = 100, 40000
+    if case == "short_reads_L16":
+        L, n = 16, 150000
+    bases, quals = synth.reads_and_quals(n, L, seed=55, n_frac=0.004, dup_frac=0.1)
+    if case == "indexed_kernels":
+        monkeypatch.setenv("SCALCE_INGEST_INDEXED", "1")
+    if case == "records_longer_than_the_overlap":   # names of up to 255 characters, repeated on the '+' line
+        recs = []
+        for i in range(n):
+            nm = b"r%d_" % i + b"x" * int(rng.integers(0, 250 - 8))
+            recs.append(b"@" + nm + b"\n" + bases[i].tobytes() + b"\n+" + nm + b"\n" + quals[i].tobytes() + b"\n")
+        fq = b"".join(recs)
+    elif case == "tile_edges":                      # name lengths cycle so that record starts sweep through every tile phase
+        recs = [b"@" + b"n" * (1 + (i * 7) % 61) + b" c\n" + bases[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n" for i in range(n)]
+        fq = b"".join(recs)
+    else:
+        fq = synth.fastq_bytes_fast(bases, quals)
+    b = hip_compress(ctx, fq, L)
+    ref = oracle_streams(oracle_trie, bases, quals, 33, None)
+    tok = b.output(host.OUT_TOKENS, 0, np.int32).reshape(-1, 2)
+    assert (tok[:, 0] == ref["pat"]).all() and (tok[:, 1] == ref["end"]).all()
+    assert (b.output(host.OUT_PERM, 0, np.uint32) == ref["perm"]).all()
+    assert (b.output(host.OUT_QINPUT, 0).reshape(n, L) == ref["qp"]).all()
+    assert (b.output(host.OUT_FREQ4, 0, np.uint64) + 1 == ref["f4"]).all()
+    # names: [u8 n][chars up to the first space] per record, in emission order
+    names = b.output(host.OUT_NAMES, 0)
+    lines = fq.split(b"\n")
+    want = bytearray()
+    for k in ref["perm"]:
+        nm = lines[4 * int(k)][1:].split(b" ")[0]
+        want.append(len(nm))
+        want += nm
+    assert names.tobytes() == bytes(want)
