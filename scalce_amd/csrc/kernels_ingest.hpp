@@ -352,15 +352,16 @@ __global__ __launch_bounds__(2 * UNP_RPB) void unpack_tiled_k(UnpackArgs a) {
 
 // ---- one pass over the text behind the count: line index, record structure and unpack fused ------------------------
 // index_write_k + unpack_tiled_k read the text twice more and keep a 32-byte line index per record in between.  For reads
-// of 16 .. 160 bases a workgroup instead takes a 32 KB tile of text (plus 1 KB: the records that start in the tile end
+// of 16 .. 160 bases a workgroup instead takes a 16 KB tile of text (plus 1 KB: the records that start in the tile end
 // there) into LDS, finds the newlines in it, knows from the tile's line base (index_count_k + scan) which of them end name
 // lines, and unpacks the records that START in the tile straight from LDS.  Text read twice instead of three times, no
 // line index.  A record that does not end inside the overlap sets `slow` and the host falls back to the indexed kernels.
-constexpr u32 ING_TILE = 2 * IDX_TILE;   // 32 KB
+constexpr u32 ING_TILE = IDX_TILE;       // 16 KB: 30 KB of LDS per workgroup, five workgroups (twenty waves) per CU
 constexpr u32 ING_OVER = 1024;
-constexpr u32 ING_NLMAX = 4096;
+constexpr u32 ING_NLMAX = 2048;
 constexpr u32 ING_QCAP = ING_TILE / 2 + 2 * 160 + 64;
-constexpr int ING_THREADS = 512;
+constexpr int ING_THREADS = 256;
+constexpr int ING_HALF = ING_THREADS / 2;
 struct IngestArgs {
   UnpackArgs u;              // text, nbytes, nrec (records to take), L, stride, outputs (already offset to the piece's rows)
   const u64 *tile_base;      // newlines in front of every IDX_TILE (exclusive scan of index_count_k)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
   __shared__ u16 nl[ING_NLMAX];
   __shared__ __attribute__((aligned(16))) u8 qt[ING_QCAP];
   __shared__ u8 lut[128];
-  __shared__ u32 sm[8];
+  __shared__ u32 sm[ING_THREADS / 64];
   __shared__ u32 s_count[2];
   const int tid = threadIdx.x;
   const u64 t0 = (u64)blockIdx.x * ING_TILE;                       // text offset of the tile
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
       if (off + 64 > len) m &= (len - off >= 64) ? ~0ull : ((1ull << (len - off)) - 1);
     }
     u32 tot;
-    u32 at = base + block_exclusive_sum<u32, 8>((u32)__popcll(m), &tot, sm);
+    u32 at = base + block_exclusive_sum<u32, ING_THREADS / 64>((u32)__popcll(m), &tot, sm);
     while (m) {
       const int bpos = __ffsll((long long)m) - 1;
       m &= m - 1;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
   const u32 count = s_count[0];
   if (count > ING_NLMAX) { if (tid == 0) atomicExch(a.slow, 1u); return; }
   // lines: the line that ends at nl[j] is line G0 + j of the text; it starts in this tile iff j > 0 or the tile begins a line
-  const u64 G0 = a.tile_base[2 * (u64)blockIdx.x];
+  const u64 G0 = a.tile_base[(u64)blockIdx.x * (ING_TILE / IDX_TILE)];
   const bool starts_line = t0 == 0 || a.u.text[t0 - 1] == '\n';
   const u32 jmin = starts_line ? 0u : 1u;
   u32 j0 = jmin + (u32)((4 - ((G0 + jmin) & 3)) & 3);               // first name line that starts here
@@ -425,9 +426,9 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
   // candidates: name lines that END in tile + overlap; kept below only if they START in the tile proper and are whole
   const u32 nloc = j0 < count ? (count - j0 + 3) / 4 : 0u;
   // every thread filters its own record; the q tile needs the number of records taken: count them with a ballot scan
-  const int lane_rec = tid & 255;
-  const bool second = tid >= 256;
-  for (u32 k0 = 0; k0 < nloc; k0 += 256) {
+  const int lane_rec = tid & (ING_HALF - 1);
+  const bool second = tid >= ING_HALF;
+  for (u32 k0 = 0; k0 < nloc; k0 += ING_HALF) {
     const u32 k = k0 + (u32)lane_rec;
     const u32 j = j0 + 4 * k;
     const u64 rid = rid0 + k;
