@@ -157,6 +157,8 @@ int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior_counts, void 
  * sequential (-T 1) result over the whole run. */
 int scalce_batch_tokenize_begin(scalce_batch *b, void *stream);
 int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior_counts, int *changed, void *stream);
+/* nsweeps (1..16) sweeps against the same prior counts, one look at their flags: *changed = 1 if any of them moved a decision */
+int scalce_batch_tokenize_sweeps(scalce_batch *b, const uint64_t *d_prior_counts, int nsweeps, int *changed, void *stream);
 int scalce_batch_tokenize_end(scalce_batch *b, void *stream);
 /* Sharded runs: the cuts the -B rule makes inside this batch's rows when `carry_in` bytes of records are already in the
  * chunk that is open where they begin (the rows of the ranks before): cuts_host[i] = row in front of which chunk i + 1
@@ -293,7 +295,8 @@ int scalce_fastq_records(scalce_ctx *ctx, int read_len, int has_buckets, const u
  * archive of a sharded run is byte for byte the archive of the same input on one GPU -- and of the reference at -T 1 with
  * the same -B -- for any number of ranks: rank boundaries are moved to the nearest spill-chunk boundary of the run-wide -B
  * rule (records change owner as text, once), so that "rank-major inside a bucket" IS the merge order of compress.cpp:104-159.
- * -B must be set (the reference's default is 4G) and a chunk must not span more than two neighbouring ranks. */
+ * -B must be set (the reference's default is 4G) and must cut the run at least once; ranks whose share is smaller than a
+ * chunk may end up without records. */
 typedef struct scalce_comm scalce_comm;
 #define SCALCE_COMM_ID_BYTES 128
 int scalce_comm_unique_id(uint8_t id[SCALCE_COMM_ID_BYTES]);  /* rank 0 makes it, the launcher hands it to every rank */

@@ -1029,6 +1029,27 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   return SCALCE_OK;
 }
 
+// Several sweeps against the same prior counts with ONE look at their flags (a sweep behind the local fixed point changes
+// nothing and costs next to nothing; a host round trip per sweep leaves the stream idle).  *changed = 1 if any moved.
+extern "C" int scalce_batch_tokenize_sweeps(scalce_batch *b, const uint64_t *d_prior, int nsweeps, int *changed, void *stream) {
+  if (!b || !b->tok_open || !changed || nsweeps < 1 || nsweeps > 16) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  StageTimer tm(b, ST_TOKENIZE, s);
+  *changed = 0;
+  if (!b->tok_n || !b->ntie) return SCALCE_OK;
+  u32 *flags = b->d_small + 32;
+  for (int i = 0; i < nsweeps; i++) { int rc = tokenize_sweep_enqueue(b, d_prior, flags + i, s); if (rc) return rc; }
+  u32 ch[16];
+  { int rc = read_u32(b, flags, ch, nsweeps, s); if (rc) return rc; }
+  for (int i = 0; i < nsweeps; i++) {
+    b->jacobi_iters++;
+    if (ch[i]) *changed = 1;
+  }
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
   if (!b || !b->tok_open) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;

@@ -122,8 +122,8 @@ template <typename T> std::vector<T> gather_host(scalce_comm *comm, const T *min
 
 // Host-only plan math, exported so that it can be checked without a GPU -------------------------------------------------
 // Rank boundaries g[0..world] (run-wide row of every rank's first record, g[world] = rows of the run) move to the nearest
-// cut of the run-wide -B rule; gn[] = the moved boundaries.  Returns SCALCE_ERR_CAPACITY when the run has no cut to move to
-// or a chunk spans more than two neighbouring ranks.
+// cut of the run-wide -B rule; gn[] = the moved boundaries (non-decreasing; ranks may end up without records when chunks are
+// larger than a rank's share).  Returns SCALCE_ERR_CAPACITY when the run has no cut to move to.
 extern "C" int scalce_shard_plan_boundaries(int world, const uint64_t *g, const uint64_t *cuts_sorted, uint64_t ncuts, uint64_t *gn) {
   if (world < 1 || !g || !gn || (ncuts && !cuts_sorted)) return SCALCE_ERR_ARG;
   for (int r = 0; r <= world; r++) gn[r] = g[r];
@@ -134,10 +134,8 @@ extern "C" int scalce_shard_plan_boundaries(int world, const uint64_t *g, const 
     if (it != cuts_sorted) { const uint64_t lo = *(it - 1); if (best < g[r] || g[r] - lo <= best - g[r]) best = lo; }
     gn[r] = best;
   }
-  for (int r = 1; r < world; r++) {
+  for (int r = 1; r < world; r++)
     if (gn[r] < gn[r - 1]) gn[r] = gn[r - 1];
-    if (gn[r] < g[r - 1] || gn[r] > g[r + 1]) return SCALCE_ERR_CAPACITY;
-  }
   return SCALCE_OK;
 }
 // The run-wide reordered quality stream of one mate (buckets in emission order, ranks in order inside a bucket; C[r][k] reads
@@ -318,50 +316,53 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     std::vector<u64> gn(W + 1);
     {
       const int prc = scalce_shard_plan_boundaries(W, g.data(), cuts_global.data(), cuts_global.size(), gn.data());
-      if (prc) throw Fail{cuts_global.empty() && W > 1
-                              ? "(ERROR) a sharded run needs -B below a rank's share of the input: no spill chunk ends inside the run, so the "
-                                "records of a bucket would have to be merged across ranks"
-                              : "(ERROR) a spill chunk spans more than two neighbouring ranks: use a smaller -B or fewer GPUs", prc};
+      if (prc) throw Fail{"(ERROR) a sharded run needs a -B that cuts the run: no spill chunk ends inside it, so the records of a bucket "
+                          "would have to be merged across ranks", prc};
     }
-    const u64 head_out = gn[rank] > g[rank] ? gn[rank] - g[rank] : 0;               // rows that leave for rank - 1
-    const u64 tail_out = gn[rank + 1] < g[rank + 1] ? g[rank + 1] - gn[rank + 1] : 0;  // ... for rank + 1
-    const u64 head_in = gn[rank] < g[rank] ? g[rank] - gn[rank] : 0;
-    const u64 tail_in = gn[rank + 1] > g[rank + 1] ? gn[rank + 1] - g[rank + 1] : 0;
+    auto clampu = [](u64 x, u64 a, u64 b) { return x < a ? a : (x > b ? b : x); };
     res->first_read = gn[rank];
     res->reads_local = gn[rank + 1] - gn[rank];
-    res->moved_in[0] = head_in;
-    res->moved_in[1] = tail_in;
+    res->moved_in[0] = gn[rank] < g[rank] ? g[rank] - clampu(gn[rank], 0, g[rank]) : 0;
+    res->moved_in[1] = gn[rank + 1] > g[rank + 1] ? gn[rank + 1] - g[rank + 1] : 0;
     bool anything_moves = false;
     for (int r = 1; r < W; r++) anything_moves = anything_moves || gn[r] != g[r];
     if (anything_moves) {
-      if (head_out + tail_out > N0) throw Fail{"internal: more rows leave than the rank holds", SCALCE_ERR_ARG};
+      // Rows [g[rank], g[rank + 1]) were ingested here; rows [gn[d], gn[d + 1]) belong to rank d now.  My rows go to their new
+      // owners in rank order, which is the order they have in my text: the text itself is the send buffer.
       uint8_t *newtext[2] = {nullptr, nullptr};
       u64 newbytes[2] = {0, 0};
       for (int m = 0; m < nm; m++) {
-        uint64_t o_head = 0, o_tail = nbytes[m];
-        SH_RC(ctx, scalce_batch_text_offset(b, m, head_out, &o_head));
-        SH_RC(ctx, scalce_batch_text_offset(b, m, N0 - tail_out, &o_tail));
-        // who sends how much to whom: only neighbours
-        std::vector<uint64_t> sendb(W, 0), recvb(W, 0);
-        if (rank > 0) sendb[rank - 1] = o_head;
-        if (rank + 1 < W) sendb[rank + 1] = nbytes[m] - o_tail;
-        u64 mine[2] = {rank > 0 ? o_head : 0, rank + 1 < W ? nbytes[m] - o_tail : 0};
-        std::vector<u64> all = gather_host<u64>(comm, mine, 2, d_small, d_gather, s);
-        if (rank > 0) recvb[rank - 1] = all[2 * (rank - 1) + 1];   // what rank - 1 sends to the rank behind it
-        if (rank + 1 < W) recvb[rank + 1] = all[2 * (rank + 1)];   // what rank + 1 sends to the rank before it
-        const u64 from_left = rank > 0 ? recvb[rank - 1] : 0, from_right = rank + 1 < W ? recvb[rank + 1] : 0;
-        const u64 kept = o_tail - o_head;
-        newbytes[m] = from_left + kept + from_right;
+        std::vector<uint64_t> sendb(W, 0), recvb(W, 0), start(W + 1, 0);
+        for (int d = 0; d <= W; d++) {
+          const u64 row = clampu(d < W ? gn[d] : gn[W], g[rank], g[rank + 1]) - g[rank];
+          uint64_t off = nbytes[m];
+          if (row < N0) SH_RC(ctx, scalce_batch_text_offset(b, m, row, &off));
+          start[d] = off;
+        }
+        start[0] = 0;  // (rows in front of gn[0] = 0 do not exist)
+        for (int d = 0; d < W; d++) sendb[d] = start[d + 1] - start[d];
+        // who receives how much from whom
+        std::vector<u64> all = gather_host<u64>(comm, sendb.data(), (size_t)W, d_small, d_gather, s);
+        for (int src = 0; src < W; src++) recvb[src] = all[(size_t)src * W + rank];
+        const u64 kept = sendb[rank];
+        u64 total = 0, before_self = 0;
+        for (int src = 0; src < W; src++) { if (src < rank) before_self += recvb[src]; total += recvb[src]; }
+        newbytes[m] = total;
         newtext[m] = mem.alloc<uint8_t>(newbytes[m] + 256);
-        uint8_t *d_send = mem.alloc<uint8_t>(sendb[rank > 0 ? rank - 1 : 0] + sendb[rank + 1 < W ? rank + 1 : 0] + 256);
-        uint8_t *d_recv = mem.alloc<uint8_t>(from_left + from_right + 256);
-        u64 so = 0;
-        if (rank > 0 && o_head) { SH_HIP(hipMemcpyAsync(d_send, text[m], o_head, hipMemcpyDeviceToDevice, s)); so = o_head; }
-        if (rank + 1 < W && nbytes[m] > o_tail) SH_HIP(hipMemcpyAsync(d_send + so, text[m] + o_tail, nbytes[m] - o_tail, hipMemcpyDeviceToDevice, s));
-        SH_CM(comm, scalce_comm_all_to_all_v(comm, d_send, sendb.data(), d_recv, recvb.data(), s));
-        if (from_left) SH_HIP(hipMemcpyAsync(newtext[m], d_recv, from_left, hipMemcpyDeviceToDevice, s));
-        if (kept) SH_HIP(hipMemcpyAsync(newtext[m] + from_left, text[m] + o_head, kept, hipMemcpyDeviceToDevice, s));
-        if (from_right) SH_HIP(hipMemcpyAsync(newtext[m] + from_left + kept, d_recv + from_left, from_right, hipMemcpyDeviceToDevice, s));
+        // everything but the rows that stay goes through the all-to-all
+        std::vector<uint64_t> sb = sendb, rb = recvb;
+        sb[rank] = 0;
+        rb[rank] = 0;
+        uint8_t *d_send = mem.alloc<uint8_t>(nbytes[m] - kept + 256);
+        uint8_t *d_recv = mem.alloc<uint8_t>(total - kept + 256);
+        if (start[rank]) SH_HIP(hipMemcpyAsync(d_send, text[m], start[rank], hipMemcpyDeviceToDevice, s));
+        if (nbytes[m] > start[rank + 1])
+          SH_HIP(hipMemcpyAsync(d_send + start[rank], text[m] + start[rank + 1], nbytes[m] - start[rank + 1], hipMemcpyDeviceToDevice, s));
+        SH_CM(comm, scalce_comm_all_to_all_v(comm, d_send, sb.data(), d_recv, rb.data(), s));
+        if (before_self) SH_HIP(hipMemcpyAsync(newtext[m], d_recv, before_self, hipMemcpyDeviceToDevice, s));
+        if (kept) SH_HIP(hipMemcpyAsync(newtext[m] + before_self, text[m] + start[rank], kept, hipMemcpyDeviceToDevice, s));
+        if (total - kept - before_self)
+          SH_HIP(hipMemcpyAsync(newtext[m] + before_self + kept, d_recv + before_self, total - kept - before_self, hipMemcpyDeviceToDevice, s));
       }
       // the rows of the new range (their quality symbols were counted by whoever held them in the first pass)
       SH_RC(ctx, scalce_batch_reset(b));
@@ -434,11 +435,11 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         for (int r = 0; r < W; r++) any = any || flags[r] != 0;
         if (round > 0 && !any) break;  // a whole round with current priors on every rank and no decision moved
         moved = 0;
-        for (int k = 0; k < 4; k++) {
+        {
           int ch = 0;
-          SH_RC(ctx, scalce_batch_tokenize_sweep(b, reinterpret_cast<const uint64_t *>(d_prior), &ch, s));
-          res->sweeps++;
-          if (ch) moved = 1; else break;
+          SH_RC(ctx, scalce_batch_tokenize_sweeps(b, reinterpret_cast<const uint64_t *>(d_prior), 4, &ch, s));
+          res->sweeps += 4;
+          if (ch) moved = 1;
         }
         if (res->rounds > total_reads + 8) throw Fail{"tie resolution did not converge", SCALCE_ERR_HIP};
       }

@@ -239,3 +239,17 @@ def test_cli_gpus_writes_the_archive_of_one_gpu(case, tmp_path, monkeypatch):
             a = open(tmp_path / f"orc_{m}.scalce{ext}", "rb").read()
             h = open(tmp_path / f"hip_{m}.scalce{ext}", "rb").read()
             assert a == h, f"{case} .scalce{ext} mate {m}: {len(h)} vs {len(a)} bytes"
+
+
+def test_cli_long_reads_two_byte_end_marker(tmp_path):
+    """Reads longer than 255 bases store `end` in two bytes (reads.cpp:106-108) and go through the indexed ingest kernels
+    (the fused one takes 16..160 bases)."""
+    n, L = 3000, 300
+    synth.write_fastq(str(tmp_path / "in_1.fq"), n, L, seed=81, n_frac=0.002, dup_frac=0.1)
+    run_cli("-c", "no", "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc")
+    for ext in "nrq":
+        assert open(tmp_path / f"orc_1.scalce{ext}", "rb").read() == open(tmp_path / f"hip_1.scalce{ext}", "rb").read(), ext
+    run_cli("-d", "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
+    O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback")
+    assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()

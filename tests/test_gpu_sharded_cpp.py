@@ -83,7 +83,7 @@ def split_records(text, cuts):
     return [text[ends[i]:ends[i + 1]] for i in range(len(ends) - 1)]
 
 
-@pytest.mark.parametrize("case", ["se100_w2", "pe150_lossy_w3", "ties36_w4", "tiny_rank_w3", "rccl_w1"])
+@pytest.mark.parametrize("case", ["se100_w2", "pe150_lossy_w3", "ties36_w4", "tiny_rank_w3", "empty_rank_w3", "rccl_w1"])
 def test_sharded_archive_equals_one_batch(case, tmp_path, patterns_blob):
     from gpu_util import device_bytes
     paired, L, n, world, B, ptxt, lossy, rccl = False, 100, 60000, 2, 1_500_000, None, 0, False
@@ -94,7 +94,7 @@ def test_sharded_archive_equals_one_batch(case, tmp_path, patterns_blob):
         L, n, world, B = 36, 40000, 4, 500_000
         ptxt = tmp_path / "p.txt"
         open(ptxt, "w").write("\n".join("".join(x) for x in itertools.product("ACGT", repeat=4)) + "\n")
-    elif case == "tiny_rank_w3":
+    elif case in ("tiny_rank_w3", "empty_rank_w3"):
         world, n, B = 3, 50000, 1_000_000
     elif case == "rccl_w1":
         world, n, rccl = 1, 30000, True
@@ -106,6 +106,8 @@ def test_sharded_archive_equals_one_batch(case, tmp_path, patterns_blob):
     cuts = [int(n * (r + 1) / world) + d for r, d in zip(range(world - 1), (7, -13, 5))]
     if case == "tiny_rank_w3":
         cuts = [3, 40000]   # rank 0 holds three records: they all move to... wherever the first chunk boundary says
+    if case == "empty_rank_w3":
+        cuts = [30000, 30000]   # the middle rank starts with no text at all
     pieces = [split_records(t, cuts) for t in texts]
     per_rank = [[pieces[m][r] for m in range(len(texts))] for r in range(world)]
     qm, qpath = None, None

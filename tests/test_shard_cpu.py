@@ -94,7 +94,7 @@ def test_boundaries_move_to_the_nearest_cut():
     assert plan([0, 10, 20, 30], [20]) == (0, [0, 20, 20, 30])                 # rank 1 ends up without records
     assert plan([0, 100], []) == (0, [0, 100])                                 # one rank: nothing to move
     assert plan([0, 100, 200], [])[0] != 0                                     # two ranks and no cut: refused
-    assert plan([0, 10, 20, 30, 40], [35])[0] != 0                             # a chunk spans more than two neighbours
+    assert plan([0, 10, 20, 30, 40], [35]) == (0, [0, 35, 35, 35, 40])         # one cut for three boundaries: two ranks end up empty
 
 
 @pytest.mark.parametrize("world", [2, 3])
