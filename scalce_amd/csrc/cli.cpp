@@ -78,7 +78,7 @@ static const char *HELP_TEXT =
     "  -B, --bucket-set-size NUM[M|G]  bucket storage that triggers a spill chunk (default 4G); order follows the reference\n"
     "  -P, --patterns FILE         text list of cores instead of the built-in table\n"
     "  -T, --threads INT           host threads that read plain input and deflate the gz containers (default: cores - 1,\n"
-    "                              at most 32);\n"
+    "                              at most 64);\n"
     "                              the hot path itself runs on the GPU\n"
     "  -t, --temp-directory STR    accepted for compatibility (nothing is spilled)\n"
     "  -S, --split-reads INT       decompression: reads per output part\n"
@@ -316,7 +316,7 @@ struct MateSource {
   // of the page cache delivers about 5 GB/s, a tenth of what the upload behind it can take.
   int64_t read_plain(uint8_t *dst, uint64_t cap) {
     const uint64_t SLICE = 16u << 20;
-    const int nt = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(g_threads, 8)), (cap + SLICE - 1) / SLICE);
+    const int nt = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(g_threads, 16)), (cap + SLICE - 1) / SLICE);
     if (nt <= 1) {
       const int64_t k = ::pread(fd, dst, (size_t)std::min<uint64_t>(cap, 1u << 30), (off_t)fpos);
       if (k > 0) fpos += (uint64_t)k;
@@ -871,7 +871,7 @@ static int multi_gpu_compress(const Options &o, const std::vector<std::string> &
   snprintf(tag, sizeof tag, "%d_%ld", (int)getpid(), (long)time(nullptr));
   {
     const int hw = (int)std::thread::hardware_concurrency();
-    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(32, hw / std::max(1, o.gpus)));
+    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(64, hw / std::max(1, o.gpus)));
   }
   std::vector<pid_t> kids;
   for (int r = 0; r < o.gpus; r++) {
@@ -1077,7 +1077,7 @@ int main(int argc, char **argv) {
   else SCOK(ctx, scalce_patterns_load_bin(ctx, table.data(), table.size()));
   {
     const int hw = (int)std::thread::hardware_concurrency();
-    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(32, hw - 1));
+    g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(64, hw - 1));
   }
   const int rc = o.decompress ? do_decompress(o, files[0], ctx) : do_compress(o, files, ctx);
   scalce_ctx_destroy(ctx);
