@@ -317,6 +317,45 @@ def entropy_begin_group(batches, prep_stream=0, stream=0):
     batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group(arr, len(batches), prep_stream, stream))
 
 
+class StreamStats(C.Structure):
+    _fields_ = [("total_s", C.c_double), ("read_wait_s", C.c_double), ("h2d_wait_s", C.c_double), ("front_s", C.c_double),
+                ("order_s", C.c_double), ("emit_s", C.c_double), ("entropy_s", C.c_double), ("rounds", C.c_uint64),
+                ("reads", C.c_uint64), ("bytes", C.c_uint64 * 2)]
+
+
+READ_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_void_p, C.c_uint64)
+STREAM_LEAN, STREAM_DEFER_ENTROPY = 1, 2
+
+
+def stream_compress(ctx, params, read1, read2=None, piece_bytes=0, reads_hint=0, flags=0):
+    """scalce_stream_compress: read1 / read2 are callables (cap) -> bytes (b"" at the end of the stream; raise for a read
+    error), called from the library's reader threads.  Returns (Batch holding the results, StreamStats)."""
+    def wrap(fn):
+        def cb(_user, dst, cap):
+            try:
+                data = fn(int(cap))
+            except Exception:  # noqa: BLE001 - reported to the library as a read error
+                return -1
+            if data:
+                C.memmove(dst, data, len(data))
+            return len(data)
+        return READ_FN(cb)
+    cb1 = wrap(read1)
+    cb2 = wrap(read2) if read2 is not None else C.cast(None, READ_FN)
+    out, st = C.c_void_p(), StreamStats()
+    msg = C.create_string_buffer(512)
+    L = ctx.L
+    L.scalce_stream_compress.argtypes = [C.c_void_p, C.POINTER(Params), READ_FN, C.c_void_p, READ_FN, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int,
+                                         C.POINTER(C.c_void_p), C.POINTER(StreamStats), C.c_char_p, C.c_size_t]
+    rc = L.scalce_stream_compress(ctx.h, C.byref(params), cb1, None, cb2, None, int(piece_bytes), int(reads_hint), int(flags), C.byref(out),
+                                  C.byref(st), msg, len(msg))
+    if rc:
+        raise ScalceError(f"[{rc}] " + msg.value.decode(errors="replace"))
+    b = Batch.__new__(Batch)
+    b.ctx, b.L, b.params, b.h, b.workspace = ctx, L, params, out, None
+    return b, st
+
+
 class Workspace:
     """Front-stage device buffers shared by several batches (scalce_workspace): see include/scalce_hip.h."""
 

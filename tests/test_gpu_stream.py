@@ -161,3 +161,60 @@ def test_windowed_coder_equals_one_launch(paired, patterns_blob, monkeypatch):
         outs.append([b.output(host.OUT_QUAL, m).copy() for m in range(len(texts))])
     for m in range(len(texts)):
         assert len(outs[0][m]) == len(outs[1][m]) and (outs[0][m] == outs[1][m]).all(), f"mate {m + 1}"
+
+
+def _params(L, paired=False, **kw):
+    import ctypes as C
+    p = host.Params()
+    host.lib().scalce_params_default(C.byref(p))
+    p.read_len[0] = L
+    p.read_len[1] = L if paired else 0
+    p.paired = int(paired)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+@pytest.mark.parametrize("case", ["dribble", "paired_hint_too_small", "read_error", "mate_runs_dry"])
+def test_stream_compress_entry_point(case, patterns_blob):
+    """scalce_stream_compress through its C entry with Python callbacks as the readers: a source that delivers a few
+    hundred bytes per call, row arrays that have to grow past the hint, a source that fails, a mate that ends early."""
+    from gpu_util import device_bytes
+    ctx = host.Context(0, patterns_bin=patterns_blob)
+    paired = case in ("paired_hint_too_small", "mate_runs_dry")
+    n, L = 30000, 100
+    texts = [synth.fastq_bytes_fast(*synth.reads_and_quals(n, L, seed=211 + m, dup_frac=0.1), prefix="p.", suffix="/%d" % (m + 1))
+             for m in range(2 if paired else 1)]
+    if case == "mate_runs_dry":
+        texts[1] = texts[1][:len(texts[1]) // 2]
+        texts[1] = texts[1][:texts[1].rfind(b"\n@p.") + 1]
+
+    def reader(text, step, fail_at=None):
+        pos = [0]
+
+        def rd(cap):
+            if fail_at is not None and pos[0] >= fail_at:
+                raise IOError("boom")
+            k = min(cap, step, len(text) - pos[0])
+            out = text[pos[0]:pos[0] + k]
+            pos[0] += k
+            return out
+        return rd
+
+    step = 700 if case == "dribble" else 1 << 20
+    r1 = reader(texts[0], step, fail_at=len(texts[0]) // 2 if case == "read_error" else None)
+    r2 = reader(texts[1], step) if paired else None
+    p = _params(L, paired, bucket_set_size=0)
+    if case in ("read_error", "mate_runs_dry"):
+        with pytest.raises(host.ScalceError):
+            host.stream_compress(ctx, p, r1, r2, piece_bytes=300_000)
+        return
+    b, st = host.stream_compress(ctx, p, r1, r2, piece_bytes=300_000, reads_hint=1000 if paired else 0)
+    assert b.n_reads == n and st.reads == n and st.rounds > 5
+    whole = host.Batch(ctx, L, n + 8, max(len(t) for t in texts) + 64, paired=paired, read_len2=L)
+    dev = [device_bytes(t) for t in texts]
+    whole.compress(dev[0].data_ptr(), len(texts[0]), dev[1].data_ptr() if paired else None, len(texts[1]) if paired else 0)
+    whole.finish()
+    for which, m in [(host.OUT_READS, 0), (host.OUT_NAMES, 0), (host.OUT_QUAL, 0)] + ([(host.OUT_READS, 1), (host.OUT_QUAL, 1)] if paired else []):
+        x, y = whole.output(which, m), b.output(which, m)
+        assert len(x) == len(y) and (x == y).all(), (which, m)
