@@ -86,16 +86,27 @@ def main():
     sharded = world > 1 or bool(os.environ.get("SCALCE_BENCH_FORCE_SHARDED"))
     comm = None
     if sharded:
-        if os.environ.get("SCALCE_COMM") == "shm":
-            name = [("/scalce_bench_%d" % os.getpid()) if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(name, src=0)
-            comm = host.Comm(local, world, rank, shm_name=name[0], slot_bytes=int(os.environ.get("SCALCE_SHM_SLOT", str(8 << 30))))
-        else:
-            uid = [host.Comm.unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(uid, src=0)
-            comm = host.Comm(local, world, rank, unique_id=uid[0])
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout is the one JSON line's, so
+        # the banner goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if os.environ.get("SCALCE_COMM") == "shm":
+                name = [("/scalce_bench_%d" % os.getpid()) if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(name, src=0)
+                comm = host.Comm(local, world, rank, shm_name=name[0], slot_bytes=int(os.environ.get("SCALCE_SHM_SLOT", str(8 << 30))))
+            else:
+                uid = [host.Comm.unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                comm = host.Comm(local, world, rank, unique_id=uid[0])
+            comm.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     # shards per coder launch / shards in flight: 3 / 6 (135 GB of the 288 GB HBM at 50 M reads per shard with the shared
     # front-stage buffers).  A sharded run also holds every in-flight shard's block range of the run-wide quality stream
     # (5 GB each) and, while a shard is worked on, the text it received from its neighbours and the all-to-all buffers

@@ -264,6 +264,33 @@ __global__ __launch_bounds__(256) void long_names_k(u64 nrec, const u8 *text, co
   for (u32 i = 0; i < n; i++) store[at + i] = text[src + i];
 }
 
+// text offset at which line number `line` (0-based) begins, from the per-tile newline counts (index_count_k + scan): the
+// tile that holds the newline in front of it, then a walk through that tile.  One wavefront; no line index needed.
+__global__ __launch_bounds__(64) void line_offset_k(const u8 *text, u64 nbytes, const u64 *tile_base, u32 ntiles, u64 line, u64 *out) {
+  if (line == 0) { if (threadIdx.x == 0) *out = 0; return; }
+  const u64 want = line - 1;  // the newline with this index (0-based) ends the line in front
+  u32 lo = 0, hi = ntiles;    // largest tile t with tile_base[t] <= want
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (tile_base[mid] <= want) lo = mid; else hi = mid;
+  }
+  u64 seen = tile_base[lo];
+  const u64 t0 = (u64)lo * IDX_TILE, t1 = t0 + IDX_TILE < nbytes ? t0 + IDX_TILE : nbytes;
+  for (u64 p = t0; p < t1; p += 64) {
+    const u64 i = p + threadIdx.x;
+    const u64 m = __ballot(i < t1 && text[i] == '\n');
+    const u32 c = (u32)__popcll(m);
+    if (seen + c > want) {  // the newline is among these 64 bytes: the (want - seen)-th set bit
+      u64 mm = m;
+      for (u64 k = seen; k < want; k++) mm &= mm - 1;
+      if (threadIdx.x == 0) *out = p + (u64)(__ffsll((long long)mm) - 1) + 1;
+      return;
+    }
+    seen += c;
+  }
+  if (threadIdx.x == 0) *out = nbytes;  // fewer lines than asked for
+}
+
 __global__ void last_record_end_k(const u64 *line_end, u64 nrec, u64 *out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *out = nrec ? line_end[4 * nrec - 1] + 1 : 0;
 }

@@ -1145,10 +1145,15 @@ extern "C" int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row,
   *offset = 0;
   if (!row) return SCALCE_OK;
   HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
-  { int rc = ensure_line_index(b, mate, nullptr); if (rc) return rc; }  // (the piece's text must still be where it was)
+  // from the per-tile newline counts of the piece (its text must still be where it was): no line index is built for this
+  const u64 nbytes = b->text_bytes[mate];
+  const u32 ntiles = cdiv(nbytes, IDX_TILE);
+  if (!ntiles || !b->piece_text[mate]) { set_err(b->ctx, "no piece ingested"); return SCALCE_ERR_ARG; }
+  u64 *d_out = b->d_small64 + 7;
+  LAUNCH(line_offset_k, 1, 64, 0, nullptr, b->piece_text[mate], nbytes, b->tile[mate].as<u64>(), ntiles, (u64)(4 * row), d_out);
   u64 v = 0;
-  HIP_TRY(b->ctx, hipMemcpy(&v, b->line_end[mate].as<u64>() + 4 * row - 1, sizeof(u64), hipMemcpyDeviceToHost));
-  *offset = v + 1;
+  HIP_TRY(b->ctx, hipMemcpy(&v, d_out, sizeof(u64), hipMemcpyDeviceToHost));
+  *offset = v;
   return SCALCE_OK;
 }
 
