@@ -1351,7 +1351,17 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
       const u32 w = (u32)b->L[m];
       ENSURE(b, b->qs[m], (size_t)w * N + 64);
       LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
-      if (b->lean) { HIP_TRY(c, hipStreamSynchronize(s)); release(b->q[m]); }  // the next mate's stream takes its place
+      if (b->lean) {
+        // q' in input order is dead once its reordered copy exists.  Mate 1's buffer becomes mate 2's reordered stream (an
+        // allocation and a release of tens of GB each cost a good part of a second), the last one is released.
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (m == 0 && b->nm == 2 && !b->qs[1].p && b->q[0].cap >= (size_t)b->L[1] * N + 64) {
+          b->qs[1] = b->q[0];
+          b->q[0] = DBuf();
+        } else {
+          release(b->q[m]);
+        }
+      }
     }
     if (b->nm == 2) {  // mate 2: bare packed reads in the same order (compress.cpp:380-383 with fR = file 4)
       const u32 w = (u32)b->szr[1];
@@ -1369,7 +1379,8 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
                     &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place, &b->chosen, &b->G, &b->cand_place,
                     &b->bucket, &b->endv, &b->tokens, &b->chunk, &b->perm_a, &b->perm_b, &b->key_a, &b->key_b, &b->hist, &b->S,
                     &b->run_head, &b->run_hcount, &b->run_rank, &b->runid, &b->run_items_a, &b->run_items_b, &b->run_pos};
-    for (DBuf *d : dead) release(*d);
+    for (DBuf *d : dead)
+      if (d->cap >= (256u << 20)) release(*d);  // (the big ones; releasing dozens of small buffers only costs time)
     b->perm = nullptr;
     b->sorted_keys = nullptr;
     b->row_cap = 0;
