@@ -316,7 +316,7 @@ struct MateSource {
   // of the page cache delivers about 5 GB/s, a tenth of what the upload behind it can take.
   int64_t read_plain(uint8_t *dst, uint64_t cap) {
     const uint64_t SLICE = 16u << 20;
-    const int nt = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(g_threads, 16)), (cap + SLICE - 1) / SLICE);
+    const int nt = (int)std::min<uint64_t>((uint64_t)std::max(1, std::min(g_threads, 8)), (cap + SLICE - 1) / SLICE);
     if (nt <= 1) {
       const int64_t k = ::pread(fd, dst, (size_t)std::min<uint64_t>(cap, 1u << 30), (off_t)fpos);
       if (k > 0) fpos += (uint64_t)k;

@@ -30,7 +30,6 @@ gens = [subprocess.Popen([sys.executable, os.path.join(R, "tools", "gen_fastq.py
 assert all(g.wait() == 0 for g in gens)
 size = os.path.getsize(f1) + os.path.getsize(f2)
 print(f"generated {N} pairs x {L} bp in {time.time() - t0:.0f} s: {size / 1e9:.1f} GB of FASTQ", flush=True)
-din = subprocess.Popen([dig, f1, f2], stdout=subprocess.PIPE, text=True)  # runs beside the compressor
 t1 = time.time()
 r = subprocess.run([cli, "-r", "-c", "no", *FLAGS, "-o", os.path.join(D, "arc"), f1, "--patterns-bin", pbin], capture_output=True, text=True)
 dt = time.time() - t1
@@ -43,7 +42,7 @@ for line in r.stderr.splitlines():
 asz = sum(os.path.getsize(os.path.join(D, f"arc_{m}.scalce{e}")) for m in (1, 2) for e in "nrq")
 print(f"compress: {dt:.1f} s wall = {size / dt / 1e6:.0f} MB/s of FASTQ, archive {asz / 1e9:.2f} GB, "
       f"host peak RSS of children {resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6:.1f} GB", flush=True)
-want = din.communicate()[0].strip()
+want = subprocess.run([dig, f1, f2], capture_output=True, text=True).stdout.strip()  # (not beside the compressor: it would share its memory bandwidth)
 os.remove(f1)
 os.remove(f2)
 t2 = time.time()
