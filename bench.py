@@ -200,13 +200,19 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        cpu = cpu_baseline(text, n, L, args.cpu_sample)
+        try:
+            cpu = cpu_baseline(text, n, L, args.cpu_sample)
+        except Exception as ex:  # noqa: BLE001
+            cpu = {"error": repr(ex)[:300]}
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e:
         for b in batches:   # the CLI is a process of its own and needs the card's memory
             b.close()
         del batches[:], pipe
-        e2e = end_to_end(text, nbytes)
+        try:
+            e2e = end_to_end(text, nbytes)
+        except Exception as ex:  # noqa: BLE001 - a side leg must not take the measured line with it
+            e2e = {"error": repr(ex)[:300]}
 
     traffic, traffic_src = None, None
     kname = "ac_encode_rows_k" if G > 1 else "ac_encode_k"
