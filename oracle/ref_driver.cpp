@@ -8,10 +8,9 @@
  * aho_search / output_name / output_read / output_quality / aho_trie_bucket /
  * bin_prepare / ac_stat / ac_coder / ac_decoder, and dumps what they return.
  *
- * Not reachable without stand-ins (buffio.cpp needs bzlib.h, main.cpp needs
- * sys/sysctl.h, neither is in this image): quality_mapping_init, ac_write/ac_read
- * framing, bin_dump, compress(), decompress().  Those call f_gets/f_read/f_write,
- * which stay unresolved in this binary and are never called.
+ * The whole-file side (quality_mapping_init's sampling loop, ac_write/ac_read framing,
+ * bin_dump, compress(), decompress()) is ref_full.cpp's job; this harness looks INSIDE the
+ * path: per-read tokens, order, records, counters, coder bytes.
  *
  * usage: ref_driver <fastq> <outdir> [-P patterns.txt] [-q qmap.txt] [-2 fastq2 [-q2 qmap2.txt]] [-f factor] [-n] [-t]
  *   -P  text core list (read_patterns_from_file) instead of the embedded patterns.bin
@@ -58,8 +57,7 @@ int _thread_count = 1;
 int _decompress = 0;
 int _no_ac = 0;
 int _compress_qualities = 1;
-int32_t read_length[2];
-int64_t reads_count = 0;
+/* read_length[2], reads_count: compress.cpp:61-62 (compress.o is linked, so nothing is left unresolved) */
 
 void bin_prepare(aho_trie *t); /* reads.cpp:54 */
 extern char _binary_patterns_bin_start, _binary_patterns_bin_end; /* reads.cpp:327-328 */

@@ -13,10 +13,12 @@
  *     coder/decoder: pinned against the real reference objects built by
  *     oracle/Makefile into oracle/_ref (tests/test_oracle_vs_ref.py) and the
  *     golden vectors under tests/golden/ generated from them.
- *   - quality_mapping_init, AC block framing, .scalce{n,r,q} layout, -B chunk
- *     rule: restated from the source text; pinned only by the known answers
- *     recorded in SURVEY.md section 8 (no reference binary can be built here
- *     without stand-ins for bzlib.h / sys/sysctl.h).
+ *   - quality_mapping_init's sampling loop, AC block framing, .scalce{n,r,q} layout, -B chunk
+ *     rule and merge order, decompressor: pinned at FILE level against the whole reference
+ *     (oracle/_ref/ref_full = the reference's own compress()/decompress(), every source but
+ *     main.cpp compiled where it lies): tests/golden/files.json holds the SHA-256 of what it
+ *     wrote for the cases of tests/filecases.py, tests/test_ref_files.py checks orc_cli (CPU)
+ *     and the scalce binary (GPU) against them.
  */
 #ifndef SCALCE_ORACLE_H
 #define SCALCE_ORACLE_H

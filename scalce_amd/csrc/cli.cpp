@@ -301,9 +301,14 @@ struct MateSource {
     return false;
   }
   uint64_t fpos = 0;  // plain files: where the next read starts
+  bool hold_at_file_end = false;  // fill_peek: the sample never runs into the next file
   int64_t read_raw(void *dst, uint64_t cap) {
     for (;;) {
-      if (fd < 0 && !gz) { if (!open_next()) return 0; fpos = 0; }
+      if (fd < 0 && !gz) {
+        if (hold_at_file_end && cur >= 1) return 0;
+        if (!open_next()) return 0;
+        fpos = 0;
+      }
       int64_t k;
       if (gz) k = gzread(gz, dst, (unsigned)std::min<uint64_t>(cap, 1u << 30));
       else k = read_plain(static_cast<uint8_t *>(dst), cap);
@@ -357,8 +362,14 @@ struct MateSource {
     }
     return read_raw(dst, cap);
   }
-  // read ahead until the text holds `records` records (or the stream ends): quality_mapping_init's sample
+  // read ahead until the text holds `records` records or the FIRST file ends: quality_mapping_init's sample is taken
+  // from files[0] alone (get_quality_stats, compress.cpp:761; the loop of qualities.cpp:66-78 stops at its end)
   void fill_peek(int records) {
+    hold_at_file_end = true;
+    fill_peek_held(records);
+    hold_at_file_end = false;
+  }
+  void fill_peek_held(int records) {
     size_t lines = 0, scanned = 0;
     for (;;) {
       const uint8_t *p = peek.data();
