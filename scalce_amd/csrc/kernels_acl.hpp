@@ -1,0 +1,431 @@
+// kernels_acl.hpp -- arithmetic coder, one 10 MiB block per LANE (ac_encode_lanes_k).
+// Reference: ac_coder::{write,flush} (/root/reference/arithmetic.cpp:108-169), block framing of ac_write (:318-363).
+//
+// ac_encode_k / ac_encode_rows_k (kernels_ac.hpp) spend a wavefront on 1, 4 or 8 blocks: lowest latency of a block, but
+// 56..63 of the 64 lanes execute garbage in every step, and a launch of three 50 M-read shards occupies 179 CUs at 59 %
+// for as long as it runs.  Here every lane of the chain wave carries its OWN block: the same ~13 instructions of a step
+// serve 64 blocks, nothing moves between lanes (no DPP, no hand-over), and 1431 blocks are 23 workgroups of three waves --
+// the chip is left to the front stages of the other shards in flight.  A block's latency stays what it was (one step is
+// still ~16 issue slots of one wavefront).
+//
+// What makes a lane self-sufficient is the form of the output.  The reference writes bits one at a time with a count of
+// pending "underflow" bits (arithmetic.cpp:133-147); that count is carry propagation in disguise: the coded block is the
+// binary expansion of
+//     X = raw16 . sum_i  B_i * 2^-(16 + S_i + 32),     S_i = t_0 + .. + t_(i-1),
+// B_i = floor(range_i * c_lo / total) the offset step i adds to `lo`, t_i the bits step i renormalises by -- closed by
+// the flush of :160-169, which keeps S + 2 bits behind the raw symbols: (X cut there | 1) + bit 30 of the final lo.
+// (Checked against the oracle's coder, incl. heavy-underflow tables, before this kernel was written; the parity tests
+// drive carries through words that were already stored.)  So the bit sink of a block is a 96-bit accumulator in three
+// registers: add B at the current bit offset, move on by t, store a word whenever 32 bits are complete; a carry beyond
+// the last complete word (it needs 32 ones in a row there) walks back through the stored words, rarely.
+//
+// Workgroup = three wavefronts over the same 64 blocks, rounds of 16 symbols per block:
+//   gather  lane b reads block b's symbols 16 at a time, forms the contexts and fetches the table rows
+//           {g(c_lo), g(c_hi)} (kernels_ac.hpp: reciprocal fractions) three rounds ahead, straight into LDS
+//           (global_load_lds_dwordx4: the row of lane b lands at ops[slot][step][b], no register in between)
+//   chain   16 x { ds_read_b128 operands, 13 VALU: A, B, D, nlo, renorm count, new (lo, M) ; ds_write_b64 (B, t) }
+//           rounds that are not plain for a lane -- the first (two raw symbols), a block's tail, a symbol that is the
+//           last of its context, a range that renormalises to the full 2^32 -- are redone for those lanes by the
+//           general step under the exec mask
+//   sink    lane b adds block b's (B, t) records of the previous round into its accumulator and stores finished words
+// One LDS-only barrier per round.  Contexts depend on symbols only, never on coder state, which is why the gather
+// wave can run ahead.
+// Only for tables whose largest context total is <= 2^29 (the host checks, as for the plain path of ac_encode_k):
+// every symbol then keeps an interval of at least two values, and the reference's coder never runs into the inverted
+// intervals whose bits are not those of X.
+#pragma once
+#include "kernels_ac.hpp"
+
+namespace scalce {
+
+constexpr int ACL_STEPS = 16;  // symbols per block and round
+
+// general step on a well-formed state, reporting what the sink needs: B = offset added to lo, t = bits dropped
+__device__ __forceinline__ void acl_step_general(u32 &lo, u32 &hi, const uint4 g, u32 &B, u32 &t) {
+  const u32 R = hi - lo;
+  u32 M;
+  const bool wrap = __builtin_add_overflow(R, 1u, &M);
+  const u32 qa = mulfrac_m(M, wrap, g.z, g.w);
+  const u32 qb = mulfrac_m(M, wrap, g.x, g.y);
+  const u32 nhi = (g.w == 0xFFFFFFFFu) ? hi : lo + qa - 1;  // c_hi == total: hi unchanged
+  const u32 nlo = lo + qb;
+  B = qb;
+  const u32 x = nlo ^ nhi;
+  const u32 kf = x ? (u32)__clz(x) : 31u;  // x == 0 needs a context total above 2^29: excluded by the host
+  const u32 ks = kf < 31u ? kf : 31u;
+  const u32 z = ((nlo & ~nhi) << ks) << 1;
+  const u32 u = (u32)__clz(~z);
+  t = ks + u;
+  lo = (nlo << t) & 0x7FFFFFFFu;
+  hi = (nhi << t) | ((1u << t) - 1) | 0x80000000u;
+}
+
+// plain step on (lo, M), M = hi - lo + 1 modulo 2^32 (sys_step of kernels_ac.hpp without the travelling): lo keeps a
+// stray bit 31 (it changes neither B nor t), M = 0 is absorbing (D + 1 = 0 whatever the operands) and is what the
+// round's exit test looks for afterwards
+__device__ __forceinline__ void acl_step_plain(u32 &lo, u32 &M, const uint4 g, u32 ones, u32 zero, u32 &B, u32 &t) {
+  const u32 A1 = (u32)(((u64)M * g.w + (((u64)ones << 32) | __umulhi(M, g.z))) >> 32);
+  B = (u32)(((u64)M * g.y + (((u64)zero << 32) | __umulhi(M, g.x))) >> 32);
+  const u32 D = A1 - B;
+  const u32 nlo = lo + B;
+  t = renorm_count(nlo, D);
+  M = (D + 1) << t;
+  lo = nlo << t;
+}
+
+// Bit sink of one block in one lane.  [w2 w1 w0] is a 96-bit window of X: w2 = the block's word at byte offset `wi4`
+// (complete, kept back because a carry may still reach it), the top bit of B sits `pos` bits below the top of w1.
+//
+// What an instruction costs a lone wavefront here (tools/ubench_lds.hip): a VALU instruction 4 cycles; a DS instruction
+// 17 (read) to 25-35 (write) whatever its width; a scattered global store ~100 with all lanes, ~40 with four; and every
+// trip from a VALU result through an SGPR into a scalar instruction or a branch -- s_and_saveexec, s_cbranch_vccz -- ~16
+// on top.  As first written, with the natural ifs (carry? word complete? room?), a step was 55 instructions, seven
+// branches and a masked store: 330 cycles, and the chain wave waited for the sink 66 % of its time; without the ifs that
+// guard nothing, 200.  Hence the shape of step(): fifteen VALU instructions and ONE LDS store, no branch, no exec mask --
+//   * w2 goes to the lane's row of an LDS staging ring in every step, complete or not (a later step overwrites it); the
+//     complete words of all lanes leave once per round, 16 bytes per lane and store;
+//   * a carry out of w2 (it needs w2 = 0xFFFFFFFF) is only COUNTED; a lane that counted one redoes its round from the
+//     saved state with careful(), which notes where the carry belongs;
+//   * the notes -- word indices, in a log that grows down from the end of the block's own output buffer -- are applied by
+//     finish(): additions commute.  (Resolved on the spot, a loop of loads and stores in the step sequence, the compiler
+//     put s_waitcnt vmcnt(0) in front of every store of the following steps.)
+constexpr int ACL_ROW_WORDS = 32;  // staging ring per lane: a round adds at most 16 words to at most 3 left over
+struct AclSink {
+  SCALCE_GLOBAL u32 *dst;
+  u32 *row;      // this lane's staging ring in LDS
+  u32 wcap;      // words the block may write
+  u32 w2, w1, w0;
+  u32 pos;       // 0..31
+  int wi4;       // byte offset of w2's word; -4 while w2 is the (empty) word in front of the block
+  int wo4;       // bytes that have left for global memory (multiple of 16)
+  u32 ncar;      // carries out of w2 counted by step() in this round
+  u32 nlog;      // notes in the log
+  bool over;
+  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 *r, u32 cap_words, u32 s0, u32 s1) {
+    dst = d; row = r; wcap = cap_words;
+    w2 = 0; w1 = (s0 << 24) | (s1 << 16); w0 = 0;  // the two raw symbols (arithmetic.cpp:110-120): 16 bits of X
+    pos = 16; wi4 = -4; wo4 = 0; ncar = 0; nlog = 0; over = false;
+  }
+  // room for a round's words and notes?  (once per round: a lane that runs out of room stops and reports)
+  __device__ __forceinline__ bool room() {
+    if (wi4 / 4 + 2 * ACL_STEPS + 2 + (int)nlog >= (int)wcap) over = true;
+    return !over;
+  }
+  // the step: X += B at the window's bit offset, then t bits on
+  __device__ __forceinline__ void step(u32 B, u32 t) {
+    const u32 b_hi = B >> pos;
+    const u32 b_lo = __builtin_amdgcn_alignbit(B, 0u, pos);  // low word of {B, 0} >> pos: B << (32 - pos), 0 for pos = 0
+    u32 c0, c1, c2;
+    w0 = __builtin_addc(w0, b_lo, 0u, &c0);
+    w1 = __builtin_addc(w1, b_hi, c0, &c1);
+    w2 = __builtin_addc(w2, 0u, c1, &c2);
+    ncar += c2;
+    const u32 pos2 = pos + t;
+    row[((u32)wi4 >> 2) & (ACL_ROW_WORDS - 1)] = w2;  // final if this step completes the word, overwritten otherwise
+    const bool f = pos2 >= 32u;
+    wi4 += (int)((pos2 >> 5) << 2);
+    w2 = f ? w1 : w2;
+    w1 = f ? w0 : w1;
+    w0 = f ? 0u : w0;
+    pos = pos2 & 31u;
+  }
+  // the same step for the rare cases: the word in front of the block is not stored, a carry out of w2 is noted
+  __device__ __forceinline__ void careful(u32 B, u32 t) {
+    const u32 b_hi = B >> pos;
+    const u32 b_lo = __builtin_amdgcn_alignbit(B, 0u, pos);
+    u32 c0, c1, c2;
+    w0 = __builtin_addc(w0, b_lo, 0u, &c0);
+    w1 = __builtin_addc(w1, b_hi, c0, &c1);
+    w2 = __builtin_addc(w2, 0u, c1, &c2);
+    if (c2 != 0u) {
+      dst[wcap - 1u - nlog] = (u32)(wi4 / 4 - 1);
+      nlog++;
+    }
+    const u32 pos2 = pos + t;
+    if (wi4 >= 0) row[((u32)wi4 >> 2) & (ACL_ROW_WORDS - 1)] = w2;
+    if (pos2 >= 32u) { wi4 += 4; w2 = w1; w1 = w0; w0 = 0u; }
+    pos = pos2 & 31u;
+  }
+  // complete words out of the staging ring, 16 bytes per lane at a time (words [wo4, wi4) are final)
+  __device__ __forceinline__ void drain() {
+    while (__any(wi4 - wo4 >= 16)) {
+      if (wi4 - wo4 >= 16) {
+        const u32x4 v = *(const u32x4 *)(row + (((u32)wo4 >> 2) & (ACL_ROW_WORDS - 1)));
+        u32x4 o;
+        o.x = __builtin_bswap32(v.x); o.y = __builtin_bswap32(v.y); o.z = __builtin_bswap32(v.z); o.w = __builtin_bswap32(v.w);
+        *(SCALCE_GLOBAL u32x4 *)(dst + ((u32)wo4 >> 2)) = o;
+        wo4 += 16;
+      }
+    }
+  }
+  static __device__ __forceinline__ void carry_back(SCALCE_GLOBAL u32 *dst, u32 wcap, int k) {
+    for (; k >= 0; k--) {
+      if ((u32)k >= wcap) continue;
+      const u32 v = __builtin_bswap32(__hip_atomic_load(&dst[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+      __hip_atomic_store(&dst[k], __builtin_bswap32(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v) break;
+    }
+  }
+  // flush (arithmetic.cpp:160-169) in terms of X: cut behind the bit after B's top position, set that bit, add bit 30 of
+  // the final lo there.  Returns the block's size in bytes.
+  __device__ __forceinline__ u32 finish(u32 final_lo) {
+    for (; wo4 < wi4; wo4 += 4) {  // what the ring still holds
+      const u32 k = (u32)wo4 >> 2;
+      if (k < wcap) dst[k] = __builtin_bswap32(row[k & (ACL_ROW_WORDS - 1)]);
+      else over = true;
+    }
+    const int wi = wi4 / 4;  // -1 .. (wi4 = -4 only for blocks of a few symbols)
+    const u64 ulp = 1ull << (62u - pos);
+    u64 v = ((u64)w1 << 32) | w0;
+    v = (v & ~(ulp - 1)) | ulp;
+    if ((final_lo >> 30) & 1u) {
+      const bool c = __builtin_add_overflow(v, ulp, &v);
+      if (c) {
+        w2 += 1u;
+        if (w2 == 0u && !over) { dst[wcap - 1u - nlog] = (u32)(wi - 1); nlog++; }
+      }
+    }
+    const u32 bits = 32u * (u32)(wi + 1) + pos + 2u;
+    const u32 words[3] = {w2, (u32)(v >> 32), (u32)v};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int idx = wi + k;
+      if (idx >= 0 && 32u * (u32)idx < bits) {
+        if ((u32)idx < wcap) dst[idx] = __builtin_bswap32(words[k]);
+        else over = true;
+      }
+    }
+    if (nlog && !over) {  // the carries noted on the way, into the words as they stand now
+      __threadfence();
+      for (u32 e = 0; e < nlog; e++) {
+        const int k = (int)__hip_atomic_load(&dst[wcap - 1u - e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        carry_back(dst, wcap, k);
+      }
+    }
+    return (bits + 7) >> 3;
+  }
+};
+
+constexpr int ACL_SLOTS = 4;   // operand ring: the gather wave runs up to three rounds ahead of the chain
+struct AclShared {
+  uint4 ops[ACL_SLOTS][ACL_STEPS][64];  // gather -> chain: operands of a round (slot = round % ACL_SLOTS), written by LDS-direct loads
+  uint2 rec[2][ACL_STEPS][64];          // chain -> sink: (B, t) of a round
+  u32 stage[64][ACL_ROW_WORDS];         // sink: coded words on their way out
+  u32 final_lo[64];
+};
+
+// VMEM of the gather wave is issued and awaited by hand.  Its loads are consumed two to four rounds after they were
+// requested, across the loop's back edge, where the compiler's own s_waitcnt placement falls back to vmcnt(0) -- a full
+// memory round trip exposed in every other round (the first version of this kernel: 110 cycles per step in the gather
+// wave).  The compiler never sees these loads, so it inserts nothing; the counts below are exact because the wave issues
+// no other vector memory instruction.
+__device__ __forceinline__ u32x4 acl_load16(const SCALCE_GLOBAL u8 *p) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void acl_wait_vm(u32x4 &v) {  // ... until at most N younger VMEM instructions are outstanding
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void acl_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
+  __shared__ AclShared sh;
+  const int lane = lane_id();
+  const int role = wave_id();  // 0 chain, 1 gather, 2 sink: three SIMDs of the CU
+  const u32 blk = blockIdx.x * 64u + (u32)lane;
+  const bool have = blk < a.nblocks;
+  const SCALCE_GLOBAL AcBlockDesc *dp = (const SCALCE_GLOBAL AcBlockDesc *)a.desc + (have ? blk : 0u);
+  const u32 n = have ? dp->n : 0u;
+  const u32 nr = (n + ACL_STEPS - 1) / ACL_STEPS;  // rounds of this lane's block
+  u32 nr_wg = nr;                                    // rounds of the workgroup = those of its longest block
+#pragma unroll
+  for (int d = 32; d; d >>= 1) { const u32 o = __shfl_xor(nr_wg, d, 64); nr_wg = o > nr_wg ? o : nr_wg; }
+  nr_wg = __builtin_amdgcn_readfirstlane(nr_wg);
+  if (!nr_wg) return;
+  if (a.prof && lane == 0) atomicOr((unsigned int *)&a.prof[blockIdx.x * 5 + 2], (simd_key() & 3u) << (4 * role));  // profiling: which SIMD each role runs on
+
+  if (role == 1) {
+    // ================= gather: table rows straight into LDS, three rounds ahead =================
+    const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
+    const SCALCE_GLOBAL u32x4 *tab = (const SCALCE_GLOBAL u32x4 *)dp->tab;
+    // 16 symbols of round k.  The block's symbols are 16-byte aligned (blocks start at multiples of 10 MiB of a 16-byte
+    // aligned stream); a read that starts inside the block may run up to 15 bytes past its end (the stream buffers are
+    // padded), one that would start past it falls back to the block's first symbols -- garbage nobody uses either way.
+    auto sym_addr = [&](u32 k) -> const SCALCE_GLOBAL u8 * {
+      const u32 off = k * ACL_STEPS < n ? k * ACL_STEPS : 0u;
+      return sp + off;
+    };
+    u32 p0 = 0, p1 = 0;  // the two symbols in front of the next round to be addressed
+    // 16 LDS-direct loads: row (p0, p1, c) of the lane's table -> ops[k % ACL_SLOTS][j][lane]
+    auto request = [&](const u32x4 sy, u32 k) {
+      uint4 *slot = &sh.ops[k % ACL_SLOTS][0][0];
+#pragma unroll
+      for (int j = 0; j < ACL_STEPS; j++) {
+        const u32 word = j < 4 ? sy.x : j < 8 ? sy.y : j < 12 ? sy.z : sy.w;
+        u32 c = (word >> (8 * (j & 3))) & 0xFFu;
+        const u32 D1 = AC_D - 1;
+        c = c < D1 ? c : D1;  // symbols >= AC_D raised E_SYMBOL at ingest; stay inside the table regardless
+        const u32 idx = (p0 * AC_D + p1) * AC_D + c;
+        __builtin_amdgcn_global_load_lds((const SCALCE_GLOBAL void *)(tab + idx), (__attribute__((address_space(3))) void *)(slot + j * 64), 16, 0, 0);
+        p0 = p1;
+        p1 = c;
+      }
+    };
+    // VMEM in issue order: prologue [S0 S1 S2 S3] wait [R0 S4] [R1 S5] [R2 S6], then per iteration i [R(i+3) S(i+7)];
+    // R = 16 instructions.  Symbols S(k) sit in set k % 4.
+    u32x4 s0 = acl_load16(sym_addr(0)), s1 = acl_load16(sym_addr(1)), s2 = acl_load16(sym_addr(2)), s3 = acl_load16(sym_addr(3));
+    acl_wait_vm<3>(s0);
+    request(s0, 0); s0 = acl_load16(sym_addr(4));
+    acl_wait_vm<2 + 17>(s1);
+    request(s1, 1); s1 = acl_load16(sym_addr(5));
+    acl_wait_vm<1 + 2 * 17>(s2);
+    request(s2, 2); s2 = acl_load16(sym_addr(6));
+    acl_wait_vm<2 * 17>();  // round 0 is in LDS
+    asm volatile("s_barrier" ::: "memory");
+    u64 gprof_wait = 0;
+    // iteration i: symbols of round i + 3 are here when at most the three iterations behind them are outstanding; round
+    // i + 1 is in LDS when at most iterations i - 1 and i are
+    auto iteration = [&](u32 i, u32x4 &sset) {
+      acl_wait_vm<3 * 17>(sset);
+      request(sset, i + 3);
+      sset = acl_load16(sym_addr(i + 7));
+      acl_wait_vm<2 * 17>();
+      if (a.prof) {
+        const u64 w0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_barrier" ::: "memory");
+        gprof_wait += __builtin_amdgcn_s_memtime() - w0;
+      } else {
+        asm volatile("s_barrier" ::: "memory");
+      }
+    };
+    for (u32 i = 0; i < nr_wg; i += 4) {
+      iteration(i, s3);
+      if (i + 1 < nr_wg) iteration(i + 1, s0);
+      if (i + 2 < nr_wg) iteration(i + 2, s1);
+      if (i + 3 < nr_wg) iteration(i + 3, s2);
+    }
+    acl_wait_vm<0>();  // nothing of this wave may land in LDS after the workgroup has gone
+    if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 3] = gprof_wait;
+  } else if (role == 0) {
+    // ================= chain: 64 coder states =================
+    __builtin_amdgcn_s_setprio(3);
+    u32 ones, zero;
+    asm("v_mov_b32 %0, -1" : "=v"(ones));
+    asm("v_mov_b32 %0, 0" : "=v"(zero));
+    u32 lo = 0, M = 0;  // M = 0 stands for 2^32
+    u64 prof_wait = 0;
+    const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
+    __syncthreads();  // round 0's operands are in LDS
+    for (u32 r = 0; r < nr_wg; r++) {
+      const int slot = r % ACL_SLOTS;
+      const u32 lo0 = lo, M0 = M;
+      // all 16 operand reads are issued before the first step (read at the point of use, every step waited for a full
+      // LDS round trip)
+      uint4 g[ACL_STEPS];
+#pragma unroll
+      for (int j = 0; j < ACL_STEPS; j++) g[j] = sh.ops[slot][j][lane];
+      u32 topw = 0;  // g(c_hi) = 2^64 - 1 marks the last symbol of a context (ac_table_k); no regular high word reaches that
+#pragma unroll
+      for (int j = 0; j < ACL_STEPS; j++) {
+        u32 B, t;
+        acl_step_plain(lo, M, g[j], ones, zero, B, t);
+        sh.rec[r & 1][j][lane] = make_uint2(B, t);
+        topw = g[j].w > topw ? g[j].w : topw;
+      }
+      const bool live = r < nr;
+      const bool poisoned = a.test_poison && r % a.test_poison == 0;
+      const bool complete = r > 0 && r * ACL_STEPS + ACL_STEPS <= n;  // not the round of the raw symbols, not a tail
+      const bool fast_ok = complete && topw != 0xFFFFFFFFu && M0 != 0u && M != 0u && !poisoned;
+      const bool fix = live && !fast_ok;  // this lane's records of the round are rewritten by general steps (a lane whose
+                                          // block has ended computes garbage nobody reads: the sink skips it)
+      if (__builtin_expect(__any(fix), 0)) {
+        if (fix) {
+          u32 glo = lo0 & 0x7FFFFFFFu, ghi = glo + M0 - 1u;
+          const u32 jstart = r == 0 ? 2u : 0u;
+          const u32 left = n - r * ACL_STEPS;
+          const u32 jend = left < (u32)ACL_STEPS ? left : (u32)ACL_STEPS;
+#pragma unroll 1
+          for (u32 j = 0; j < (u32)ACL_STEPS; j++) {
+            const uint4 gj = sh.ops[slot][j][lane];
+            u32 B = 0, t = 0;
+            if (j >= jstart && j < jend) acl_step_general(glo, ghi, gj, B, t);
+            sh.rec[r & 1][j][lane] = make_uint2(B, t);
+          }
+          lo = glo;
+          M = ghi - glo + 1u;
+        }
+      }
+      if (r + 1 == nr) sh.final_lo[lane] = lo & 0x7FFFFFFFu;
+      if (a.prof) {
+        const u64 w0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        prof_wait += __builtin_amdgcn_s_memtime() - w0;
+      } else {
+        __syncthreads();
+      }
+    }
+    if (a.prof && lane == 0) {
+      a.prof[blockIdx.x * 5 + 0] = prof_wait;
+      a.prof[blockIdx.x * 5 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
+    }
+  } else {
+    // ================= sink: 64 bit accumulators, one round behind the chain =================
+    AclSink sk;
+    {
+      const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
+      const u32 s0 = n ? (u32)sp[0] : 0u, s1 = n > 1 ? (u32)sp[1] : 0u;
+      sk.init((SCALCE_GLOBAL u32 *)dp->dst, &sh.stage[lane][0], a.out_cap / 4, s0, s1);
+    }
+    barrier_lds_only();
+    u64 sprof_wait = 0;
+    auto take = [&](u32 r) {  // the records of round r
+      if (r < nr && sk.room()) {  // (per lane: a block that has ended has no records)
+        uint2 v[ACL_STEPS];
+#pragma unroll
+        for (int j = 0; j < ACL_STEPS; j++) v[j] = sh.rec[r & 1][j][lane];
+        if (r == 0) {  // the first word of the block is on its way: the careful step knows about the empty word in front of it
+#pragma unroll 1
+          for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[0][j][lane].x, sh.rec[0][j][lane].y);
+        } else {
+          const u32 s2 = sk.w2, s1 = sk.w1, s0 = sk.w0, spos = sk.pos;
+          const int swi4 = sk.wi4;
+          sk.ncar = 0;
+#pragma unroll
+          for (int j = 0; j < ACL_STEPS; j++) sk.step(v[j].x, v[j].y);
+          if (__builtin_expect(__any(sk.ncar != 0u), 0)) {
+            if (sk.ncar != 0u) {
+              sk.w2 = s2; sk.w1 = s1; sk.w0 = s0; sk.pos = spos; sk.wi4 = swi4;
+#pragma unroll 1
+              for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[r & 1][j][lane].x, sh.rec[r & 1][j][lane].y);
+            }
+          }
+        }
+      }
+      sk.drain();
+    };
+    for (u32 r = 0; r < nr_wg; r++) {
+      if (r > 0) take(r - 1);
+      if (a.prof) {
+        const u64 w0 = __builtin_amdgcn_s_memtime();
+        barrier_lds_only();
+        sprof_wait += __builtin_amdgcn_s_memtime() - w0;
+      } else {
+        barrier_lds_only();
+      }
+    }
+    if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 4] = sprof_wait;
+    take(nr_wg - 1);
+    if (have && n) {
+      const u32 bytes = sk.finish(sh.final_lo[lane]);
+      *(SCALCE_GLOBAL u32 *)dp->out_size = bytes;
+      if (sk.over) dev_fail(dp->err, E_ACOVERFLOW, dp->index, bytes);
+    }
+  }
+}
+
+}  // namespace scalce

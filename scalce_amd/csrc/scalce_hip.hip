@@ -13,7 +13,7 @@
 
 #include "../../include/scalce_hip.h"
 #include "automaton.hpp"
-#include "kernels_ac.hpp"
+#include "kernels_acl.hpp"
 #include "kernels_fastq.hpp"
 
 using namespace scalce;
@@ -332,6 +332,7 @@ struct scalce_batch {
   // entropy launched but its result size not read back yet (scalce_batch_entropy_begin / _end): blocks per mate
   u64 *prof_ptr = nullptr;  // SCALCE_AC_PROF of the last rows-coder launch this shard led
   u32 prof_n = 0;
+  bool prof_lanes = false;
   u32 ent_pending[2] = {0, 0};
   u32 frame_deferred[2] = {0, 0};  // blocks coded by a grouped launch and not framed yet (entropy_collect frames them)
   // symbol stream to code per mate: the shard's own reordered stream, or one the caller assembled (sharded runs)
@@ -1528,9 +1529,13 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
+    // one block per lane only follows the reference while no interval can invert (kernels_acl.hpp)
+    if (blocks_per_wg == 64 && general) blocks_per_wg = 8;
     const u32 nwg = cdiv(total, (u32)blocks_per_wg);
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * nwg)); }
-    if (blocks_per_wg == 8) {
+    if (blocks_per_wg == 64) {
+      LAUNCH(ac_encode_lanes_k, cdiv(total, 64), 192, 0, s, a);
+    } else if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
     } else {
@@ -1541,6 +1546,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     if (a.prof) {  // profiling only: read back when the lead shard is collected (the launch keeps running beside others)
       lead->prof_ptr = a.prof;
       lead->prof_n = nwg;
+      lead->prof_lanes = blocks_per_wg == 64;
     }
   }
   for (int i = 0; i < njobs; i++) lead->k_in_bytes += jobs[i].nsym;
@@ -1564,7 +1570,7 @@ static int ac_blocks_per_wg() {
   // one block per workgroup (lowest latency of a block) or four (0.57 x the SIMD time per block, 1.2 x the latency)
   const char *bpw = getenv("SCALCE_AC_BLOCKS_PER_WG");
   const int v = bpw ? atoi(bpw) : 1;
-  return (v == 4 || v == 8) ? v : 1;
+  return (v == 4 || v == 8 || v == 64) ? v : 1;
 }
 
 // Code one mate's symbol stream `d_sym` (nsym symbols, first symbol = start of a 10 MiB block of the run-wide
@@ -1587,6 +1593,14 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
     fprintf(stderr, "ac prof (rows): %u workgroups, chain waves waited at the barrier %.1f %% of their time (%.0f of %.0f Mcycles each), "
             "the first helper wave %.1f %%\n",
             b->prof_n, 100.0 * wait / tot, wait / b->prof_n / 1e6, tot / b->prof_n / 1e6, 100.0 * hwait / (htot > 0 ? htot : 1));
+    if (b->prof_lanes) {
+      fprintf(stderr, "ac prof (lanes): SIMD of chain / gather / sink per workgroup:");
+      for (u32 i = 0; i < b->prof_n && i < 24; i++) fprintf(stderr, " %llu%llu%llu", h[5 * i + 2] & 15, (h[5 * i + 2] >> 4) & 15, (h[5 * i + 2] >> 8) & 15);
+      fprintf(stderr, "\n");
+    }
+    if (b->prof_lanes)
+      fprintf(stderr, "ac prof (lanes): of the chain wave's %.0f Mcycles the gather wave waited at the barrier %.1f %%, the sink wave %.1f %%\n",
+              tot / b->prof_n / 1e6, 100.0 * hwait / tot, 100.0 * htot / tot);
     hipFree(b->prof_ptr);
     b->prof_ptr = nullptr;
   }

@@ -482,7 +482,7 @@ def test_grouped_coder_launch_equals_separate_launches(ctx, monkeypatch):
             quals = (rng.integers(0, 80, size=(n, L)) + 33).astype(np.uint8)
         fq = synth.fastq_bytes_fast(bases, quals)
         texts.append((device_bytes(fq), len(fq), n, L))
-    for variant in ("1", "4"):
+    for variant in ("1", "4", "64"):
         monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", variant)
         outs = []
         for t, nb, n, L in texts:
@@ -492,8 +492,9 @@ def test_grouped_coder_launch_equals_separate_launches(ctx, monkeypatch):
             outs.append(b.output(host.OUT_QUAL, 0).copy())
         alone.append(outs)
     monkeypatch.delenv("SCALCE_AC_BLOCKS_PER_WG")
-    for a1, a4 in zip(*alone):
+    for a1, a4, a64 in zip(*alone):
         assert len(a1) == len(a4) and (a1 == a4).all()
+        assert len(a1) == len(a64) and (a1 == a64).all()
     group = []
     for t, nb, n, L in texts:
         b = host.Batch(ctx, L, n + 8, nb + 64)
@@ -507,7 +508,7 @@ def test_grouped_coder_launch_equals_separate_launches(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks_per_wave", ["1", "4", "8"])
+@pytest.mark.parametrize("blocks_per_wave", ["1", "4", "8", "64"])
 def test_rows_coder_redo_path(blocks_per_wave, ctx, oracle_trie, monkeypatch):
     """The coder kernels find a step that needed the general path by the absorbing state it leaves behind (range = 2^32
     -> M = 0 in the last lane at the end of the super-round) and redoes the block's super-round on the general path.
@@ -578,7 +579,7 @@ def test_rows_coder_repeated_launches(ctx, oracle_trie, monkeypatch):
     ref = oracle_streams(oracle_trie, bases, quals, 33, None)
     want = None
     for rep in range(6):
-        for bpw in ("8", "4"):
+        for bpw in ("8", "4", "64"):
             monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", bpw)
             b = hip_compress(ctx, fq, 100)
             if want is None:
@@ -588,7 +589,7 @@ def test_rows_coder_repeated_launches(ctx, oracle_trie, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("blocks_per_wave", ["1", "4", "8"])
+@pytest.mark.parametrize("blocks_per_wave", ["1", "4", "8", "64"])   # (64: the host falls back to eight per wave)
 def test_coder_general_step_through_inverted_intervals(blocks_per_wave, ctx, monkeypatch):
     """A context total beyond 2^30 (reachable at 50 M x 100 with binned, low-entropy qualities) makes the reference's
     32-bit coder run through inverted intervals: lo = 1.., hi = 0.. after a step (about 1 % of the steps with this
@@ -614,6 +615,62 @@ def test_coder_general_step_through_inverted_intervals(blocks_per_wave, ctx, mon
     assert len(enc) == len(want), f"{len(enc)} vs {len(want)} bytes"
     bad = np.flatnonzero(enc != want)
     assert len(bad) == 0, f"coder bytes differ from the oracle's first at byte {bad[:3]} of {len(want)}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocks_per_wave", ["1", "8", "64"])
+def test_coder_long_underflow_runs_and_carries(blocks_per_wave, ctx, monkeypatch):
+    """Symbols chosen with the coder's state in hand (gpu_util.craft_straddle): runs of 1..40 symbols whose interval holds
+    the midpoint, so every one of them adds pending underflow bits (arithmetic.cpp:140-146), up to ~260 in a row, and the
+    next symbol resolves them all at once -- '1 000..0' or '0 111..1'.  A quarter of the coded words are all ones or all
+    zeros.  For the one-block-per-lane coder that is a carry walking back through words it has already stored
+    (AclSink::carry_back); for the others the serial emit path.  Two blocks that start with 60 000 such symbols."""
+    import torch
+    from gpu_util import craft_straddle
+    monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", blocks_per_wave)
+    rng = np.random.default_rng(4)
+    row = np.ones(80, dtype=np.uint32)
+    row[8:40] = 1000
+    cum = np.concatenate([[0], np.cumsum(row)])
+    nsym = 10 * 1024 * 1024 + 150_000
+    sym = rng.integers(8, 40, size=nsym).astype(np.uint8)
+    for start in (0, 10 * 1024 * 1024):
+        part, maxpend = craft_straddle(60_000, cum, int(cum[-1]), rng)
+        assert maxpend > 128
+        sym[start:start + len(part)] = part
+    table = np.tile(row, 6400)
+    want = O.AcStat(table).encode_stream(sym)
+    words = np.frombuffer(want[4:4 + 36000].tobytes(), dtype=np.uint32)
+    assert (words == 0xFFFFFFFF).sum() > 500 and (words == 0).sum() > 500   # the case is what it claims to be
+    b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
+    d_sym = torch.from_numpy(sym).to("cuda:0")
+    d_tab = torch.from_numpy(table.view(np.int32)).to("cuda:0")
+    b.entropy_stream(0, d_tab.data_ptr(), d_sym.data_ptr(), nsym)
+    b.finish()
+    enc = b.output(host.OUT_QUAL, 0)
+    assert len(enc) == len(want), f"{len(enc)} vs {len(want)} bytes"
+    bad = np.flatnonzero(enc != want)
+    assert len(bad) == 0, f"coder bytes differ from the oracle's first at byte {bad[:3]} of {len(want)}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsym", [1, 2, 3, 15, 16, 17, 33, 10 * 1024 * 1024, 10 * 1024 * 1024 + 1, 10 * 1024 * 1024 + 2])
+def test_lanes_coder_block_edges(nsym, ctx, monkeypatch):
+    """One block per lane: blocks of 1, 2 and 3 symbols (nothing but the raw symbols and the flush), a round that is
+    exactly full, a second block of one or two symbols behind a full one."""
+    import torch
+    monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", "64")
+    rng = np.random.default_rng(nsym % 1000)
+    sym = np.clip(np.rint(rng.normal(28, 8, size=nsym)), 0, 41).astype(np.uint8)
+    table = (rng.integers(1, 200, size=512000)).astype(np.uint32)
+    want = O.AcStat(table).encode_stream(sym)
+    b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
+    d_sym = torch.from_numpy(np.concatenate([sym, np.zeros(64, np.uint8)])).to("cuda:0")
+    d_tab = torch.from_numpy(table.view(np.int32)).to("cuda:0")
+    b.entropy_stream(0, d_tab.data_ptr(), d_sym.data_ptr(), nsym)
+    b.finish()
+    enc = b.output(host.OUT_QUAL, 0)
+    assert len(enc) == len(want) and (enc == want).all(), f"{nsym} symbols: {len(enc)} vs {len(want)} bytes"
 
 
 @pytest.mark.gpu
