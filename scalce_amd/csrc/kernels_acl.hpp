@@ -19,17 +19,21 @@
 // registers: add B at the current bit offset, move on by t, store a word whenever 32 bits are complete; a carry beyond
 // the last complete word (it needs 32 ones in a row there) walks back through the stored words, rarely.
 //
-// Workgroup = three wavefronts over the same 64 blocks, rounds of 16 symbols per block:
+// Workgroup = four wavefronts (one per SIMD of a CU) over the same 64 blocks, rounds of 16 symbols per block:
 //   gather  lane b reads block b's symbols 16 at a time, forms the contexts and fetches the table rows
 //           {g(c_lo), g(c_hi)} (kernels_ac.hpp: reciprocal fractions) three rounds ahead, straight into LDS
 //           (global_load_lds_dwordx4: the row of lane b lands at ops[slot][step][b], no register in between)
-//   chain   16 x { ds_read_b128 operands, 13 VALU: A, B, D, nlo, renorm count, new (lo, M) ; ds_write_b64 (B, t) }
-//           rounds that are not plain for a lane -- the first (two raw symbols), a block's tail, a symbol that is the
+//   chain   16 x { ds_read_b128 operands, 14 VALU: A, B, D, nlo, renorm count, new (lo, M), Q += t ; ds_write_b64 (B, Q) }
+//           Q = 16 + bits dropped so far = where the top bit of the next B belongs in the block's bit stream.
+//           Rounds that are not plain for a lane -- the first (two raw symbols), a block's tail, a symbol that is the
 //           last of its context, a range that renormalises to the full 2^32 -- are redone for those lanes by the
 //           general step under the exec mask
-//   sink    lane b adds block b's (B, t) records of the previous round into its accumulator and stores finished words
+//   sink    lane b adds block b's (B, Q) records of the previous round into its accumulator; the word that may still
+//           take a carry goes to a staging ring in LDS in every step
+//   writer  moves the words that are final from the ring to the block's output, 16 bytes per lane and store
 // One LDS-only barrier per round.  Contexts depend on symbols only, never on coder state, which is why the gather
-// wave can run ahead.
+// wave can run ahead.  Measured costs behind this split: tools/ubench_lds.hip (a DS instruction costs a wave 17-35 cycles
+// whatever its width, a branch on a VALU result ~30, a VALU instruction 4), DESIGN.md section 5.
 // Only for tables whose largest context total is <= 2^29 (the host checks, as for the plain path of ac_encode_k):
 // every symbol then keeps an interval of at least two values, and the reference's coder never runs into the inverted
 // intervals whose bits are not those of X.
@@ -73,90 +77,83 @@ __device__ __forceinline__ void acl_step_plain(u32 &lo, u32 &M, const uint4 g, u
   lo = nlo << t;
 }
 
-// Bit sink of one block in one lane.  [w2 w1 w0] is a 96-bit window of X: w2 = the block's word at byte offset `wi4`
-// (complete, kept back because a carry may still reach it), the top bit of B sits `pos` bits below the top of w1.
+// Bit sink of one block in one lane.  [w2 w1 w0] is a 96-bit window of X: with Qb the stream position of the next B's
+// top bit, w1 is the block's word Qb >> 5, w2 the word in front of it -- complete, kept back because a carry may still
+// reach it -- and B's top bit sits Qb & 31 bits below the top of w1.
 //
 // What an instruction costs a lone wavefront here (tools/ubench_lds.hip): a VALU instruction 4 cycles; a DS instruction
 // 17 (read) to 25-35 (write) whatever its width; a scattered global store ~100 with all lanes, ~40 with four; and every
 // trip from a VALU result through an SGPR into a scalar instruction or a branch -- s_and_saveexec, s_cbranch_vccz -- ~16
 // on top.  As first written, with the natural ifs (carry? word complete? room?), a step was 55 instructions, seven
-// branches and a masked store: 330 cycles, and the chain wave waited for the sink 66 % of its time; without the ifs that
-// guard nothing, 200.  Hence the shape of step(): fifteen VALU instructions and ONE LDS store, no branch, no exec mask --
-//   * w2 goes to the lane's row of an LDS staging ring in every step, complete or not (a later step overwrites it); the
-//     complete words of all lanes leave once per round, 16 bytes per lane and store;
+// branches and a masked store: 330 cycles, and the chain wave waited for the sink 66 % of its time.  Hence the shape of
+// step(): fourteen VALU instructions and ONE LDS store, no branch, no exec mask --
+//   * w2 goes to the staging ring in every step, complete or not (a later step overwrites it); the writer wave takes the
+//     final words of all lanes out, 16 bytes per lane and store;
 //   * a carry out of w2 (it needs w2 = 0xFFFFFFFF) is only COUNTED; a lane that counted one redoes its round from the
 //     saved state with careful(), which notes where the carry belongs;
 //   * the notes -- word indices, in a log that grows down from the end of the block's own output buffer -- are applied by
 //     finish(): additions commute.  (Resolved on the spot, a loop of loads and stores in the step sequence, the compiler
 //     put s_waitcnt vmcnt(0) in front of every store of the following steps.)
-constexpr int ACL_ROW_WORDS = 32;  // staging ring per lane: a round adds at most 16 words to at most 3 left over
+constexpr int ACL_RING = 64;  // staging ring, words per lane: the sink is at most three rounds (48 words) ahead of the writer
 struct AclSink {
   SCALCE_GLOBAL u32 *dst;
-  u32 *row;      // this lane's staging ring in LDS
+  u32 (*ring)[64];  // [slot][lane]: word k of the block lives in slot (k + 1) & 63 -- lane l always hits bank l
+  int lane;
   u32 wcap;      // words the block may write
   u32 w2, w1, w0;
-  u32 pos;       // 0..31
-  int wi4;       // byte offset of w2's word; -4 while w2 is the (empty) word in front of the block
-  int wo4;       // bytes that have left for global memory (multiple of 16)
+  u32 Qb;        // stream position of the next B's top bit
   u32 ncar;      // carries out of w2 counted by step() in this round
   u32 nlog;      // notes in the log
   bool over;
-  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 *r, u32 cap_words, u32 s0, u32 s1) {
-    dst = d; row = r; wcap = cap_words;
+  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 (*r)[64], int l, u32 cap_words, u32 s0, u32 s1) {
+    dst = d; ring = r; lane = l; wcap = cap_words;
     w2 = 0; w1 = (s0 << 24) | (s1 << 16); w0 = 0;  // the two raw symbols (arithmetic.cpp:110-120): 16 bits of X
-    pos = 16; wi4 = -4; wo4 = 0; ncar = 0; nlog = 0; over = false;
+    Qb = 16; ncar = 0; nlog = 0; over = false;      // (w2 = the empty word in front of the block: ring slot 0, never taken out)
+  }
+  __device__ __forceinline__ u32 final_words() const {  // the words in front of w2 are final
+    const u32 wq = Qb >> 5;
+    return wq ? wq - 1u : 0u;
   }
   // room for a round's words and notes?  (once per round: a lane that runs out of room stops and reports)
   __device__ __forceinline__ bool room() {
-    if (wi4 / 4 + 2 * ACL_STEPS + 2 + (int)nlog >= (int)wcap) over = true;
+    if ((Qb >> 5) + 2 * ACL_STEPS + 2 + nlog >= wcap) over = true;
     return !over;
   }
-  // the step: X += B at the window's bit offset, then t bits on
-  __device__ __forceinline__ void step(u32 B, u32 t) {
+  // the step: X += B at bit Qb, then on to Qa
+  __device__ __forceinline__ void step(u32 B, u32 Qa) {
+    const u32 pos = Qb & 31u;
     const u32 b_hi = B >> pos;
     const u32 b_lo = __builtin_amdgcn_alignbit(B, 0u, pos);  // low word of {B, 0} >> pos: B << (32 - pos), 0 for pos = 0
-    u32 c0, c1, c2;
+    u32 c0, c1, c2, c3;
     w0 = __builtin_addc(w0, b_lo, 0u, &c0);
     w1 = __builtin_addc(w1, b_hi, c0, &c1);
     w2 = __builtin_addc(w2, 0u, c1, &c2);
-    ncar += c2;
-    const u32 pos2 = pos + t;
-    row[((u32)wi4 >> 2) & (ACL_ROW_WORDS - 1)] = w2;  // final if this step completes the word, overwritten otherwise
-    const bool f = pos2 >= 32u;
-    wi4 += (int)((pos2 >> 5) << 2);
+    ncar = __builtin_addc(ncar, 0u, c2, &c3);
+    const u32 wq = Qb >> 5;
+    ring[wq & (ACL_RING - 1)][lane] = w2;  // final if this step completes w1, overwritten otherwise
+    const bool f = (Qa >> 5) != wq;
     w2 = f ? w1 : w2;
     w1 = f ? w0 : w1;
     w0 = f ? 0u : w0;
-    pos = pos2 & 31u;
+    Qb = Qa;
   }
-  // the same step for the rare cases: the word in front of the block is not stored, a carry out of w2 is noted
-  __device__ __forceinline__ void careful(u32 B, u32 t) {
+  // the same step for a round in which step() counted a carry out of w2: it belongs to the word in front of w2
+  __device__ __forceinline__ void careful(u32 B, u32 Qa) {
+    const u32 pos = Qb & 31u;
     const u32 b_hi = B >> pos;
     const u32 b_lo = __builtin_amdgcn_alignbit(B, 0u, pos);
     u32 c0, c1, c2;
     w0 = __builtin_addc(w0, b_lo, 0u, &c0);
     w1 = __builtin_addc(w1, b_hi, c0, &c1);
     w2 = __builtin_addc(w2, 0u, c1, &c2);
+    const u32 wq = Qb >> 5;
     if (c2 != 0u) {
-      dst[wcap - 1u - nlog] = (u32)(wi4 / 4 - 1);
+      dst[wcap - 1u - nlog] = wq - 2u;  // (wq >= 2: a carry out of w2 needs 32 ones there, the empty word in front of the block has none)
       nlog++;
     }
-    const u32 pos2 = pos + t;
-    if (wi4 >= 0) row[((u32)wi4 >> 2) & (ACL_ROW_WORDS - 1)] = w2;
-    if (pos2 >= 32u) { wi4 += 4; w2 = w1; w1 = w0; w0 = 0u; }
-    pos = pos2 & 31u;
-  }
-  // complete words out of the staging ring, 16 bytes per lane at a time (words [wo4, wi4) are final)
-  __device__ __forceinline__ void drain() {
-    while (__any(wi4 - wo4 >= 16)) {
-      if (wi4 - wo4 >= 16) {
-        const u32x4 v = *(const u32x4 *)(row + (((u32)wo4 >> 2) & (ACL_ROW_WORDS - 1)));
-        u32x4 o;
-        o.x = __builtin_bswap32(v.x); o.y = __builtin_bswap32(v.y); o.z = __builtin_bswap32(v.z); o.w = __builtin_bswap32(v.w);
-        *(SCALCE_GLOBAL u32x4 *)(dst + ((u32)wo4 >> 2)) = o;
-        wo4 += 16;
-      }
-    }
+    ring[wq & (ACL_RING - 1)][lane] = w2;
+    if ((Qa >> 5) != wq) { w2 = w1; w1 = w0; w0 = 0u; }
+    Qb = Qa;
   }
   static __device__ __forceinline__ void carry_back(SCALCE_GLOBAL u32 *dst, u32 wcap, int k) {
     for (; k >= 0; k--) {
@@ -167,14 +164,10 @@ struct AclSink {
     }
   }
   // flush (arithmetic.cpp:160-169) in terms of X: cut behind the bit after B's top position, set that bit, add bit 30 of
-  // the final lo there.  Returns the block's size in bytes.
+  // the final lo there.  The words below w2 are in global memory by now (writer wave).  Returns the block's size in bytes.
   __device__ __forceinline__ u32 finish(u32 final_lo) {
-    for (; wo4 < wi4; wo4 += 4) {  // what the ring still holds
-      const u32 k = (u32)wo4 >> 2;
-      if (k < wcap) dst[k] = __builtin_bswap32(row[k & (ACL_ROW_WORDS - 1)]);
-      else over = true;
-    }
-    const int wi = wi4 / 4;  // -1 .. (wi4 = -4 only for blocks of a few symbols)
+    const u32 pos = Qb & 31u;
+    const int wi = (int)(Qb >> 5) - 1;  // index of w2's word, -1 for a block of a few symbols
     const u64 ulp = 1ull << (62u - pos);
     u64 v = ((u64)w1 << 32) | w0;
     v = (v & ~(ulp - 1)) | ulp;
@@ -185,7 +178,7 @@ struct AclSink {
         if (w2 == 0u && !over) { dst[wcap - 1u - nlog] = (u32)(wi - 1); nlog++; }
       }
     }
-    const u32 bits = 32u * (u32)(wi + 1) + pos + 2u;
+    const u32 bits = Qb + 2u;
     const u32 words[3] = {w2, (u32)(v >> 32), (u32)v};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -209,8 +202,9 @@ struct AclSink {
 constexpr int ACL_SLOTS = 4;   // operand ring: the gather wave runs up to three rounds ahead of the chain
 struct AclShared {
   uint4 ops[ACL_SLOTS][ACL_STEPS][64];  // gather -> chain: operands of a round (slot = round % ACL_SLOTS), written by LDS-direct loads
-  uint2 rec[2][ACL_STEPS][64];          // chain -> sink: (B, t) of a round
-  u32 stage[64][ACL_ROW_WORDS];         // sink: coded words on their way out
+  uint2 rec[2][ACL_STEPS][64];          // chain -> sink: (B, Q) of a round
+  u32 stage[ACL_RING][64];              // sink -> writer: coded words on their way out
+  u32 pub[2][64];                       // sink -> writer: words below this index are final
   u32 final_lo[64];
 };
 
@@ -233,10 +227,10 @@ __device__ __forceinline__ void acl_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
+__global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
   __shared__ AclShared sh;
   const int lane = lane_id();
-  const int role = wave_id();  // 0 chain, 1 gather, 2 sink: three SIMDs of the CU
+  const int role = wave_id();  // 0 chain, 1 gather, 2 sink, 3 writer: the four SIMDs of the CU
   const u32 blk = blockIdx.x * 64u + (u32)lane;
   const bool have = blk < a.nblocks;
   const SCALCE_GLOBAL AcBlockDesc *dp = (const SCALCE_GLOBAL AcBlockDesc *)a.desc + (have ? blk : 0u);
@@ -310,6 +304,8 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
       if (i + 3 < nr_wg) iteration(i + 3, s2);
     }
     acl_wait_vm<0>();  // nothing of this wave may land in LDS after the workgroup has gone
+    asm volatile("s_barrier" ::: "memory");  // (the sink's last round)
+    asm volatile("s_barrier" ::: "memory");  // (the writer's last words)
     if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 3] = gprof_wait;
   } else if (role == 0) {
     // ================= chain: 64 coder states =================
@@ -318,12 +314,13 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
     asm("v_mov_b32 %0, -1" : "=v"(ones));
     asm("v_mov_b32 %0, 0" : "=v"(zero));
     u32 lo = 0, M = 0;  // M = 0 stands for 2^32
+    u32 Q = 16;         // stream position of the next B's top bit: the two raw symbols, then every bit dropped
     u64 prof_wait = 0;
     const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads();  // round 0's operands are in LDS
     for (u32 r = 0; r < nr_wg; r++) {
       const int slot = r % ACL_SLOTS;
-      const u32 lo0 = lo, M0 = M;
+      const u32 lo0 = lo, M0 = M, Q0 = Q;
       // all 16 operand reads are issued before the first step (read at the point of use, every step waited for a full
       // LDS round trip)
       uint4 g[ACL_STEPS];
@@ -334,7 +331,8 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
       for (int j = 0; j < ACL_STEPS; j++) {
         u32 B, t;
         acl_step_plain(lo, M, g[j], ones, zero, B, t);
-        sh.rec[r & 1][j][lane] = make_uint2(B, t);
+        Q += t;
+        sh.rec[r & 1][j][lane] = make_uint2(B, Q);
         topw = g[j].w > topw ? g[j].w : topw;
       }
       const bool live = r < nr;
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
                                           // block has ended computes garbage nobody reads: the sink skips it)
       if (__builtin_expect(__any(fix), 0)) {
         if (fix) {
-          u32 glo = lo0 & 0x7FFFFFFFu, ghi = glo + M0 - 1u;
+          u32 glo = lo0 & 0x7FFFFFFFu, ghi = glo + M0 - 1u, gq = Q0;
           const u32 jstart = r == 0 ? 2u : 0u;
           const u32 left = n - r * ACL_STEPS;
           const u32 jend = left < (u32)ACL_STEPS ? left : (u32)ACL_STEPS;
@@ -354,10 +352,12 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
             const uint4 gj = sh.ops[slot][j][lane];
             u32 B = 0, t = 0;
             if (j >= jstart && j < jend) acl_step_general(glo, ghi, gj, B, t);
-            sh.rec[r & 1][j][lane] = make_uint2(B, t);
+            gq += t;
+            sh.rec[r & 1][j][lane] = make_uint2(B, gq);
           }
           lo = glo;
           M = ghi - glo + 1u;
+          Q = gq;
         }
       }
       if (r + 1 == nr) sh.final_lo[lane] = lo & 0x7FFFFFFFu;
@@ -369,18 +369,22 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
         __syncthreads();
       }
     }
+    __syncthreads();  // (the sink's last round)
+    __syncthreads();  // (the writer's last words)
     if (a.prof && lane == 0) {
       a.prof[blockIdx.x * 5 + 0] = prof_wait;
       a.prof[blockIdx.x * 5 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
     }
-  } else {
+  } else if (role == 2) {
     // ================= sink: 64 bit accumulators, one round behind the chain =================
     AclSink sk;
     {
       const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
       const u32 s0 = n ? (u32)sp[0] : 0u, s1 = n > 1 ? (u32)sp[1] : 0u;
-      sk.init((SCALCE_GLOBAL u32 *)dp->dst, &sh.stage[lane][0], a.out_cap / 4, s0, s1);
+      sk.init((SCALCE_GLOBAL u32 *)dp->dst, sh.stage, lane, a.out_cap / 4, s0, s1);
     }
+    sh.pub[0][lane] = 0;
+    sh.pub[1][lane] = 0;
     barrier_lds_only();
     u64 sprof_wait = 0;
     auto take = [&](u32 r) {  // the records of round r
@@ -388,28 +392,22 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
         uint2 v[ACL_STEPS];
 #pragma unroll
         for (int j = 0; j < ACL_STEPS; j++) v[j] = sh.rec[r & 1][j][lane];
-        if (r == 0) {  // the first word of the block is on its way: the careful step knows about the empty word in front of it
-#pragma unroll 1
-          for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[0][j][lane].x, sh.rec[0][j][lane].y);
-        } else {
-          const u32 s2 = sk.w2, s1 = sk.w1, s0 = sk.w0, spos = sk.pos;
-          const int swi4 = sk.wi4;
-          sk.ncar = 0;
+        const u32 s2 = sk.w2, s1 = sk.w1, s0 = sk.w0, sq = sk.Qb;
+        sk.ncar = 0;
 #pragma unroll
-          for (int j = 0; j < ACL_STEPS; j++) sk.step(v[j].x, v[j].y);
-          if (__builtin_expect(__any(sk.ncar != 0u), 0)) {
-            if (sk.ncar != 0u) {
-              sk.w2 = s2; sk.w1 = s1; sk.w0 = s0; sk.pos = spos; sk.wi4 = swi4;
+        for (int j = 0; j < ACL_STEPS; j++) sk.step(v[j].x, v[j].y);
+        if (__builtin_expect(__any(sk.ncar != 0u), 0)) {
+          if (sk.ncar != 0u) {
+            sk.w2 = s2; sk.w1 = s1; sk.w0 = s0; sk.Qb = sq;
 #pragma unroll 1
-              for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[r & 1][j][lane].x, sh.rec[r & 1][j][lane].y);
-            }
+            for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[r & 1][j][lane].x, sh.rec[r & 1][j][lane].y);
           }
         }
       }
-      sk.drain();
     };
-    for (u32 r = 0; r < nr_wg; r++) {
-      if (r > 0) take(r - 1);
+    for (u32 i = 0; i < nr_wg; i++) {  // iteration i: round i - 1
+      if (i > 0) take(i - 1);
+      sh.pub[i & 1][lane] = sk.final_words();
       if (a.prof) {
         const u64 w0 = __builtin_amdgcn_s_memtime();
         barrier_lds_only();
@@ -420,11 +418,44 @@ __global__ __launch_bounds__(192) void ac_encode_lanes_k(AcEncArgs a) {
     }
     if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 4] = sprof_wait;
     take(nr_wg - 1);
+    sh.pub[nr_wg & 1][lane] = sk.final_words();
+    barrier_lds_only();   // the writer takes out every final word ...
+    barrier_lds_only();   // ... and they are in memory (its fence): the notes go on top
     if (have && n) {
       const u32 bytes = sk.finish(sh.final_lo[lane]);
       *(SCALCE_GLOBAL u32 *)dp->out_size = bytes;
       if (sk.over) dev_fail(dp->err, E_ACOVERFLOW, dp->index, bytes);
     }
+  } else {
+    // ================= writer: final words out of the staging ring =================
+    SCALCE_GLOBAL u32 *dst = (SCALCE_GLOBAL u32 *)dp->dst;
+    const u32 wcap = a.out_cap / 4;
+    u32 wo = 0;  // words of this lane's block in global memory (multiple of 4 until the end)
+    auto word = [&](u32 k) -> u32 { return __builtin_bswap32(sh.stage[(k + 1u) & (ACL_RING - 1)][lane]); };
+    auto drain = [&](u32 lim) {  // 16 bytes per lane and store while any lane has them
+      while (__any(lim - wo >= 4u && lim > wo)) {
+        if (lim - wo >= 4u && lim > wo) {
+          u32x4 o;
+          o.x = word(wo); o.y = word(wo + 1); o.z = word(wo + 2); o.w = word(wo + 3);
+          if (wo + 4u <= wcap) *(SCALCE_GLOBAL u32x4 *)(dst + wo) = o;
+          wo += 4;
+        }
+      }
+    };
+    barrier_lds_only();
+    for (u32 i = 0; i < nr_wg; i++) {  // iteration i: what the sink published in iteration i - 1
+      if (i > 0) drain(sh.pub[(i - 1) & 1][lane]);
+      barrier_lds_only();
+    }
+    barrier_lds_only();  // the sink's last round is in the ring
+    {
+      const u32 lim = sh.pub[nr_wg & 1][lane];
+      drain(lim);
+      for (; wo < lim; wo++)
+        if (wo < wcap) dst[wo] = word(wo);
+      __threadfence();
+    }
+    barrier_lds_only();
   }
 }
 

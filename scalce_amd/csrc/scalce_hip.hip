@@ -1534,7 +1534,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     const u32 nwg = cdiv(total, (u32)blocks_per_wg);
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * nwg)); }
     if (blocks_per_wg == 64) {
-      LAUNCH(ac_encode_lanes_k, cdiv(total, 64), 192, 0, s, a);
+      LAUNCH(ac_encode_lanes_k, cdiv(total, 64), 256, 0, s, a);
     } else if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
@@ -1594,8 +1594,8 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
             "the first helper wave %.1f %%\n",
             b->prof_n, 100.0 * wait / tot, wait / b->prof_n / 1e6, tot / b->prof_n / 1e6, 100.0 * hwait / (htot > 0 ? htot : 1));
     if (b->prof_lanes) {
-      fprintf(stderr, "ac prof (lanes): SIMD of chain / gather / sink per workgroup:");
-      for (u32 i = 0; i < b->prof_n && i < 24; i++) fprintf(stderr, " %llu%llu%llu", h[5 * i + 2] & 15, (h[5 * i + 2] >> 4) & 15, (h[5 * i + 2] >> 8) & 15);
+      fprintf(stderr, "ac prof (lanes): SIMD of chain / gather / sink / writer per workgroup:");
+      for (u32 i = 0; i < b->prof_n && i < 24; i++) fprintf(stderr, " %llu%llu%llu%llu", h[5 * i + 2] & 15, (h[5 * i + 2] >> 4) & 15, (h[5 * i + 2] >> 8) & 15, (h[5 * i + 2] >> 12) & 15);
       fprintf(stderr, "\n");
     }
     if (b->prof_lanes)
