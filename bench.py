@@ -144,7 +144,8 @@ def main():
 
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
-    pipe = ShardPipeline(batches, group=G, sharded=sharded, trace=mark if trace else None)
+    pipe = ShardPipeline(batches, group=G, sharded=sharded, trace=mark if trace else None,
+                         coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "1")))
     front = pipe.front
 
     def run(k):

@@ -40,7 +40,10 @@ __device__ __forceinline__ u64 recip_frac(u32 c, u32 d) {
   const u64 ql = (rem << 32) / d;
   return ((qh << 32) | ql) + 1;
 }
-__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/, u32 *max_total) {
+// `tab8` (may be null): the same fractions as one u64 per cumulative bound, [6400][81] -- g(c_hi) of a symbol is g(c_lo) of
+// the next, so the 16 bytes at &tab8[ctx * 81 + s] ARE symbol s's operands and the table is half the size (4.1 MB): the
+// one-block-per-lane coder gathers from it (kernels_acl.hpp; an XCD's 4 MB L2 holds the rows in use of one table, not of two).
+__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/, u32 *max_total, u64 *tab8 = nullptr) {
   const u32 ctx = blockIdx.x * blockDim.x + threadIdx.x;
   if (ctx >= AC_D * AC_D) return;
   const u32 *f = table + (u64)ctx * AC_D;
@@ -50,11 +53,13 @@ __global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u
   u32 run = 0;
   u64 glo = 1;  // c == 0 -> quotient 0
   cum[ctx * 81] = 0;
+  if (tab8) tab8[(u64)ctx * 81] = glo;
   for (int s = 0; s < AC_D; s++) {
     run += f[s];
     cum[ctx * 81 + s + 1] = run;
     const u64 ghi = (run == tot) ? ~0ull : recip_frac(run, tot);
     tab[(u64)ctx * AC_D + s] = make_uint4((u32)glo, (u32)(glo >> 32), (u32)ghi, (u32)(ghi >> 32));
+    if (tab8) tab8[(u64)ctx * 81 + s + 1] = ghi;
     glo = ghi;
   }
 }

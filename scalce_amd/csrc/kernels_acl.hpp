@@ -199,7 +199,7 @@ struct AclSink {
   }
 };
 
-constexpr int ACL_SLOTS = 4;   // operand ring: the gather wave runs up to three rounds ahead of the chain
+constexpr int ACL_SLOTS = 5;   // operand ring: the gather wave runs four rounds ahead of the chain
 struct AclShared {
   uint4 ops[ACL_SLOTS][ACL_STEPS][64];  // gather -> chain: operands of a round (slot = round % ACL_SLOTS), written by LDS-direct loads
   uint2 rec[2][ACL_STEPS][64];          // chain -> sink: (B, Q) of a round
@@ -227,11 +227,19 @@ __device__ __forceinline__ void acl_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <bool EXCLUSIVE>
 __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
   __shared__ AclShared sh;
   const int lane = lane_id();
   const int role = wave_id();  // 0 chain, 1 gather, 2 sink, 3 writer: the four SIMDs of the CU
-  const u32 blk = blockIdx.x * 64u + (u32)lane;
+  // Workgroups are dealt to the 8 XCDs in turn (b and b + 8 share one: MI355X_MICROARCH.md, Workgroup dispatch), and
+  // every XCD has an L2 of its own.  A launch holds the blocks of several streams back to back, each stream with its own
+  // 4 MB table: the workgroups of an XCD take CONSECUTIVE groups of 64 blocks, so that an L2 serves one or two tables
+  // instead of all of them (with three tables per L2 the gather wave, not the chain, set the pace of a launch).  Speed
+  // only: any placement gives the same bytes.
+  const u32 nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7u, xcd = blockIdx.x & 7u;
+  const u32 wg = (xcd < xr ? xcd * (xq + 1u) : xr * (xq + 1u) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const u32 blk = wg * 64u + (u32)lane;
   const bool have = blk < a.nblocks;
   const SCALCE_GLOBAL AcBlockDesc *dp = (const SCALCE_GLOBAL AcBlockDesc *)a.desc + (have ? blk : 0u);
   const u32 n = have ? dp->n : 0u;
@@ -241,12 +249,19 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
   for (int d = 32; d; d >>= 1) { const u32 o = __shfl_xor(nr_wg, d, 64); nr_wg = o > nr_wg ? o : nr_wg; }
   nr_wg = __builtin_amdgcn_readfirstlane(nr_wg);
   if (!nr_wg) return;
+  // Front stages of other shards run beside this kernel.  Their waves on a coder wave's SIMD take issue slots from it
+  // (every one of the four waves is on the round's critical path, the one-instruction-per-four-cycles kind), and their
+  // memory traffic queues in front of the gather wave's table rows in the CU's own memory pipeline.  EXCLUSIVE makes each
+  // coder wave claim its SIMD's whole register file (256 VGPRs + 256 AGPRs: an empty asm statement that names the last
+  // of each), so that the dispatcher places nothing else on the CU; otherwise all four only run at raised priority.
+  if (EXCLUSIVE) asm volatile("" ::: "v255", "a255");
+  __builtin_amdgcn_s_setprio(3);
   if (a.prof && lane == 0) atomicOr((unsigned int *)&a.prof[blockIdx.x * 5 + 2], (simd_key() & 3u) << (4 * role));  // profiling: which SIMD each role runs on
 
   if (role == 1) {
     // ================= gather: table rows straight into LDS, three rounds ahead =================
     const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
-    const SCALCE_GLOBAL u32x4 *tab = (const SCALCE_GLOBAL u32x4 *)dp->tab;
+    const SCALCE_GLOBAL u64 *tab = (const SCALCE_GLOBAL u64 *)dp->tab;  // compact: [6400][81] bounds (ac_table_k)
     // 16 symbols of round k.  The block's symbols are 16-byte aligned (blocks start at multiples of 10 MiB of a 16-byte
     // aligned stream); a read that starts inside the block may run up to 15 bytes past its end (the stream buffers are
     // padded), one that would start past it falls back to the block's first symbols -- garbage nobody uses either way.
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
       return sp + off;
     };
     u32 p0 = 0, p1 = 0;  // the two symbols in front of the next round to be addressed
-    // 16 LDS-direct loads: row (p0, p1, c) of the lane's table -> ops[k % ACL_SLOTS][j][lane]
+    // 16 LDS-direct loads: bounds c and c + 1 of context (p0, p1) in the lane's table -> ops[k % ACL_SLOTS][j][lane]
     auto request = [&](const u32x4 sy, u32 k) {
       uint4 *slot = &sh.ops[k % ACL_SLOTS][0][0];
 #pragma unroll
@@ -264,14 +279,15 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
         u32 c = (word >> (8 * (j & 3))) & 0xFFu;
         const u32 D1 = AC_D - 1;
         c = c < D1 ? c : D1;  // symbols >= AC_D raised E_SYMBOL at ingest; stay inside the table regardless
-        const u32 idx = (p0 * AC_D + p1) * AC_D + c;
+        const u32 idx = (p0 * AC_D + p1) * (AC_D + 1) + c;
         __builtin_amdgcn_global_load_lds((const SCALCE_GLOBAL void *)(tab + idx), (__attribute__((address_space(3))) void *)(slot + j * 64), 16, 0, 0);
         p0 = p1;
         p1 = c;
       }
     };
-    // VMEM in issue order: prologue [S0 S1 S2 S3] wait [R0 S4] [R1 S5] [R2 S6], then per iteration i [R(i+3) S(i+7)];
-    // R = 16 instructions.  Symbols S(k) sit in set k % 4.
+    // VMEM in issue order: prologue [S0 S1 S2 S3] wait [R0 S4] [R1 S5] [R2 S6] [R3 S7], then per iteration i
+    // [R(i+4) S(i+8)]; R = 16 instructions.  Symbols S(k) sit in set k % 4.  The hardware counts at most 63 outstanding
+    // vector memory instructions per wave: three rounds in flight behind the one awaited is as deep as it goes.
     u32x4 s0 = acl_load16(sym_addr(0)), s1 = acl_load16(sym_addr(1)), s2 = acl_load16(sym_addr(2)), s3 = acl_load16(sym_addr(3));
     acl_wait_vm<3>(s0);
     request(s0, 0); s0 = acl_load16(sym_addr(4));
@@ -279,16 +295,18 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
     request(s1, 1); s1 = acl_load16(sym_addr(5));
     acl_wait_vm<1 + 2 * 17>(s2);
     request(s2, 2); s2 = acl_load16(sym_addr(6));
-    acl_wait_vm<2 * 17>();  // round 0 is in LDS
+    acl_wait_vm<3 * 17>(s3);
+    request(s3, 3); s3 = acl_load16(sym_addr(7));
+    acl_wait_vm<3 * 17>();  // round 0 is in LDS
     asm volatile("s_barrier" ::: "memory");
     u64 gprof_wait = 0;
-    // iteration i: symbols of round i + 3 are here when at most the three iterations behind them are outstanding; round
-    // i + 1 is in LDS when at most iterations i - 1 and i are
+    // iteration i: symbols of round i + 4 are here when at most the three iterations behind them are outstanding; round
+    // i + 1 is in LDS when at most the three requests behind it are
     auto iteration = [&](u32 i, u32x4 &sset) {
       acl_wait_vm<3 * 17>(sset);
-      request(sset, i + 3);
-      sset = acl_load16(sym_addr(i + 7));
-      acl_wait_vm<2 * 17>();
+      request(sset, i + 4);
+      sset = acl_load16(sym_addr(i + 8));
+      acl_wait_vm<3 * 17>();
       if (a.prof) {
         const u64 w0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_barrier" ::: "memory");
@@ -298,10 +316,10 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
       }
     };
     for (u32 i = 0; i < nr_wg; i += 4) {
-      iteration(i, s3);
-      if (i + 1 < nr_wg) iteration(i + 1, s0);
-      if (i + 2 < nr_wg) iteration(i + 2, s1);
-      if (i + 3 < nr_wg) iteration(i + 3, s2);
+      iteration(i, s0);
+      if (i + 1 < nr_wg) iteration(i + 1, s1);
+      if (i + 2 < nr_wg) iteration(i + 2, s2);
+      if (i + 3 < nr_wg) iteration(i + 3, s3);
     }
     acl_wait_vm<0>();  // nothing of this wave may land in LDS after the workgroup has gone
     asm volatile("s_barrier" ::: "memory");  // (the sink's last round)
@@ -309,7 +327,6 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
     if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 3] = gprof_wait;
   } else if (role == 0) {
     // ================= chain: 64 coder states =================
-    __builtin_amdgcn_s_setprio(3);
     u32 ones, zero;
     asm("v_mov_b32 %0, -1" : "=v"(ones));
     asm("v_mov_b32 %0, 0" : "=v"(zero));

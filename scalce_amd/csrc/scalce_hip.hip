@@ -309,7 +309,7 @@ struct scalce_batch {
   DBuf &perm_a, &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b, &run_pos;
   DBuf &name_off;
   u32 order_run_members = 0;
-  DBuf out_reads[2], out_names, ac_tab[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
+  DBuf out_reads[2], out_names, ac_tab[2], ac_tab8[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
   AcBlockDesc *ac_desc_host = nullptr;  // block descriptors of the last coder launch this shard led: pinned, so that the
   u32 ac_desc_cap = 0;                  // asynchronous upload never reads memory the next launch is already rewriting
   u32 *perm = nullptr;  // final permutation (points into perm_a or perm_b)
@@ -389,7 +389,7 @@ static void free_all(scalce_batch *b) {
   DBuf *all[] = {&b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->counts_total, &b->bucket_name_bytes,
                  &b->ac_scan, &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->ac_tab[0], &b->ac_cum[0], &b->ac_blocks[0],
                  &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1], &b->ac_sizes[1], &b->ac_off[1],
-                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1]};
+                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1], &b->ac_tab8[0], &b->ac_tab8[1]};
   for (DBuf *d : all)
     if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
   if (b->owns_ws) { b->ws->free_all(); delete b->ws; }
@@ -1413,7 +1413,8 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true) {
   ENSURE(b, b->ac_tab[m], sizeof(uint4) * 512000);
   ENSURE(b, b->ac_cum[m], sizeof(u32) * 6400 * 81);
   HIP_TRY(c, hipMemsetAsync(b->d_small + 12 + m, 0, sizeof(u32), s));
-  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab[m].as<uint4>(), b->ac_cum[m].as<u32>(), b->d_small + 12 + m);
+  ENSURE(b, b->ac_tab8[m], sizeof(u64) * (6400 * 81 + 2));
+  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab[m].as<uint4>(), b->ac_cum[m].as<u32>(), b->d_small + 12 + m, b->ac_tab8[m].as<u64>());
   u32 max_total = 0;
   { int rc = read_u32(b, b->d_small + 12 + m, &max_total, 1, s); if (rc) return rc; }
   // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
@@ -1504,6 +1505,9 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
       HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&lead->ac_desc_host), sizeof(AcBlockDesc) * (size_t)(total + total / 2), hipHostMallocDefault));
       lead->ac_desc_cap = total + total / 2;
     }
+    // one block per lane only follows the reference while no interval can invert (kernels_acl.hpp)
+    if (blocks_per_wg == 64 && general) blocks_per_wg = 8;
+    const bool lanes = blocks_per_wg == 64;  // gathers from the compact table
     AcBlockDesc *d = lead->ac_desc_host;
     u32 nd = 0;
     for (int i = 0; i < njobs; i++) {
@@ -1513,7 +1517,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
         AcBlockDesc x;
         const u64 off = (u64)k * AC_BLOCK_SYMS;
         x.sym = jobs[i].sym + off;
-        x.tab = b->ac_tab[m].as<uint4>();
+        x.tab = lanes ? reinterpret_cast<const uint4 *>(b->ac_tab8[m].as<u64>()) : b->ac_tab[m].as<uint4>();
         x.dst = reinterpret_cast<u32 *>(b->ac_blocks[m].as<u8>() + (u64)k * AC_STRIDE);
         x.out_size = b->ac_sizes[m].as<u32>() + k;
         x.err = b->d_err;
@@ -1529,12 +1533,11 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
-    // one block per lane only follows the reference while no interval can invert (kernels_acl.hpp)
-    if (blocks_per_wg == 64 && general) blocks_per_wg = 8;
     const u32 nwg = cdiv(total, (u32)blocks_per_wg);
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * nwg)); }
     if (blocks_per_wg == 64) {
-      LAUNCH(ac_encode_lanes_k, cdiv(total, 64), 256, 0, s, a);
+      if (getenv("SCALCE_AC_LANES_SHARED")) LAUNCH(ac_encode_lanes_k<false>, cdiv(total, 64), 256, 0, s, a);
+      else LAUNCH(ac_encode_lanes_k<true>, cdiv(total, 64), 256, 0, s, a);
     } else if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
@@ -1702,7 +1705,8 @@ extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_tab
   if (!b->p.no_ac) {
     u64 blocks = 0;
     for (int m = 0; m < b->nm; m++) blocks += cdiv(N * (u64)b->L[m], AC_BLOCK_SYMS);
-    if (blocks > AC_WINDOW_BLOCKS || getenv("SCALCE_AC_WINDOWED")) return entropy_windowed(b, d_table_override, s);
+    const u64 one_launch = getenv("SCALCE_AC_ONE_LAUNCH_BLOCKS") ? strtoull(getenv("SCALCE_AC_ONE_LAUNCH_BLOCKS"), nullptr, 10) : AC_WINDOW_BLOCKS;
+    if (blocks > one_launch || getenv("SCALCE_AC_WINDOWED")) return entropy_windowed(b, d_table_override, s);
   }
   if (b->nm == 2 && !b->p.no_ac && ac_blocks_per_wg() == 1) {
     // paired reads: both mates' streams in ONE launch (several blocks per chain wave) instead of two launches of the
@@ -1770,6 +1774,7 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
   for (auto &j : jobs) total += j.nblk;
   int bpw = total <= 4 * 256 ? 4 : 8;
   if (ac_blocks_per_wg() != 1) bpw = ac_blocks_per_wg();
+
   int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);
   if (rc) return rc;
   // The framing ([u32 size][bytes] per block: scan of the sizes + one copy kernel, ~5 ms per 50 M-read shard) is left to

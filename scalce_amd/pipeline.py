@@ -26,7 +26,7 @@ from . import host
 
 
 class ShardPipeline:
-    def __init__(self, batches, group=1, on_retire=None, sharded=False, trace=None):
+    def __init__(self, batches, group=1, on_retire=None, sharded=False, trace=None, coder_streams=1):
         import torch
         self.torch = torch
         self.batches = list(batches)
@@ -35,7 +35,11 @@ class ShardPipeline:
         if self.G > 1 and self.D < 2 * self.G:
             raise ValueError("a grouped pipeline needs at least 2 * group batches")
         self.front = torch.cuda.Stream()
-        self.coder = torch.cuda.Stream()
+        # coder launches rotate over `coder_streams` streams: the one-block-per-lane coder (ac_encode_lanes_k) takes a
+        # fraction of a CU per 64 blocks for ~0.5 s whatever the size of the launch, so several launches run side by side
+        self.coders = [torch.cuda.Stream() for _ in range(max(1, int(coder_streams)))]
+        self.coder = self.coders[0]
+        self._launches = 0
         self.on_retire = on_retire
         self.sharded = sharded          # shards arrive prepared (scalce_sharded_compress with SCALCE_SHARD_PREPARE_ONLY / _CODER_ASYNC)
         self.trace = trace
@@ -87,9 +91,11 @@ class ShardPipeline:
     def flush(self):
         if not self._pending:
             return
-        host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, self.coder.cuda_stream)
+        coder = self.coders[self._launches % len(self.coders)]
+        self._launches += 1
+        host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, coder.cuda_stream)
         ev = self.torch.cuda.Event()
-        ev.record(self.coder)
+        ev.record(coder)
         for sl in self._pending:
             self._busy[sl] = ev
         self._pending = []
