@@ -9,9 +9,14 @@ scalce_sharded_compress, the C++ host of scalce_amd/csrc/sharded.cpp over RCCL (
 tie-break, quality model and 10 MiB block cutting, byte-identical with the one-GPU archive of the same input.
 torch.distributed is only used to hand RCCL's unique id to the ranks and for the timing barrier.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (ac_encode_k): algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
-  cpu_baseline -- the reference's own hot-path objects (oracle/_ref, else the C port), one thread, on a bounded sample
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline       -- SURVEY 8(d): algorithmic bytes of a step (308 B per read) / ms_per_step against the 8 TB/s HBM peak;
+                    beside it the dominant kernel's own views (HBM bytes and issue slots per launch, HIP events)
+  cpu_baseline   -- the reference's own compress() (oracle/_ref/ref_full: every reference source but main.cpp, built in
+                    the dev container, the binary travels) at -T 1 and at its default thread count, on a bounded sample
+  parity_checked -- the run proves its own output: the LAST timed shard is decoded on the device back to FASTQ text whose
+                    record multiset equals the input's, and the sample of the CPU leg gives byte-identical archives
+                    through the `scalce` binary and through the reference
 """
 import argparse
 import json
@@ -43,6 +48,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_500_000, help="records of the CPU baseline sample (0 = skip)")
     ap.add_argument("--stage-times", action="store_true", help="also print per-stage HIP-event times to stderr")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> archive leg (the `scalce` binary on the same shard written to a file)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the last timed shard (device decode + record digest)")
     args = ap.parse_args()
 
     import numpy as np
@@ -199,10 +205,28 @@ def main():
         print("stage ms:", {s: round(v[0], 2) for s, v in batch.stage_ms().items()}, stats, file=sys.stderr)
         batch.stage_reset(False)
 
+    # ---- the run proves its own output (never inside the timed region) ----
+    parity = {}
+    if rank == 0 and not sharded and not args.no_verify:
+        try:
+            from scalce_amd import verify
+            last = batches[(pipe._next - 1) % D]            # the batch that holds the last timed shard
+            tv0 = time.perf_counter()
+            want = verify.record_digest(text)
+            back = verify.decode_shard(ctx, last, L, off, dev)
+            got = verify.record_digest(back)
+            parity["full_shard"] = {"ok": bool(got == want and want[0] == n), "records": got[0],
+                                    "what": "last timed shard: archive streams -> scalce_ac_decode + scalce_fastq_records on the "
+                                            "device -> FASTQ text; (count, two 64-bit sums of per-record hashes) equal to the input's",
+                                    "seconds": round(time.perf_counter() - tv0, 2)}
+            del back
+        except Exception as ex:  # noqa: BLE001
+            parity["full_shard"] = {"ok": False, "error": repr(ex)[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         try:
-            cpu = cpu_baseline(text, n, L, args.cpu_sample)
+            cpu, parity["sample"] = cpu_baseline(text, n, L, args.cpu_sample)
         except Exception as ex:  # noqa: BLE001
             cpu = {"error": repr(ex)[:300]}
     e2e = None
@@ -215,28 +239,49 @@ def main():
         except Exception as ex:  # noqa: BLE001 - a side leg must not take the measured line with it
             e2e = {"error": repr(ex)[:300]}
 
-    traffic, traffic_src = None, None
-    kname = "ac_encode_rows_k" if G > 1 else "ac_encode_k"
-    # HBM bytes of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, units of KB;
-    # FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM").  The counters come from a
-    # profile kept under profiles/ -- of this round's build when PROFILE_TAG names one, and the tag is printed with them.
-    tag = os.environ.get("SCALCE_PROFILE_TAG", "r02_final")
+    # Counter figures come from rocprofv3 summaries of THIS build kept under profiles/ (tools/profile_round.sh <tag>,
+    # tools/pmc_sq.sh <tag>; SCALCE_PROFILE_TAG names the tag): HBM bytes from --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes (KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM"), instructions
+    # from --pmc SQ_INSTS_*.  A figure whose file is missing is null, never a constant.
+    kname = {1: "ac_encode_k", 64: "ac_encode_lanes_k"}.get(1 if G == 1 else int(os.environ.get("SCALCE_AC_BLOCKS_PER_WG", "0") or 0), "ac_encode_rows_k")
+    tag = os.environ.get("SCALCE_PROFILE_TAG", "r03_final")
     pmc = os.path.join(ROOT, "profiles", f"{tag}_bench50m_pmc_fetch_write.json")
+    sqf = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")
+    k_traffic, step_traffic, traffic_src, instr_per_symbol, issue_src = None, None, None, None, None
     if rank == 0 and n == 50_000_000 and L == 100 and os.path.exists(pmc):
-        nblocks = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
-        want = (kname + ("<false, 8>" if nblocks > 1024 else "<false, 16>")) if G > 1 else kname + "<"
-        for row in json.load(open(pmc)):
-            if want in row["kernel"]:
-                launches = max(row["calls"], 1)
-                traffic = int((2 * row["FETCH_SIZE_KB"] + row["WRITE_SIZE_KB"]) * 1024 / launches)
-                traffic_src = os.path.relpath(pmc, ROOT)
+        rows = json.load(open(pmc))
+        shards = max((r.get("shards") or 0) for r in rows) or None
+        traffic_src = os.path.relpath(pmc, ROOT)
+        if shards:
+            step_traffic = int(sum((2 * r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"]) * 1024 for r in rows) / shards)
+        for r in rows:
+            if kname in r["kernel"] and (k_traffic is None or r["calls"] > 0):
+                k_traffic = int((2 * r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"]) * 1024 / max(r["calls"], 1))
+                break
+    if rank == 0 and os.path.exists(sqf):
+        for r in json.load(open(sqf)):
+            if kname in r["kernel"] and r.get("symbols"):
+                instr_per_symbol = (r["SQ_INSTS_VALU"] + r["SQ_INSTS_SALU"] + r["SQ_INSTS_LDS"]) / r["symbols"]
+                issue_src = os.path.relpath(sqf, ROOT)
+                break
     if rank == 0:
         total_in = nbytes * world
         ms_per_step = dt / args.steps * 1e3
         value = total_in * args.steps / dt / 1e6
-        per_launch_ms = k["total_ms"] / max(k["launches"], 1)
-        alg_bytes = (k["bytes_in"] + k["bytes_out"]) / max(k["launches"], 1)
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        launches = max(k["launches"], 1)
+        per_launch_ms = k["total_ms"] / launches
+        k_alg = (k["bytes_in"] + k["bytes_out"]) / launches
+        k_ach = k_alg / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        sym_per_launch = k["bytes_in"] / launches
+        # compulsory traffic of a step = the record read once + the final streams written once
+        alg_step = int(nbytes + out_bytes)
+        step_ach = alg_step * world / (ms_per_step * 1e-3) / 1e9
+        issue = None
+        if instr_per_symbol is not None and per_launch_ms > 0:
+            ips = instr_per_symbol * sym_per_launch / (per_launch_ms * 1e-3)
+            issue = {"achieved": round(ips / 1e9, 2), "peak": round(1024 * 2.4, 1), "unit": "Ginstr/s", "frac": round(ips / (1024 * 2.4e9), 4),
+                     "instr_per_symbol": round(instr_per_symbol, 3), "issue_source": issue_src}
+        parity_checked = bool(parity) and all(v.get("ok") for v in parity.values())
         line = {
             "metric": "input FASTQ MB/s compressed, 100 bp reads, bit-exact decompress",
             "value": round(value, 2),
@@ -251,6 +296,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "parity_checked": parity_checked,
+            "parity": parity or None,
             "config": {"workload": f"{n} x {L} bp single-end synthetic FASTQ per GPU, arithmetic-coded qualities "
                                    "(BASELINE.json configs[1])", "reads_per_gpu": n, "read_length": L,
                        "input_bytes_per_gpu": nbytes, "output_bytes_per_gpu": int(out_bytes),
@@ -258,24 +305,22 @@ def main():
                        "bucket_set_size": B, "spill_chunks": stats["chunks"],
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
                        "shards_in_flight": D, "shards_per_coder_launch": G, "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
-            # The dominant kernel is a serial coder chain per 10 MiB block: its roof is the chip's instruction issue rate, not
-            # HBM.  achieved = instructions it issues per second -- 6.3 per symbol (4.8 VALU + 1.3 SALU + 0.2 LDS,
-            # rocprofv3 --pmc SQ_INSTS_*, profiles/r01 pmc_sq) x symbols per launch / launch time -- against 1024 SIMDs x
-            # 2.4 GHz.  The HBM view of the same launch (algorithmic bytes / time against 8 TB/s) is kept beside it.
-            "roofline": {"bound": "issue", "kernel": kname,
-                         "achieved": round(6.3 * k["bytes_in"] / max(k["launches"], 1) / (per_launch_ms * 1e-3) / 1e9, 2) if per_launch_ms > 0 else None,
-                         "peak": round(1024 * 2.4, 1), "unit": "Ginstr/s",
-                         "frac": round(6.3 * k["bytes_in"] / max(k["launches"], 1) / (1024 * 2.4e9 * per_launch_ms * 1e-3), 4) if per_launch_ms > 0 else None,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                                 "alg_bytes_per_launch": int(alg_bytes)},
-                         "launch_ms": round(per_launch_ms, 3),
-                         "ns_per_symbol_per_block": round(per_launch_ms * 1e6 / min(max(k["bytes_in"] / max(k["launches"], 1), 1), 10 * 1024 * 1024), 2),
-                         "shards_per_launch": G,
-                         "note": "serial coder chain per 10 MiB block: bound by the issue slots of one wavefront per eight blocks (ns per "
-                                 "symbol per block is the figure to watch); blocks run concurrently, "
-                                 + ("four or eight per chain wave, one launch for %d shards at one workgroup per CU" % G
-                                    if G > 1 else "one 2-wave workgroup each")},
+            # achieved = algorithmic bytes of a step (the FASTQ record read once + the three archive streams
+            # written once: 308 B per read) / ms_per_step, against the HBM peak.  `kernel` = the dominant kernel on its own:
+            # algorithmic bytes of a launch (symbols in + coded bytes out) / its HIP-event time, its counter traffic, and the
+            # issue-slot view (it is a serial chain per 10 MiB block: bound by instruction issue, not by HBM).
+            "roofline": {"bound": "hbm", "achieved": round(step_ach, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                         "frac": round(step_ach / (HBM_PEAK_GBS * world), 5),
+                         "traffic": step_traffic, "traffic_source": traffic_src,
+                         "alg_bytes_per_step": alg_step, "bytes_per_read": round(alg_step / n, 1),
+                         "kernel": {"name": kname, "launch_ms": round(per_launch_ms, 3), "shards_per_launch": G,
+                                    "bound": "issue",
+                                    "achieved": round(k_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_ach / HBM_PEAK_GBS, 6),
+                                    "alg_bytes_per_launch": int(k_alg), "traffic": k_traffic,
+                                    "issue": issue,
+                                    "ns_per_symbol_per_block": round(per_launch_ms * 1e6 / min(max(sym_per_launch, 1), 10 * 1024 * 1024), 2),
+                                    "note": "serial coder chain per 10 MiB block: the time of a launch is 10.5 M steps of one wavefront, "
+                                            "whatever the number of blocks beside it"}},
             "cpu_baseline": cpu,
             "e2e": e2e,
             "note": "value = device-resident steady state with %d shards (independent jobs of the configs[1] size) in flight; "
@@ -326,12 +371,17 @@ def end_to_end(text, nbytes):
 
 
 def cpu_baseline(text, n, L, sample):
-    """Time the CPU side on the first `sample` records of the same shard, on this box's host cores.
+    """Time the CPU side on the first `sample` records of the same shard, on this box's host cores, and check the
+    product against it on the same bytes.  Returns (cpu_baseline object, parity object).
 
-    kind "reference": oracle/_ref/ref_driver -t -- the reference's OWN hot-path objects (aho_search, output_read,
-    output_quality, aho_trie_bucket, bin_prepare, ac_coder; built in the dev container from /root/reference, the
-    binary travels with the repo) driven by a harness that plays main()/thread() at -T 1.  Falls back to kind
-    "port" (oracle/orc_cli, the plain-C restatement) where that binary is missing."""
+    kind "reference": oracle/_ref/ref_full -- the reference's OWN compress() (compress.cpp:721; every reference source
+    but main.cpp compiled where it lies, in the dev container; the binary travels with the repo), file in, archive out,
+    at -T 1 (deterministic: the parity contract) and at the reference's default thread count (main.cpp:171).  Falls back
+    to kind "port" (oracle/orc_cli, the plain-C restatement) where that binary is missing.
+    Parity: the `scalce` binary compresses the same sample file; its three archive files must be byte-identical with the
+    -T 1 files of the CPU leg."""
+    import hashlib
+
     import numpy as np
     sample = min(sample, n)
     approx = sample * (2 * L + 8 + len(str(sample)))
@@ -339,42 +389,63 @@ def cpu_baseline(text, n, L, sample):
     nl = np.flatnonzero(head == 10)
     sample = min(sample, len(nl) // 4)
     end = int(nl[4 * sample - 1]) + 1
-    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    pbin = os.path.join(ROOT, "tests", "golden", "patterns.bin")
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_full")
     exe = os.path.join(ROOT, "oracle", "orc_cli")
+    cli = os.path.join(ROOT, "scalce_amd", "bin", "scalce")
     use_ref = os.path.exists(ref) and os.access(ref, os.X_OK)
     if not use_ref and not os.path.exists(exe):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    with tempfile.TemporaryDirectory() as d:
+    T = max(1, min(4, (os.cpu_count() or 2) - 1))
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=base) as d:
         fq = os.path.join(d, "s_1.fq")
         head[:end].tofile(fq)
-        t0 = time.perf_counter()
-        if use_ref:
-            r = subprocess.run([ref, fq, d, "-t"], capture_output=True, text=True)
-            use_ref = r.returncode == 0
-        if not use_ref:
+
+        def run_cpu(threads, out):
+            if use_ref:
+                cmd = [ref, "compress", pbin, fq, os.path.join(d, out), "-c", "no", "-T", str(threads), "-t", os.path.join(d, "tmp_" + out)]
+            else:
+                cmd = [exe, "compress", pbin, fq, os.path.join(d, out), "-c", "no", "-T", str(threads)]
             t0 = time.perf_counter()
-            subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
-                            os.path.join(d, "o"), "-c", "no", "-T", "1"], check=True, capture_output=True)
-        dt = time.perf_counter() - t0
-        # second leg: the reference's default thread count, main.cpp:171.  The reference's own thread() is not
-        # linkable here (needs buffio) and is racy at -T > 1; the C port codes the arithmetic-coder blocks on T threads and
-        # keeps the record loop on one.
-        T = max(1, min(4, (os.cpu_count() or 2) - 1))
-        if not os.path.exists(exe):
-            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-        t1 = time.perf_counter()
-        r4 = subprocess.run([exe, "compress", os.path.join(ROOT, "tests", "golden", "patterns.bin"), fq,
-                             os.path.join(d, "o4"), "-c", "no", "-T", str(T)], capture_output=True)
-        dt4 = time.perf_counter() - t1 if r4.returncode == 0 else None
-    what = ("oracle/_ref/ref_driver -t (the reference's own objects, one thread)" if use_ref
-            else "orc_cli compress -c no -T 1 (C restatement, one thread)")
-    return {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"first {sample} records ({end} bytes) of the same shard, {what}, {dt:.2f} s wall incl. file I/O",
-            "host_cpus": os.cpu_count(),
-            "threads_default": None if dt4 is None else {
-                "value": round(end / dt4 / 1e6, 2), "unit": "MB/s", "cores": T, "kind": "port",
-                "sample": f"same sample, orc_cli compress -c no -T {T} (main.cpp:171 default thread count; coder blocks on "
-                          f"{T} threads, record loop on one), {dt4:.2f} s wall"}}
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            return time.perf_counter() - t0, r.returncode
+
+        dt, rc = run_cpu(1, "cpu1")
+        if rc != 0 and use_ref:
+            use_ref = False
+            dt, rc = run_cpu(1, "cpu1")
+        if rc != 0:
+            raise RuntimeError("CPU leg failed")
+        dt4, rc4 = run_cpu(T, "cpuT") if T > 1 else (None, 1)
+        what = ("oracle/_ref/ref_full compress -c no (the reference's own compress(), file in, archive out)" if use_ref
+                else "orc_cli compress -c no (C restatement)")
+        cpu = {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
+               "sample": f"first {sample} records ({end} bytes) of the same shard, {what} -T 1, {dt:.2f} s wall incl. file I/O on tmpfs",
+               "host_cpus": os.cpu_count(),
+               "threads_default": None if rc4 != 0 else {
+                   "value": round(end / dt4 / 1e6, 2), "unit": "MB/s", "cores": T, "kind": "reference" if use_ref else "port",
+                   "sample": f"same sample, -T {T} (main.cpp:171 default thread count"
+                             + ("; the reference's output at -T > 1 is racy, its time is not" if use_ref else "; coder blocks on threads, record loop on one")
+                             + f"), {dt4:.2f} s wall"}}
+        # the product on the same bytes
+        parity = {"ok": False, "what": f"`scalce -c no` on the same {sample}-record file: .scalce{{n,r,q}} byte-identical with the "
+                                       + ("reference's" if use_ref else "C restatement's") + " -T 1 files"}
+        if os.path.exists(cli):
+            r = subprocess.run([cli, "-c", "no", "-o", os.path.join(d, "hip"), fq, "--patterns-bin", pbin], capture_output=True, text=True)
+            if r.returncode != 0:
+                parity["error"] = r.stderr[-300:]
+            else:
+                same = {}
+                for e in "nrq":
+                    ha = hashlib.sha256(open(os.path.join(d, f"hip_1.scalce{e}"), "rb").read()).hexdigest()
+                    hb = hashlib.sha256(open(os.path.join(d, f"cpu1_1.scalce{e}"), "rb").read()).hexdigest()
+                    same["scalce" + e] = ha == hb
+                parity["files"] = same
+                parity["ok"] = all(same.values())
+        else:
+            parity["error"] = "scalce binary not built"
+    return cpu, parity
 
 
 if __name__ == "__main__":

@@ -1,0 +1,86 @@
+"""Self-checks of a timed run (bench.py): does the shard that was just compressed come back?
+
+Host-side plumbing around the C ABI, torch only as device memory: the archive streams of a finished Batch are decoded
+on the device (scalce_ac_decode, scalce_fastq_records: the inverse path, /root/reference/decompress.cpp:240-366) and
+the rebuilt FASTQ text is compared with the input through an order-independent digest of its records -- the archive
+holds the records in bucket order, so the comparison is one of multisets, as in tools/fastq_digest.c.
+"""
+import numpy as np
+
+from . import host
+
+_P = 0x9E3779B97F4A7C15          # odd: invertible modulo 2^64
+_PINV = pow(_P, -1, 1 << 64)
+_CHUNK = 1 << 27
+
+
+def _i64(x):
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _mix(h, torch):
+    """64-bit finaliser on int64 tensors (shifts are arithmetic in torch: mask the sign extension away)."""
+    h = h ^ ((h >> 31) & 0x1FFFFFFFF)
+    h = h * _i64(0x7FB5D329728EA185)
+    h = h ^ ((h >> 27) & 0x1FFFFFFFFF)
+    h = h * _i64(0x81DADEF4BC2DD44D)
+    h = h ^ ((h >> 33) & 0x7FFFFFFF)
+    return h
+
+
+def record_digest(text):
+    """(records, sum of a 64-bit hash per record, sum of a second hash) of FASTQ text held in a uint8 device tensor.
+    A record is four lines; its hash does not depend on where it stands, so two texts with the same records in any order
+    give the same triple.  Everything modulo 2^64 (int64 wrap-around)."""
+    import torch
+    dev = text.device
+    n = text.numel()
+    pw = torch.cumprod(torch.full((_CHUNK,), _i64(_P), dtype=torch.int64, device=dev), 0)        # P^(i+1)
+    pinv = torch.cumprod(torch.full((_CHUNK,), _i64(_PINV), dtype=torch.int64, device=dev), 0)   # P^-(i+1)
+    count, s1, s2 = 0, 0, 0
+    pos = 0
+    while pos < n:
+        end = min(n, pos + _CHUNK)
+        seg = text[pos:end]
+        nl = (seg == 10).nonzero().flatten()
+        k = nl.numel() // 4 * 4
+        if k == 0:
+            raise ValueError("no complete FASTQ record in %d bytes at offset %d" % (end - pos, pos))
+        rec_end = nl[3:k:4]                       # index of each record's last newline
+        used = int(rec_end[-1]) + 1
+        if end == n and (k != nl.numel() or used != end - pos):
+            raise ValueError("text does not end on a record boundary")
+        seg = seg[:used].to(torch.int64)
+        c = torch.cumsum(seg * pw[:used], 0)      # c[i] = sum_{j <= i} b_j P^(j+1)
+        starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), rec_end[:-1] + 1])
+        before = torch.where(starts > 0, c[(starts - 1).clamp(min=0)], torch.zeros_like(starts))
+        h = (c[rec_end] - before) * torch.where(starts > 0, pinv[(starts - 1).clamp(min=0)], torch.ones_like(starts))
+        count += int(rec_end.numel())
+        s1 = (s1 + int(_mix(h, torch).sum())) & ((1 << 64) - 1)
+        s2 = (s2 + int(_mix(h ^ _i64(0xD6E8FEB86659FD93), torch).sum())) & ((1 << 64) - 1)
+        pos += used
+        del seg, c, h, before, starts, nl, rec_end
+    return count, s1, s2
+
+
+def decode_shard(ctx, batch, read_len, phred, device):
+    """The finished single-end Batch's archive streams back to FASTQ text on the device (uint8 tensor)."""
+    import ctypes as C
+
+    import torch
+    n = batch.n_reads
+    nsym = n * read_len
+    sym = torch.empty(nsym + 64, dtype=torch.uint8, device=device)
+    p, nbytes = batch.output_ptr(host.OUT_QUAL, 0)
+    ctx.ac_decode(batch.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nsym, sym.data_ptr())
+    reads = batch.output(host.OUT_READS, 0)
+    names = batch.output(host.OUT_NAMES, 0)
+    L = ctx.L
+    cap = L.scalce_fastq_text_bytes(read_len, n, len(names), None)
+    out = torch.empty(cap + 64, dtype=torch.uint8, device=device)
+    nb = C.c_uint64(0)
+    ctx._check(L.scalce_fastq_records(ctx.h, read_len, 1, reads.ctypes.data, len(reads), n, sym.data_ptr(), int(phred),
+                                      names.ctypes.data, len(names), b"", 0, out.data_ptr(), cap, C.byref(nb), None, 0))
+    torch.cuda.synchronize()
+    return out[: nb.value]

@@ -8,9 +8,9 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 9 --warmup 3 --cpu-sample 0 --no-e2e > $O/stats.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --steps 3 --warmup 3 --cpu-sample 0 --no-e2e > $O/fetch.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- python3 $R/bench.py --steps 3 --warmup 3 --cpu-sample 0 --no-e2e > $O/write.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 9 --warmup 3 --cpu-sample 0 --no-e2e --no-verify > $O/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --steps 3 --warmup 3 --cpu-sample 0 --no-e2e --no-verify > $O/fetch.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- python3 $R/bench.py --steps 3 --warmup 3 --cpu-sample 0 --no-e2e --no-verify > $O/write.log 2>&1
 cd $R
 python3 tools/prof_summary.py stats $O/stats $R/gpurun_out/${TAG}_bench50m_kernel_stats.csv
 python3 tools/prof_summary.py pmc $O/fetch $O/write $R/gpurun_out/${TAG}_bench50m_pmc_fetch_write.json 10
