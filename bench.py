@@ -118,11 +118,14 @@ def main():
     # (5 GB each) and, while a shard is worked on, the text it received from its neighbours and the all-to-all buffers
     # (about 25 GB): 190 GB.  Larger groups do not pay yet: from four shards per launch on the front stages, not the coder,
     # bound the pipeline.
+    # four shards per coder launch, two launches side by side, twelve shards in flight (234 GB): a launch of the
+    # one-block-per-lane coder takes ~0.56 s whatever it holds and 60 CUs for four shards, so the pipeline needs two of
+    # them running beside the front stages of the next four shards (profiles/README.md, r03 rows)
     G = args.group
     if G is None:
-        G = 3
+        G = 4
     G = max(1, G)
-    D = max(1, args.inflight) if args.inflight is not None else 2 * G
+    D = max(1, args.inflight) if args.inflight is not None else 3 * G
     if G > 1:
         D = max(D, 2 * G)
     # -B: the reference's default, 4 GiB of record bytes per spill chunk (main.cpp:68) -- 50 M reads of 100 bp are 3 chunks
@@ -151,7 +154,7 @@ def main():
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
     pipe = ShardPipeline(batches, group=G, sharded=sharded, trace=mark if trace else None,
-                         coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "1")))
+                         coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "2" if G > 1 else "1")))
     front = pipe.front
 
     def run(k):
@@ -243,7 +246,9 @@ def main():
     # tools/pmc_sq.sh <tag>; SCALCE_PROFILE_TAG names the tag): HBM bytes from --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes (KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM"), instructions
     # from --pmc SQ_INSTS_*.  A figure whose file is missing is null, never a constant.
-    kname = {1: "ac_encode_k", 64: "ac_encode_lanes_k"}.get(1 if G == 1 else int(os.environ.get("SCALCE_AC_BLOCKS_PER_WG", "0") or 0), "ac_encode_rows_k")
+    bpw_env = int(os.environ.get("SCALCE_AC_BLOCKS_PER_WG", "0") or 0)
+    nblk_launch = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
+    kname = "ac_encode_k" if G == 1 else ("ac_encode_rows_k" if bpw_env in (4, 8) or (bpw_env == 0 and nblk_launch < 900) else "ac_encode_lanes_k")
     tag = os.environ.get("SCALCE_PROFILE_TAG", "r03_final")
     pmc = os.path.join(ROOT, "profiles", f"{tag}_bench50m_pmc_fetch_write.json")
     sqf = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")

@@ -94,10 +94,10 @@ __device__ __forceinline__ void acl_step_plain(u32 &lo, u32 &M, const uint4 g, u
 //   * the notes -- word indices, in a log that grows down from the end of the block's own output buffer -- are applied by
 //     finish(): additions commute.  (Resolved on the spot, a loop of loads and stores in the step sequence, the compiler
 //     put s_waitcnt vmcnt(0) in front of every store of the following steps.)
-constexpr int ACL_RING = 64;  // staging ring, words per lane: the sink is at most three rounds (48 words) ahead of the writer
+constexpr int ACL_RING = 128;  // staging ring, words per lane: the writer takes whole 128-byte lines (32 words), the sink is at most three rounds (48 words) ahead of it
 struct AclSink {
   SCALCE_GLOBAL u32 *dst;
-  u32 (*ring)[64];  // [slot][lane]: word k of the block lives in slot (k + 1) & 63 -- lane l always hits bank l
+  u32 (*ring)[64];  // [slot][lane]: word k of the block lives in slot (k + 1) & (ACL_RING - 1) -- lane l always hits bank l
   int lane;
   u32 wcap;      // words the block may write
   u32 w2, w1, w0;
@@ -239,8 +239,9 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
   // only: any placement gives the same bytes.
   const u32 nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7u, xcd = blockIdx.x & 7u;
   const u32 wg = (xcd < xr ? xcd * (xq + 1u) : xr * (xq + 1u) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  const u32 blk = wg * 64u + (u32)lane;
-  const bool have = blk < a.nblocks;
+  const u32 bpw = a.lanes_used ? a.lanes_used : 64u;  // blocks per workgroup (lanes in use)
+  const u32 blk = wg * bpw + (u32)lane;
+  const bool have = blk < a.nblocks && (u32)lane < bpw;
   const SCALCE_GLOBAL AcBlockDesc *dp = (const SCALCE_GLOBAL AcBlockDesc *)a.desc + (have ? blk : 0u);
   const u32 n = have ? dp->n : 0u;
   const u32 nr = (n + ACL_STEPS - 1) / ACL_STEPS;  // rounds of this lane's block
@@ -285,28 +286,37 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
         p1 = c;
       }
     };
-    // VMEM in issue order: prologue [S0 S1 S2 S3] wait [R0 S4] [R1 S5] [R2 S6] [R3 S7], then per iteration i
-    // [R(i+4) S(i+8)]; R = 16 instructions.  Symbols S(k) sit in set k % 4.  The hardware counts at most 63 outstanding
-    // vector memory instructions per wave: three rounds in flight behind the one awaited is as deep as it goes.
-    u32x4 s0 = acl_load16(sym_addr(0)), s1 = acl_load16(sym_addr(1)), s2 = acl_load16(sym_addr(2)), s3 = acl_load16(sym_addr(3));
-    acl_wait_vm<3>(s0);
-    request(s0, 0); s0 = acl_load16(sym_addr(4));
-    acl_wait_vm<2 + 17>(s1);
-    request(s1, 1); s1 = acl_load16(sym_addr(5));
-    acl_wait_vm<1 + 2 * 17>(s2);
-    request(s2, 2); s2 = acl_load16(sym_addr(6));
-    acl_wait_vm<3 * 17>(s3);
-    request(s3, 3); s3 = acl_load16(sym_addr(7));
-    acl_wait_vm<3 * 17>();  // round 0 is in LDS
+    // Symbols come 128 bytes per lane at a time (8 rounds; two chunks alternate: A = rounds 0..7 of every 16, B = 8..15),
+    // each chunk requested eight rounds before its first symbol is used.  Sixteen bytes per round -- as this wave first
+    // did -- touches every 128-byte line of the block eight times, 0.75 us apart, and beside another shard's front stages
+    // the line has left the L2 in between: the stream was fetched from HBM several times over and a launch took 1.7 x
+    // as long beside the ingest stage as alone.
+    // VMEM in issue order: prologue [A B] wait [R0 R1 R2 R3], then per iteration i [R(i+4)] and, twice in 16 iterations, a
+    // chunk of 8 loads behind it; R = 16 instructions.  The hardware counts at most 63 outstanding vector memory
+    // instructions per wave: three requests in flight behind the one awaited is as deep as it goes, and everything older
+    // than those 48 instructions -- the chunks, requested 8 rounds ahead -- has landed by then.
+    u32x4 ca[8], cb[8];
+    auto load_chunk = [&](u32x4 (&c)[8], u32 first) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) c[q] = acl_load16(sym_addr(first + q));
+    };
+    load_chunk(ca, 0);
+    load_chunk(cb, 8);
+#pragma unroll
+    for (int q = 0; q < 8; q++) { acl_wait_vm<0>(ca[q]); acl_wait_vm<0>(cb[q]); }
+    request(ca[0], 0);
+    request(ca[1], 1);
+    request(ca[2], 2);
+    request(ca[3], 3);
+    acl_wait_vm<3 * 16>();  // round 0 is in LDS
     asm volatile("s_barrier" ::: "memory");
     u64 gprof_wait = 0;
-    // iteration i: symbols of round i + 4 are here when at most the three iterations behind them are outstanding; round
-    // i + 1 is in LDS when at most the three requests behind it are
-    auto iteration = [&](u32 i, u32x4 &sset) {
-      acl_wait_vm<3 * 17>(sset);
-      request(sset, i + 4);
-      sset = acl_load16(sym_addr(i + 8));
-      acl_wait_vm<3 * 17>();
+    // iteration i: request round i + 4; round i + 1 is in LDS when at most the three requests behind it are outstanding
+    auto iteration = [&](u32 i, const u32x4 &sy) {
+      request(sy, i + 4);
+    };
+    auto close = [&]() {
+      acl_wait_vm<3 * 16>();
       if (a.prof) {
         const u64 w0 = __builtin_amdgcn_s_memtime();
         asm volatile("s_barrier" ::: "memory");
@@ -315,11 +325,17 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
         asm volatile("s_barrier" ::: "memory");
       }
     };
-    for (u32 i = 0; i < nr_wg; i += 4) {
-      iteration(i, s0);
-      if (i + 1 < nr_wg) iteration(i + 1, s1);
-      if (i + 2 < nr_wg) iteration(i + 2, s2);
-      if (i + 3 < nr_wg) iteration(i + 3, s3);
+    for (u32 i0 = 0; i0 < nr_wg; i0 += 16) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        if (i0 + j < nr_wg) {
+          // round i0 + j + 4: symbols 4..7 of chunk A, then chunk B, then 0..3 of the next chunk A (requested at j = 4)
+          iteration(i0 + j, j < 4 ? ca[j + 4] : j < 12 ? cb[j - 4] : ca[j - 12]);
+          if (j == 4) load_chunk(ca, i0 + 16);
+          if (j == 12) load_chunk(cb, i0 + 24);
+          close();
+        }
+      }
     }
     acl_wait_vm<0>();  // nothing of this wave may land in LDS after the workgroup has gone
     asm volatile("s_barrier" ::: "memory");  // (the sink's last round)
@@ -447,15 +463,21 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
     // ================= writer: final words out of the staging ring =================
     SCALCE_GLOBAL u32 *dst = (SCALCE_GLOBAL u32 *)dp->dst;
     const u32 wcap = a.out_cap / 4;
-    u32 wo = 0;  // words of this lane's block in global memory (multiple of 4 until the end)
+    u32 wo = 0;  // words of this lane's block in global memory (multiple of 32 until the end)
     auto word = [&](u32 k) -> u32 { return __builtin_bswap32(sh.stage[(k + 1u) & (ACL_RING - 1)][lane]); };
-    auto drain = [&](u32 lim) {  // 16 bytes per lane and store while any lane has them
-      while (__any(lim - wo >= 4u && lim > wo)) {
-        if (lim - wo >= 4u && lim > wo) {
-          u32x4 o;
-          o.x = word(wo); o.y = word(wo + 1); o.z = word(wo + 2); o.w = word(wo + 3);
-          if (wo + 4u <= wcap) *(SCALCE_GLOBAL u32x4 *)(dst + wo) = o;
-          wo += 4;
+    // Whole 128-byte lines: 32 words per lane in eight 16-byte stores back to back.  (Sixteen bytes per lane and visit left
+    // every line of the output half written in the L2 for several rounds -- where another shard's front stages stream
+    // through the same L2 it went to memory in pieces.)
+    auto drain = [&](u32 lim) {
+      while (__any(lim >= wo + 32u)) {
+        if (lim >= wo + 32u) {
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            u32x4 o;
+            o.x = word(wo + 4 * q); o.y = word(wo + 4 * q + 1); o.z = word(wo + 4 * q + 2); o.w = word(wo + 4 * q + 3);
+            if (wo + 4 * q + 4u <= wcap) *(SCALCE_GLOBAL u32x4 *)(dst + wo + 4 * q) = o;
+          }
+          wo += 32;
         }
       }
     };

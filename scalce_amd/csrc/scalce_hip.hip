@@ -1433,7 +1433,19 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true) {
   return SCALCE_OK;
 }
 
-// ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 / 8 = ac_encode_rows_k.
+// Blocks per workgroup of ac_encode_lanes_k.  A lane per block would be 64; the default is 32, half of the lanes idle: all
+// table rows of a workgroup's blocks go through ONE CU's vector memory pipeline (1024 scattered 16-byte reads per
+// 0.75 us round at 64), and beside another shard's streaming front stages -- when an L2 miss takes three times as long --
+// that pipeline, not the coder, set the pace of a launch: 908 ms beside the ingest stage and 1299 ms beside the order stage
+// at 64 blocks per workgroup against 575 / 694 ms at 32 and 560 / 559 ms at 16 (543 ms alone; tools/coder_beside.py).
+static u32 ac_lanes_used() {
+  const char *e = getenv("SCALCE_AC_LANES_USED");
+  const int v = e ? atoi(e) : 32;
+  return (u32)(v < 1 || v > 64 ? 32 : v);
+}
+
+// ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 / 8 = ac_encode_rows_k,
+// 64 = ac_encode_lanes_k (one block per lane).
 // `ps` = the stream the tables were prepared on: the block descriptors are uploaded there (never behind a coder that
 // is still running on `s`), and `s` is made to wait for it.
 static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, hipStream_t ps) {
@@ -1533,11 +1545,12 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
-    const u32 nwg = cdiv(total, (u32)blocks_per_wg);
+    const u32 nwg = cdiv(total, blocks_per_wg == 64 ? ac_lanes_used() : (u32)blocks_per_wg);
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * nwg)); }
     if (blocks_per_wg == 64) {
-      if (getenv("SCALCE_AC_LANES_SHARED")) LAUNCH(ac_encode_lanes_k<false>, cdiv(total, 64), 256, 0, s, a);
-      else LAUNCH(ac_encode_lanes_k<true>, cdiv(total, 64), 256, 0, s, a);
+      a.lanes_used = ac_lanes_used();
+      if (getenv("SCALCE_AC_LANES_SHARED")) LAUNCH(ac_encode_lanes_k<false>, cdiv(total, a.lanes_used), 256, 0, s, a);
+      else LAUNCH(ac_encode_lanes_k<true>, cdiv(total, a.lanes_used), 256, 0, s, a);
     } else if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
@@ -1772,7 +1785,10 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
   // a SIMD to itself -- four for up to two 50 M-read shards, eight beyond
   u32 total = 0;
   for (auto &j : jobs) total += j.nblk;
-  int bpw = total <= 4 * 256 ? 4 : 8;
+  // one shard (477 blocks at 50 M x 100): four blocks per chain wave, the lowest latency that still leaves every chain wave a
+  // SIMD of its own; from two shards on one block per LANE -- the launch then takes ~0.56 s whatever its size, but on a
+  // sixth of the SIMD time per block, and the front stages of the next shards keep the chip
+  int bpw = total < 900 ? 4 : 64;
   if (ac_blocks_per_wg() != 1) bpw = ac_blocks_per_wg();
 
   int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);

@@ -31,7 +31,10 @@ stages = {
     "order": lambda: B.order(s2.cuda_stream),
     "emit": lambda: B.emit(s2.cuda_stream),
 }
+only = sys.argv[1].split(",") if len(sys.argv) > 1 else None
 for name, f in stages.items():
+    if only and name not in only:
+        continue
     for b in grp:
         b.front(text.data_ptr(), nbytes, None, 0, s1.cuda_stream)
     torch.cuda.synchronize()
