@@ -29,7 +29,12 @@
 #include <string>
 #include <vector>
 
+#include <cerrno>
+#include <csignal>
+
 #include "../../include/scalce_hip.h"
+
+static const int EXIT_UNCUT = 3;  // a rank's exit status: -B does not cut the run (scalce_sharded_compress: SCALCE_ERR_UNCUT)
 
 #ifndef SCALCE_VERSION
 #define SCALCE_VERSION "2.8-mi355x"
@@ -62,6 +67,8 @@ struct Options {
   std::string out, library, patterns, temp = "__temp__", patterns_bin;
   int gpus = 1;                           // --gpus N: one process per GPU, ONE archive (plain-text input, -c no)
   int container = 1;                      // 0 plain, 1 gzip (main.cpp:181-184 at -T 1)
+  uint64_t first_file_bytes[2] = {0, 0};  // --gpus over several files written out as one: where the first file ends (the
+                                          // quality sample never leaves files[0], compress.cpp:761)
 };
 
 static const char *HELP_TEXT =
@@ -662,6 +669,7 @@ static int rank_main(const Options &o, const std::vector<std::string> &files, co
     src.files.push_back(path[m]);
     src.fill_peek(o.sample);
     if (!src.all_plain) FAIL("--gpus needs plain (not gzip) input: the file is split by byte ranges\n");
+    if (o.first_file_bytes[m] && src.peek.size() > o.first_file_bytes[m]) src.peek.resize((size_t)o.first_file_bytes[m]);
     int32_t qhist[128];
     int rl = 0;
     sample_stats(src.peek, o.sample, qhist, rl);
@@ -745,8 +753,11 @@ static int rank_main(const Options &o, const std::vector<std::string> &files, co
   SCOK(ctx, scalce_batch_create(ctx, &p, rows + rows / 3, std::max(hi[0] - lo[0], nm == 2 ? hi[1] - lo[1] : 0) + 256, &b));
   scalce_shard_result res;
   memset(&res, 0, sizeof res);
-  if (scalce_sharded_compress(comm, ctx, b, d_text[0], hi[0] - lo[0], nm == 2 ? d_text[1] : nullptr, nm == 2 ? hi[1] - lo[1] : 0, 0, s, nullptr, &res))
-    exit(1);
+  {
+    const int rc = scalce_sharded_compress(comm, ctx, b, d_text[0], hi[0] - lo[0], nm == 2 ? d_text[1] : nullptr, nm == 2 ? hi[1] - lo[1] : 0, 0, s, nullptr, &res);
+    if (rc == SCALCE_ERR_UNCUT) _exit(EXIT_UNCUT);  // every rank alike; nothing has been written yet
+    if (rc) exit(1);
+  }
   for (int m = 0; m < nm; m++) hipFree(d_text[m]);
   const double t2 = now();
   // ---- every rank writes its pieces of the archive
@@ -873,13 +884,98 @@ static int rank_main(const Options &o, const std::vector<std::string> &files, co
   return 0;
 }
 
-static int multi_gpu_compress(const Options &o, const std::vector<std::string> &files, const char *argv0) {
-  if (o.container != 0) FAIL("--gpus writes the archive in pieces at computed offsets: use -c no\n");
-  if (files.size() != 1) FAIL("--gpus takes one input file (and its mate with -r)\n");
-  if (o.gpus > 64) FAIL("--gpus: at most 64\n");
+// --gpus splits ONE plain file per mate by byte ranges.  Several input files, or gzip input (the reference runs any number
+// of files, each through its gz reader, compress.cpp:756-811): the record stream of every mate -- the files one after the
+// other, inflated -- is written out once as a plain file under -t, and the ranks split that.
+static bool plain_single_input(const Options &o, const std::vector<std::string> &files) {
+  if (files.size() != 1) return false;
+  for (int m = 0; m < (o.paired ? 2 : 1); m++) {
+    std::string path = files[0];
+    if (m && !second_file(files[0], path)) return true;  // (the rank reports it)
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    uint8_t mg[2] = {0, 0};
+    const bool gz = fd >= 0 && ::pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1F && mg[1] == 0x8B;
+    if (fd >= 0) ::close(fd);
+    if (gz) return false;
+  }
+  return true;
+}
+static std::string materialize_inputs(Options &o, const std::vector<std::string> &files, const char *tag, std::vector<std::string> &made) {
+  struct stat st;
+  std::string dir = o.temp;
+  if (stat(dir.c_str(), &st) != 0 && mkdir(dir.c_str(), 0777) != 0) dir = "/tmp";
+  // the mate digit is the LAST '1' of the path (get_second_file, const.cpp:51-64): it closes the name
+  std::string base = dir + "/scalce_gpus_" + tag + "_m";
+  for (char &c : base) if (&c >= &base[dir.size()] && c == '1') c = 'x';
+  std::vector<uint8_t> buf(64u << 20);
+  for (int m = 0; m < (o.paired ? 2 : 1); m++) {
+    MateSource src;
+    for (auto &f : files) {
+      std::string path = f;
+      if (m && !second_file(f, path)) FAIL("Cannot get file name for paired end for file %s. File should contain character 1.\n", f.c_str());
+      if (stat(path.c_str(), &st) != 0) FAIL("File %s does not exist or it is not accessible.\n", path.c_str());
+      src.files.push_back(path);
+    }
+    const std::string out = base + (m ? "2" : "1");
+    FILE *f = fopen(out.c_str(), "wb");
+    if (!f) FAIL("Cannot create %s\n", out.c_str());
+    made.push_back(out);
+    uint64_t total = 0;
+    for (;;) {
+      const size_t before = src.cur;
+      const int64_t k = src.read(buf.data(), buf.size());
+      if (k < 0) FAIL("Read error\n");
+      // (a read never spans two files: the first file has ended when the source has moved on to the second)
+      if (!o.first_file_bytes[m] && files.size() > 1 && before >= 1 && src.cur >= 2) o.first_file_bytes[m] = total;
+      if (k == 0) break;
+      if (fwrite(buf.data(), 1, (size_t)k, f) != (size_t)k) FAIL("write failed (%s)\n", out.c_str());
+      total += (uint64_t)k;
+    }
+    fclose(f);
+  }
+  return base + "1";
+}
+// -c gz behind --gpus: the ranks write the plain archive at computed offsets; the streams the reference would have sent
+// through its gzip writer are then rewritten as gzip members by this process's threads
+static void gzip_in_place(const std::string &path) {
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) FAIL("Cannot read %s\n", path.c_str());
+  OutFile out;
+  out.open(path + ".gz.tmp", true);
+  std::vector<uint8_t> buf(256u << 20);
+  for (;;) {
+    const ssize_t k = ::read(fd, buf.data(), buf.size());
+    if (k < 0) FAIL("Read error on %s\n", path.c_str());
+    if (k == 0) break;
+    out.write(buf.data(), (size_t)k);
+  }
+  ::close(fd);
+  out.close();
+  if (rename((path + ".gz.tmp").c_str(), path.c_str()) != 0) FAIL("Cannot replace %s\n", path.c_str());
+}
+
+static int multi_gpu_compress(const Options &o_in, const std::vector<std::string> &files_in, const char *argv0) {
+  if (o_in.gpus > 64) FAIL("--gpus: at most 64\n");
   LOG("Preprocessing FASTQ files ...\n");
   char tag[64];
   snprintf(tag, sizeof tag, "%d_%ld", (int)getpid(), (long)time(nullptr));
+  {
+    const int hw = (int)std::thread::hardware_concurrency();
+    g_threads = o_in.threads > 0 ? o_in.threads : std::max(1, std::min(64, hw - 1));
+  }
+  Options o = o_in;
+  o.container = 0;  // the ranks write plain; -c gz is applied to the finished files below
+  std::vector<std::string> files = files_in, made;
+  if (!plain_single_input(o, files)) {
+    const double t0 = now();
+    files.assign(1, materialize_inputs(o, files_in, tag, made));
+    LOG("\t%zu input file(s) per mate written out as one plain file under %s (%.2f s)\n", files_in.size(),
+        made[0].substr(0, made[0].rfind('/')).c_str(), now() - t0);
+  }
+  struct Cleanup {
+    std::vector<std::string> &v;
+    ~Cleanup() { for (auto &f : v) unlink(f.c_str()); }
+  } cleanup{made};
   {
     const int hw = (int)std::thread::hardware_concurrency();
     g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(64, hw / std::max(1, o.gpus)));
@@ -891,13 +987,38 @@ static int multi_gpu_compress(const Options &o, const std::vector<std::string> &
     if (pid == 0) _exit(rank_main(o, files, argv0, r, o.gpus, tag));
     kids.push_back(pid);
   }
-  int bad = 0;
-  for (pid_t k : kids) {
+  // Ranks are collected in the order they end.  One that fails on its own (a crash, an error outside the collective
+  // protocol of scalce_sharded_compress) leaves the others waiting for it in a collective: the first bad exit ends them.
+  int bad = 0, uncut = 0;
+  size_t left = kids.size();
+  while (left) {
     int st = 0;
-    waitpid(k, &st, 0);
-    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+    const pid_t k = waitpid(-1, &st, 0);
+    if (k < 0) { if (errno == EINTR) continue; break; }
+    auto it = std::find(kids.begin(), kids.end(), k);
+    if (it == kids.end()) continue;
+    *it = -1;
+    left--;
+    const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
+    if (WIFEXITED(st) && WEXITSTATUS(st) == EXIT_UNCUT) uncut++;
+    else if (!ok && !bad) {
+      bad = 1;
+      for (pid_t o2 : kids) if (o2 > 0) kill(o2, SIGTERM);
+    }
   }
   if (bad) { fprintf(stderr, "(ERROR) a rank failed\n"); return 1; }
+  if (uncut) return EXIT_UNCUT;  // every rank found the same: -B does not cut this run (the caller goes on with one GPU)
+  if (o_in.container != 0) {  // compress.cpp:249: the arithmetic-coded stream is never containerised
+    const int hw = (int)std::thread::hardware_concurrency();
+    g_threads = o_in.threads > 0 ? o_in.threads : std::max(1, std::min(64, hw - 1));
+    const double t0 = now();
+    for (int m = 0; m < (o.paired ? 2 : 1); m++)
+      for (const char *ext : {"r", "n", "q"}) {
+        if (ext[0] == 'q' && !o.no_ac) continue;
+        gzip_in_place(o.out + "_" + std::to_string(m + 1) + ".scalce" + ext);
+      }
+    LOG("\tgzip containers written by %d host threads: %.2f s\n", g_threads, now() - t0);
+  }
   LOG("Done!\n");
   return 0;
 }
@@ -1079,7 +1200,14 @@ int main(int argc, char **argv) {
       if (stat(f2.c_str(), &st) != 0) FAIL("File %s does not exist or it is not accessible.\n", f2.c_str());
     }
   }
-  if (o.gpus > 1 && !o.decompress) return multi_gpu_compress(o, files, argv[0]);  // forks before anything touches a GPU
+  if (o.gpus > 1 && !o.decompress) {  // forks before anything touches a GPU
+    const int rc = multi_gpu_compress(o, files, argv[0]);
+    if (rc != EXIT_UNCUT) return rc;
+    // The archive of N GPUs is the one-GPU archive only while rank boundaries can sit on spill-chunk boundaries
+    // (compress.cpp:708-715): a run that -B does not cut anywhere is one chunk, and one chunk is one GPU's work.
+    LOG("** -B %llu does not cut this input into spill chunks: compressing on one GPU (give a smaller -B to use %d) **\n",
+        (unsigned long long)o.bucket_set_size, o.gpus);
+  }
   scalce_ctx *ctx = nullptr;
   if (scalce_ctx_create(0, &ctx)) FAIL("%s\n", scalce_last_error(ctx));
   bool is_text = false;

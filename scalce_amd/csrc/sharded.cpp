@@ -242,31 +242,60 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     const void *dp = nullptr;
     uint64_t nb = 0;
     // ---- 1. first pass over the own piece: rows + quality counters, no tie-break yet
+    // A failure that only ONE rank sees -- a malformed record in its byte range, a read of another length, a buffer that
+    // is too small -- must not leave the others waiting in the next collective for ever.  Rank-local work runs under
+    // local(): what it throws is kept, the rank goes on to the next exchange with empty hands, and the status travels with
+    // an exchange that happens anyway (or with agree(), one word per rank) -- then every rank throws together.
+    Fail local_err{"", 0};
+    auto local = [&](auto &&fn) {
+      if (local_err.rc) return;
+      try { fn(); } catch (const Fail &f) { local_err = f; if (!local_err.rc) local_err.rc = SCALCE_ERR_HIP; }
+    };
+    auto together = [&](const std::vector<u64> &status, size_t stride, size_t at, const char *where) {
+      for (int r = 0; r < W; r++)
+        if (status[(size_t)r * stride + at]) {
+          if (r == rank && local_err.rc) throw local_err;
+          throw Fail{std::string("rank ") + std::to_string(r) + " failed (" + where + "); see its message", (int)status[(size_t)r * stride + at]};
+        }
+      if (local_err.rc) throw local_err;  // (cannot happen: the own status was in the exchange)
+    };
     uint64_t used[2] = {0, 0};
-    SH_RC(ctx, scalce_batch_reset(b));
-    SH_RC(ctx, scalce_batch_append(b, text[0], nbytes[0], text[1], nbytes[1], SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_TOKENIZE, used, s));
-    const u64 N0 = scalce_batch_reads(b);
-    mark("first pass (ingest+quality)");
-    const uint32_t nb1 = (uint32_t)scalce_patterns_buckets(ctx) + 1;
-    res->nb1 = nb1;
+    u64 N0 = 0;
     const int nm = text[1] ? 2 : 1;
     int L[2] = {0, 0};
-    {  // read lengths: symbols per row of the q' output
-      for (int m = 0; m < nm; m++) {
+    local([&] {
+      SH_RC(ctx, scalce_batch_reset(b));
+      SH_RC(ctx, scalce_batch_append(b, text[0], nbytes[0], text[1], nbytes[1], SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_TOKENIZE, used, s));
+      N0 = scalce_batch_reads(b);
+      for (int m = 0; m < nm; m++) {  // read lengths: symbols per row of the q' output
         SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QINPUT, m, &dp, &nb));
         L[m] = N0 ? (int)(nb / N0) : 0;
       }
-    }
+    });
+    if (local_err.rc) N0 = 0;
+    mark("first pass (ingest+quality)");
+    const uint32_t nb1 = (uint32_t)scalce_patterns_buckets(ctx) + 1;
+    res->nb1 = nb1;
     u64 *d_small = mem.alloc<u64>(4096 + 64 * (size_t)W);
     u64 *d_gather = mem.alloc<u64>((size_t)W * 4096 + (size_t)W * 64 * W);
-    // rows and read lengths of everyone (a rank without reads learns the read length here)
+    auto agree = [&](const char *where) {  // one status word per rank
+      u64 mine = (u64)local_err.rc;
+      std::vector<u64> all = gather_host<u64>(comm, &mine, 1, d_small, d_gather, s);
+      together(all, 1, 0, where);
+    };
+    // rows and read lengths of everyone (a rank without reads learns the read length here), and how the first pass went
     std::vector<u64> meta;
     {
-      u64 mine[4] = {N0, (u64)L[0], (u64)L[1], 0};
+      u64 mine[4] = {N0, (u64)L[0], (u64)L[1], (u64)local_err.rc};
       meta = gather_host<u64>(comm, mine, 4, d_small, d_gather, s);
+      together(meta, 4, 3, "first pass over its piece of the input");
       for (int r = 0; r < W; r++)
-        for (int m = 0; m < nm; m++)
-          if (!L[m] && meta[4 * r + 1 + m]) L[m] = (int)meta[4 * r + 1 + m];
+        for (int m = 0; m < nm; m++) {
+          const int Lr = (int)meta[4 * r + 1 + m];
+          if (!L[m] && Lr) L[m] = Lr;
+          // every rank sees the same table: they all stop here together (the reference: compress.cpp:628-634)
+          if (Lr && L[m] && Lr != L[m]) throw Fail{"(ERROR) reads of different lengths in the input (" + std::to_string(L[m]) + " vs " + std::to_string(Lr) + ")", SCALCE_ERR_FORMAT};
+        }
     }
     std::vector<u64> g(W + 1, 0);  // run-wide index of every rank's first record
     for (int r = 0; r < W; r++) g[r + 1] = g[r] + meta[4 * r];
@@ -291,23 +320,26 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       std::vector<uint64_t> cuts(CAP);
       uint32_t nc = 0;
       uint64_t carry_out = 0;
-      SH_RC(ctx, scalce_batch_chunk_plan(b, 0, cuts.data(), CAP, &nc, &carry_out, s));  // sizes of all rows: every rank at once
+      local([&] { SH_RC(ctx, scalce_batch_chunk_plan(b, 0, cuts.data(), CAP, &nc, &carry_out, s)); });  // sizes of all rows: every rank at once
       u64 carry_in = 0;
       for (int k = 0; k < W; k++) {  // rank k can cut once it knows what rank k - 1 left open
-        if (k == rank) SH_RC(ctx, scalce_batch_chunk_plan(b, carry_in, cuts.data(), CAP, &nc, &carry_out, s));
+        if (k == rank) local([&] { SH_RC(ctx, scalce_batch_chunk_plan(b, carry_in, cuts.data(), CAP, &nc, &carry_out, s)); });
         if (W > 1) {
           u64 mine = k == rank ? carry_out : 0;
           std::vector<u64> all = gather_host<u64>(comm, &mine, 1, d_small, d_gather, s);
           if (rank == k + 1) carry_in = all[k];
         }
       }
-      if (nc >= CAP) throw Fail{"more than 4000 spill chunks on one rank: -B is too small for this input", SCALCE_ERR_CAPACITY};
-      std::vector<u64> mine(CAP + 1, 0);
+      local([&] { if (nc >= CAP) throw Fail{"more than 4000 spill chunks on one rank: -B is too small for this input", SCALCE_ERR_CAPACITY}; });
+      if (local_err.rc) nc = 0;
+      std::vector<u64> mine(CAP + 2, 0);
       mine[0] = nc;
+      mine[CAP + 1] = (u64)local_err.rc;
       for (uint32_t i = 0; i < nc; i++) mine[1 + i] = g[rank] + cuts[i];
-      std::vector<u64> all = gather_host<u64>(comm, mine.data(), CAP + 1, d_small, d_gather, s);
+      std::vector<u64> all = gather_host<u64>(comm, mine.data(), CAP + 2, d_small, d_gather, s);
+      together(all, CAP + 2, CAP + 1, "spill-chunk plan");
       for (int r = 0; r < W; r++)
-        for (u64 i = 0; i < all[(size_t)r * (CAP + 1)]; i++) cuts_global.push_back(all[(size_t)r * (CAP + 1) + 1 + i]);
+        for (u64 i = 0; i < all[(size_t)r * (CAP + 2)]; i++) cuts_global.push_back(all[(size_t)r * (CAP + 2) + 1 + i]);
       std::sort(cuts_global.begin(), cuts_global.end());
       res->chunks_total = (uint32_t)cuts_global.size() + ((cuts_global.empty() || cuts_global.back() < total_reads) ? 1 : 0);
     }
@@ -316,8 +348,9 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     std::vector<u64> gn(W + 1);
     {
       const int prc = scalce_shard_plan_boundaries(W, g.data(), cuts_global.data(), cuts_global.size(), gn.data());
-      if (prc) throw Fail{"(ERROR) a sharded run needs a -B that cuts the run: no spill chunk ends inside it, so the records of a bucket "
-                          "would have to be merged across ranks", prc};
+      // (every rank computes the same plan from the same cuts: they all leave here together)
+      if (prc) throw Fail{"a sharded run needs a -B that cuts the run: no spill chunk ends inside it, so the records of a bucket "
+                          "would have to be merged across ranks", SCALCE_ERR_UNCUT};
     }
     auto clampu = [](u64 x, u64 a, u64 b) { return x < a ? a : (x > b ? b : x); };
     res->first_read = gn[rank];
@@ -336,7 +369,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         for (int d = 0; d <= W; d++) {
           const u64 row = clampu(d < W ? gn[d] : gn[W], g[rank], g[rank + 1]) - g[rank];
           uint64_t off = nbytes[m];
-          if (row < N0) SH_RC(ctx, scalce_batch_text_offset(b, m, row, &off));
+          if (row < N0) local([&] { SH_RC(ctx, scalce_batch_text_offset(b, m, row, &off)); });
           start[d] = off;
         }
         start[0] = 0;  // (rows in front of gn[0] = 0 do not exist)
@@ -365,11 +398,15 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
           SH_HIP(hipMemcpyAsync(newtext[m] + before_self + kept, d_recv + before_self, total - kept - before_self, hipMemcpyDeviceToDevice, s));
       }
       // the rows of the new range (their quality symbols were counted by whoever held them in the first pass)
-      SH_RC(ctx, scalce_batch_reset(b));
-      SH_RC(ctx, scalce_batch_append(b, newtext[0], newbytes[0], nm == 2 ? newtext[1] : nullptr, newbytes[1],
-                                     SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_QUALITY | SCALCE_APPEND_NO_TOKENIZE, used, s));
-      if (scalce_batch_reads(b) != res->reads_local) throw Fail{"internal: row count after the exchange differs from the plan", SCALCE_ERR_ARG};
+      local([&] {
+        SH_RC(ctx, scalce_batch_reset(b));
+        SH_RC(ctx, scalce_batch_append(b, newtext[0], newbytes[0], nm == 2 ? newtext[1] : nullptr, newbytes[1],
+                                       SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_QUALITY | SCALCE_APPEND_NO_TOKENIZE, used, s));
+        if (scalce_batch_reads(b) != res->reads_local) throw Fail{"internal: row count after the exchange differs from the plan", SCALCE_ERR_ARG};
+      });
     }
+    if (W > 1) agree("exchange of rows between ranks");
+    else if (local_err.rc) throw local_err;
     mark("exchange + re-ingest");
     const u64 N = scalce_batch_reads(b);
     // ---- 4. run-wide quality model: trigrams across the ORIGINAL piece boundaries, all-reduce, scaling
@@ -416,7 +453,8 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     mark("quality model");
     // ---- 5. tie-break across ranks: rounds of (all-gather counts -> prior, a few local sweeps) until nobody moves
     {
-      SH_RC(ctx, scalce_batch_tokenize_begin(b, s));
+      local([&] { SH_RC(ctx, scalce_batch_tokenize_begin(b, s)); });
+      if (W > 1) agree("tokenizer"); else if (local_err.rc) throw local_err;
       const uint32_t stride = nb1 + 1;
       u64 *d_mine = mem.alloc<u64>(stride), *d_all = mem.alloc<u64>((size_t)W * stride), *d_prior = mem.alloc<u64>(nb1);
       u64 moved = 1;
@@ -434,16 +472,22 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         bool any = false;
         for (int r = 0; r < W; r++) any = any || flags[r] != 0;
         if (round > 0 && !any) break;  // a whole round with current priors on every rank and no decision moved
+        for (int r = 0; r < W; r++)
+          if (flags[r] >= 2) {  // a rank's sweeps failed: its status came with the flag
+            if (r == rank && local_err.rc) throw local_err;
+            throw Fail{"rank " + std::to_string(r) + " failed (tie-break sweeps); see its message", (int)(flags[r] - 2)};
+          }
         moved = 0;
-        {
+        local([&] {
           int ch = 0;
           SH_RC(ctx, scalce_batch_tokenize_sweeps(b, reinterpret_cast<const uint64_t *>(d_prior), 4, &ch, s));
           res->sweeps += 4;
           if (ch) moved = 1;
-        }
+        });
+        if (local_err.rc) moved = 2 + (u64)local_err.rc;
         if (res->rounds > total_reads + 8) throw Fail{"tie resolution did not converge", SCALCE_ERR_HIP};
       }
-      SH_RC(ctx, scalce_batch_tokenize_end(b, s));
+      local([&] { SH_RC(ctx, scalce_batch_tokenize_end(b, s)); });  // (its status travels with the order stage's, below)
     }
     mark("tie-break");
     // ---- 6. order (the run's cuts inside this rank's rows are its chunks) and emit
@@ -451,10 +495,13 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       std::vector<uint64_t> starts(1, 0);
       for (u64 c : cuts_global)
         if (c > gn[rank] && c < gn[rank + 1]) starts.push_back(c - gn[rank]);
-      SH_RC(ctx, scalce_batch_set_chunks(b, starts.data(), (uint32_t)starts.size()));
-      SH_RC(ctx, scalce_batch_order(b, s));
-      SH_RC(ctx, scalce_batch_emit(b, s));
-      SH_RC(ctx, scalce_batch_set_chunks(b, nullptr, 0));
+      local([&] {
+        SH_RC(ctx, scalce_batch_set_chunks(b, starts.data(), (uint32_t)starts.size()));
+        SH_RC(ctx, scalce_batch_order(b, s));
+        SH_RC(ctx, scalce_batch_emit(b, s));
+        SH_RC(ctx, scalce_batch_set_chunks(b, nullptr, 0));
+      });
+      if (W > 1) agree("order and emit stages"); else if (local_err.rc) throw local_err;
     }
     mark("order + emit");
     // ---- 7. who holds how much of every bucket

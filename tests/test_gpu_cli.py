@@ -1,6 +1,7 @@
 """-m gpu: the `scalce` command line (C++ host over the C ABI) against the oracle's files, both directions."""
 import gzip
 import os
+import sys
 import subprocess
 
 import pytest
@@ -253,3 +254,97 @@ def test_cli_long_reads_two_byte_end_marker(tmp_path):
     run_cli("-d", "-o", tmp_path / "back", tmp_path / "hip_1.scalcen", "--patterns-bin", PBIN)
     O.orc_cli("decompress", PBIN, tmp_path / "orc_1.scalcen", tmp_path / "oback")
     assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()
+
+
+def test_cli_gpus_run_that_B_does_not_cut_goes_to_one_gpu(tmp_path, monkeypatch):
+    """A run shorter than one spill chunk has no chunk boundary for a rank boundary to sit on (compress.cpp:708-715): the
+    ranks find that out together, nothing is written, and the same command goes on with one GPU -- a warning, never an
+    (ERROR) -- to the archive the oracle writes."""
+    monkeypatch.setenv("SCALCE_COMM", "shm")
+    n, L = 20000, 100
+    b1, q1 = synth.reads_and_quals(n, L, seed=91, n_frac=0.003, dup_frac=0.1)
+    open(tmp_path / "in_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1))
+    r = run_cli("-c", "no", "--gpus", 2, "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)   # default -B 4G
+    assert "compressing on one GPU" in r.stderr and "(ERROR)" not in r.stderr, r.stderr[-600:]
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc")
+    for ext in "nrq":
+        assert open(tmp_path / f"orc_1.scalce{ext}", "rb").read() == open(tmp_path / f"hip_1.scalce{ext}", "rb").read(), ext
+
+
+def test_cli_gpus_failure_of_one_rank_ends_the_run(tmp_path, monkeypatch):
+    """A malformed record in ONE rank's byte range: that rank's status travels with the next exchange, every rank stops
+    with it, and the command returns 1 -- it once hung, the other ranks waiting in a collective for ever."""
+    monkeypatch.setenv("SCALCE_COMM", "shm")
+    n, L = 60000, 100
+    b1, q1 = synth.reads_and_quals(n, L, seed=92)
+    lines = synth.fastq_bytes_fast(b1, q1).split(b"\n")
+    lines[4 * 50000 + 1] = lines[4 * 50000 + 1][:-5]          # a short read, in the last rank's part of the file
+    open(tmp_path / "bad_1.fq", "wb").write(b"\n".join(lines))
+    r = subprocess.run([CLI, "-c", "no", "-B", "1M", "--gpus", "3", "-o", str(tmp_path / "o"), str(tmp_path / "bad_1.fq"),
+                        "--patterns-bin", PBIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "(ERROR)" in r.stderr, r.stderr[-600:]
+
+
+def test_cli_gpus_several_files_gzip_in_and_out(tmp_path, monkeypatch):
+    """--gpus with what the reference's one mode takes (compress.cpp:756-811): several input files, one of them gzipped,
+    a first file shorter than the quality sample, -c gz.  Against the same command on one GPU (pinned to the reference's
+    files by tests/test_ref_files.py::multi) and, where the reference binary is present, against the reference itself."""
+    import filecases as F
+    monkeypatch.setenv("SCALCE_COMM", "shm")
+    n, L = 45000, 100
+    b1, q1 = synth.reads_and_quals(n, L, seed=93, n_frac=0.004, dup_frac=0.1)
+    b2, q2 = synth.reads_and_quals(n, L, seed=94)
+    cuts = [0, 900, 30000, n]
+    names = []
+    for k in range(3):
+        for m, (bb, qq) in enumerate(((b1, q1), (b2, q2))):
+            text = b"".join(b"@p.%d/%d\n" % (i, m + 1) + bb[i].tobytes() + b"\n+\n" + qq[i].tobytes() + b"\n" for i in range(cuts[k], cuts[k + 1]))
+            fn = tmp_path / ("part%c_%d.fq" % (97 + k, m + 1))
+            if k == 1:
+                fn = tmp_path / ("part%c_%d.fq.gz" % (97 + k, m + 1))
+                text = gzip.compress(text, 1)
+            open(fn, "wb").write(text)
+        names.append(tmp_path / ("part%c_1.fq%s" % (97 + k, ".gz" if k == 1 else "")))
+    flags = ["-r", "-B", "1M", "-s", "5000", "-p", "30", "-c", "gz"]
+    run_cli(*flags, "--gpus", 3, "-t", tmp_path / "tmpd", "-o", tmp_path / "multi", *names, "--patterns-bin", PBIN)
+    run_cli(*flags, "-o", tmp_path / "one", *names, "--patterns-bin", PBIN)
+    have_ref = os.path.exists(F.REF_FULL)
+    if have_ref:
+        subprocess.run([F.REF_FULL, "compress", PBIN, ",".join(map(str, names)), str(tmp_path / "ref"), "-r", "-B", "1048576", "-s", "5000",
+                        "-p", "30", "-c", "gz", "-T", "1", "-t", str(tmp_path / "tmpr")], check=True, capture_output=True)
+    for m in (1, 2):
+        for ext in "nrq":
+            a = maybe_gunzip(tmp_path / f"multi_{m}.scalce{ext}")
+            assert a == maybe_gunzip(tmp_path / f"one_{m}.scalce{ext}"), f".scalce{ext} mate {m}: three ranks vs one GPU"
+            if have_ref:
+                assert a == maybe_gunzip(tmp_path / f"ref_{m}.scalce{ext}"), f".scalce{ext} mate {m}: three ranks vs the reference"
+    assert open(tmp_path / "multi_1.scalcer", "rb").read(2) == b"\x1f\x8b"
+    assert not list((tmp_path / "tmpd").glob("scalce_gpus_*")), "the plain copy of the input was left behind"
+
+
+def test_cli_gpus_over_rccl_when_there_are_two_gpus(tmp_path):
+    """The N > 1 data path over RCCL (ncclAllGather / AllReduce / Send / Recv between processes that own a GPU each): runs
+    wherever two GPUs are visible -- the driver's 8-GPU box -- and is skipped on a one-GPU box, where the same code runs
+    over the shared-memory transport in the tests above."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n, L = 200000, 100
+    b1, q1 = synth.reads_and_quals(n, L, seed=95, n_frac=0.003, dup_frac=0.1)
+    open(tmp_path / "in_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1))
+    env = dict(os.environ)
+    env.pop("SCALCE_COMM", None)
+    r = subprocess.run([CLI, "-c", "no", "-B", "4M", "--gpus", "2", "-o", str(tmp_path / "hip"), str(tmp_path / "in_1.fq"),
+                        "--patterns-bin", PBIN], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "GPUs: 2" in r.stderr, r.stderr[-800:]
+    O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc", "-B", str(4 << 20))
+    for ext in "nrq":
+        assert open(tmp_path / f"orc_1.scalce{ext}", "rb").read() == open(tmp_path / f"hip_1.scalce{ext}", "rb").read(), ext
+    # and the bench's sharded path at two ranks (torchrun, RCCL): one JSON line, positive throughput
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--reads", "2000000", "--cpu-sample", "0", "--no-e2e"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-1500:]
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
