@@ -168,8 +168,9 @@ int scalce_batch_tokenize_end(scalce_batch *b, void *stream);
  * not tokenized (record sizes depend on the core's length only). */
 int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint64_t *cuts_host, uint32_t cap, uint32_t *ncuts,
                             uint64_t *carry_out, void *stream);
-/* Byte offset, in the text of the piece ingested last, at which record `row` (0 .. rows of that piece) begins. */
-int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset);
+/* Byte offset, in the text of the piece ingested last, at which record `row` (0 .. rows of that piece) begins; runs on
+ * `stream`, behind the ingest of that piece. */
+int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset, void *stream);
 /* Spill-chunk boundaries given by the caller instead of the -B rule: starts[0] = 0 < starts[1] < ...;
  * records of chunk i precede those of chunk i+1 inside every bucket (merge order, compress.cpp:104-159).
  * A sharded run uses one chunk per shard. */
@@ -258,8 +259,8 @@ int scalce_memcpy_d2h(scalce_ctx *ctx, void *dst_host, const void *src_dev, uint
 int scalce_memcpy_h2d(scalce_ctx *ctx, void *dst_dev, const void *src_host, uint64_t nbytes);
 int scalce_memcpy_d2d(scalce_ctx *ctx, void *dst_dev, const void *src_dev, uint64_t nbytes, void *stream); /* async */
 /* diagnostics of the last run: tie reads, candidate events, fixed-point sweeps, spill chunks, records that
- * needed the second sort phase */
-int scalce_batch_stats(const scalce_batch *b, uint32_t out[5]);
+ * needed the second sort phase, 1 if the tie-break ended in the sequential fallback (tie_sequential_k) */
+int scalce_batch_stats(const scalce_batch *b, uint32_t out[6]);
 
 /* Device self-test of the arithmetic coder's closed-form step (multiply-high by reciprocal fractions, merged
  * renormalisation shift) against the literal loop of arithmetic.cpp:122-152 on `ncases` random and crafted

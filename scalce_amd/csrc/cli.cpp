@@ -497,7 +497,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   const double t2 = now();
   const uint64_t N = scalce_batch_reads(b);
   LOG("\tDone with file %s, %llu reads found\n", files[0].c_str(), (unsigned long long)N);
-  uint32_t st4[5] = {0, 0, 0, 0, 0};
+  uint32_t st4[6] = {0, 0, 0, 0, 0, 0};
   scalce_batch_stats(b, st4);
   // the arithmetic coder starts on its own stream; the read and name streams come down and are written beside it
   // (a run of up to 2048 blocks is one launch that takes as long as ONE block's serial chain, about 0.3 s)

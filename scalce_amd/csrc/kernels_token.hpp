@@ -422,6 +422,71 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
   }
 }
 
+// The bounded way out.  A sweep makes at least the earliest undecided tie read final, so ntie + 1 sweeps always suffice --
+// and on an adversarial input (two equally long cores alternating in every read, a 50x pile-up of one short sequence)
+// nothing better can be promised: O(ntie^2).  After a fixed number of sweeps the host therefore stops sweeping and lets ONE
+// wavefront decide the tie reads in input order, which is the reference's own loop (reads.cpp:413-429 with bin_size
+// cumulative, :246): count(b) = prior[b] + fixed reads of b in front of the read + tie reads that chose b so far.
+// The lanes stage the next 64 tie reads' candidates in LDS (bucket, prior + fixed_before), lane 0 walks them; the
+// running counters sit in LDS when the table has few enough buckets (15 601: yes; a million-core table: global memory).
+// ~0.1 us per tie read: 1 s for the 9 M tie reads of a 50 M-read shard, against 47 sweeps = 16 ms when sweeping works.
+struct TieSeqArgs {
+  u32 ntie, nb1;
+  const u32 *tie_off, *tie_ncand, *cand_bucket, *fixed_before;
+  const u64 *prior;      // may be null
+  u32 *choice;
+  u32 *tiecount;         // [nb1] zeroed; used when the counters do not fit LDS
+  u32 lds_counters;      // 1: counters in LDS
+};
+constexpr int TIESEQ_K = 6;  // candidates per tie read staged in LDS (more: read from memory on the spot)
+__global__ __launch_bounds__(64) void tie_sequential_k(TieSeqArgs a) {
+  extern __shared__ u32 dyn[];
+  __shared__ u32 sb[64][TIESEQ_K];
+  __shared__ u64 sc[64][TIESEQ_K];
+  __shared__ u32 sk[64], so[64];
+  const int lane = threadIdx.x;
+  u32 *cnt = a.lds_counters ? dyn : a.tiecount;
+  if (a.lds_counters) for (u32 i = lane; i < a.nb1; i += 64) dyn[i] = 0;
+  __syncthreads();
+  for (u32 base = 0; base < a.ntie; base += 64) {
+    const u32 t = base + lane;
+    if (t < a.ntie) {
+      const u32 off = a.tie_off[t], k = a.tie_ncand[t];
+      sk[lane] = k; so[lane] = off;
+      for (u32 j = 0; j < k && j < (u32)TIESEQ_K; j++) {
+        const u32 bk = a.cand_bucket[off + j];
+        sb[lane][j] = bk;
+        sc[lane][j] = (a.prior ? a.prior[bk] : 0ull) + (u64)a.fixed_before[off + j];
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      const u32 m = a.ntie - base < 64u ? a.ntie - base : 64u;
+      for (u32 i = 0; i < m; i++) {
+        const u32 k = sk[i], off = so[i];
+        u32 best = 0, bestb = 0;
+        u64 bestc = 0;
+        for (u32 j = 0; j < k; j++) {
+          u32 bk;
+          u64 c;
+          if (j < (u32)TIESEQ_K) { bk = sb[i][j]; c = sc[i][j]; }
+          else { bk = a.cand_bucket[off + j]; c = (a.prior ? a.prior[bk] : 0ull) + (u64)a.fixed_before[off + j]; }
+          c += cnt[bk];
+          if (j == 0 || c > bestc) { best = j; bestc = c; bestb = bk; }  // strict: the earlier candidate keeps the bucket
+        }
+        cnt[bestb]++;
+        a.choice[base + i] = best;
+      }
+    }
+    __syncthreads();
+  }
+}
+// `chosen` flags of the candidates' events from the decisions (the array is zero when this runs)
+__global__ __launch_bounds__(256) void chosen_from_choice_k(u32 ntie, const u32 *tie_off, const u32 *choice, const u32 *cand_place, u8 *chosen) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < ntie) chosen[cand_place[tie_off[t] + choice[t]]] = 1;
+}
+
 // cross-shard prior counts that moved since the last sweep wake up the reads of those buckets
 __global__ __launch_bounds__(256) void prior_dirty_k(u32 nb1, const u64 *prior, u64 *seen, u32 *dirty) {
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -316,6 +316,7 @@ struct scalce_batch {
   // host-side results
   u64 out_reads_bytes[2] = {0, 0}, out_names_bytes = 0, out_qual_bytes[2] = {0, 0};
   u32 ntie = 0, nev = 0, ntev = 0, ncand_cap = 0, jacobi_iters = 0, nchunks = 1, sweep_no = 0;
+  bool tie_fallback = false;  // the last tie-break ended in tie_sequential_k
   bool tok_open = false;
   int dirty_cur = 0;
   std::vector<uint64_t> explicit_chunks;  // spill-chunk starts given by the caller (sharded runs), else -B rule
@@ -839,6 +840,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   const u64 N = b->tok_n;
   const u8 *packed0 = b->packed[0].as<u8>() + b->tok_base * (u64)b->stride[0];
   b->jacobi_iters = 0;
+  b->tie_fallback = false;
   b->sweep_no = 0;
   b->tok_open = true;
   const u32 nb1 = (u32)c->A.n_buckets + 1;  // buckets incl. root
@@ -1030,6 +1032,46 @@ extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_pr
   return SCALCE_OK;
 }
 
+// The tie reads decided in input order by one wavefront (tie_sequential_k): what scalce_batch_tokenize falls back to when
+// the sweeps have not reached their fixed point after tie_max_sweeps() of them.  Leaves choice / chosen / G / counts as
+// the converged sweeps would.
+static u32 tie_max_sweeps() {
+  const char *e = getenv("SCALCE_TIE_MAX_SWEEPS");  // (tests lower it to drive the fallback on ordinary input)
+  const int v = e ? atoi(e) : 256;
+  return (u32)(v < 1 ? 1 : v);
+}
+static int tokenize_sequential(scalce_batch *b, const uint64_t *d_prior, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie;
+  if (b->tok_base) {
+    if (d_prior) {
+      LAUNCH(add_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), b->counts_total.as<u64>(), b->prior_buf.as<u64>());
+      d_prior = b->prior_buf.as<uint64_t>();
+    } else {
+      d_prior = b->counts_total.as<uint64_t>();
+    }
+  }
+  ENSURE(b, b->Gseg, sizeof(u32) * (nb1 + 2));
+  TieSeqArgs a;
+  a.ntie = ntie; a.nb1 = nb1; a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
+  a.fixed_before = b->cand_fixed.as<u32>(); a.prior = reinterpret_cast<const u64 *>(d_prior); a.choice = b->choice.as<u32>();
+  a.tiecount = b->Gseg.as<u32>();
+  const size_t lds = (size_t)nb1 * 4;
+  a.lds_counters = lds <= 100 * 1024 ? 1u : 0u;
+  if (!a.lds_counters) HIP_TRY(c, hipMemsetAsync(a.tiecount, 0, sizeof(u32) * nb1, s));
+  if (a.lds_counters && lds > 48 * 1024)
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(tie_sequential_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  LAUNCH(tie_sequential_k, 1, 64, a.lds_counters ? lds : 0, s, a);
+  HIP_TRY(c, hipMemsetAsync(b->chosen.p, 0, b->nev + 64, s));
+  LAUNCH(chosen_from_choice_k, cdiv(ntie, 256), 256, 0, s, ntie, b->tie_off.as<u32>(), b->choice.as<u32>(), b->cand_place.as<u32>(), b->chosen.as<u8>());
+  u32 *d0 = b->dirty.as<u32>();
+  HIP_TRY(c, hipMemsetAsync(d0, 0, sizeof(u32) * nb1, s));  // every bucket: new prefix sums and counts
+  LAUNCH(seg_rescan_k, nb1, 256, 0, s, nb1, b->seg.as<u32>() + (nb1 + 2), d0, b->chosen.as<u8>(), b->G.as<u32>(), b->seg.as<u32>() + 2 * (nb1 + 2),
+         b->counts.as<u64>());
+  b->tie_fallback = true;
+  return SCALCE_OK;
+}
+
 // Several sweeps against the same prior counts with ONE look at their flags (a sweep behind the local fixed point changes
 // nothing and costs next to nothing; a host round trip per sweep leaves the stream idle).  *changed = 1 if any moved.
 extern "C" int scalce_batch_tokenize_sweeps(scalce_batch *b, const uint64_t *d_prior, int nsweeps, int *changed, void *stream) {
@@ -1091,7 +1133,10 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
       b->jacobi_iters++;  // sweeps up to and including the first one that moved nothing, as one at a time would count
       if (!ch[i]) done = true;
     }
-    if (b->jacobi_iters > b->ntie + 1 + SWEEPS_PER_LOOK) { set_err(b->ctx, "tie resolution did not converge"); return SCALCE_ERR_HIP; }
+    if (!done && b->jacobi_iters >= tie_max_sweeps()) {  // worst cases are quadratic in sweeps: decide in input order instead
+      if ((rc = tokenize_sequential(b, d_prior, s))) return rc;
+      done = true;
+    }
   }
   return scalce_batch_tokenize_end(b, stream);
 }
@@ -1136,12 +1181,16 @@ extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint6
   u32 n = 0;
   { int rc = read_u32(b, b->d_small + 8, &n, 1, s); if (rc) return rc; }
   { u64 co = 0; int rc = read_u64(b, b->d_small64 + 7, &co, 1, s); if (rc) return rc; *carry_out = co; }
-  if (n) HIP_TRY(c, hipMemcpy(cuts_host, b->chunk_start.p, sizeof(u64) * n, hipMemcpyDeviceToHost));
+  if (n) {  // (on the caller's stream: a blocking copy would go through the null stream, which does not wait for `s`)
+    HIP_TRY(c, hipMemcpyAsync(cuts_host, b->chunk_start.p, sizeof(u64) * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+  }
   *ncuts = n;
   return SCALCE_OK;
 }
 
-extern "C" int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset) {
+extern "C" int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
   if (!b || !offset || mate < 0 || mate >= b->nm || row > b->NP) return SCALCE_ERR_ARG;
   *offset = 0;
   if (!row) return SCALCE_OK;
@@ -1150,10 +1199,12 @@ extern "C" int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row,
   const u64 nbytes = b->text_bytes[mate];
   const u32 ntiles = cdiv(nbytes, IDX_TILE);
   if (!ntiles || !b->piece_text[mate]) { set_err(b->ctx, "no piece ingested"); return SCALCE_ERR_ARG; }
-  u64 *d_out = b->d_small64 + 7;
-  LAUNCH(line_offset_k, 1, 64, 0, nullptr, b->piece_text[mate], nbytes, b->tile[mate].as<u64>(), ntiles, (u64)(4 * row), d_out);
+  // on the caller's stream, behind the ingest that produced the tile counts, and in a word of its own (slot 7 belongs to
+  // scalce_batch_chunk_plan's carry)
+  u64 *d_out = b->d_small64 + 10;
+  LAUNCH(line_offset_k, 1, 64, 0, s, b->piece_text[mate], nbytes, b->tile[mate].as<u64>(), ntiles, (u64)(4 * row), d_out);
   u64 v = 0;
-  HIP_TRY(b->ctx, hipMemcpy(&v, d_out, sizeof(u64), hipMemcpyDeviceToHost));
+  { int rc = read_u64(b, d_out, &v, 1, s); if (rc) return rc; }
   *offset = v;
   return SCALCE_OK;
 }
@@ -1977,10 +2028,11 @@ extern "C" int scalce_memcpy_d2d(scalce_ctx *c, void *dst, const void *src, uint
   HIP_TRY(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SCALCE_OK;
 }
-extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[5]) {
+extern "C" int scalce_batch_stats(const scalce_batch *b, uint32_t out[6]) {
   if (!b || !out) return SCALCE_ERR_ARG;
   out[0] = b->ntie; out[1] = b->nev; out[2] = b->jacobi_iters; out[3] = b->nchunks;
   out[4] = b->order_run_members;
+  out[5] = b->tie_fallback ? 1u : 0u;
   return SCALCE_OK;
 }
 

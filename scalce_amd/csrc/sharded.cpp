@@ -369,7 +369,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         for (int d = 0; d <= W; d++) {
           const u64 row = clampu(d < W ? gn[d] : gn[W], g[rank], g[rank + 1]) - g[rank];
           uint64_t off = nbytes[m];
-          if (row < N0) local([&] { SH_RC(ctx, scalce_batch_text_offset(b, m, row, &off)); });
+          if (row < N0) local([&] { SH_RC(ctx, scalce_batch_text_offset(b, m, row, &off, s)); });
           start[d] = off;
         }
         start[0] = 0;  // (rows in front of gn[0] = 0 do not exist)

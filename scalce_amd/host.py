@@ -123,7 +123,7 @@ def lib():
     L.scalce_batch_entropy_stream.argtypes = [vp, i32, vp, vp, u64, vp]
     L.scalce_ac_scale.argtypes = [vp, vp, C.c_uint32, vp, vp]
     L.scalce_batch_chunk_plan.argtypes = [vp, u64, C.POINTER(u64), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(u64), vp]
-    L.scalce_batch_text_offset.argtypes = [vp, i32, u64, C.POINTER(u64)]
+    L.scalce_batch_text_offset.argtypes = [vp, i32, u64, C.POINTER(u64), vp]
     L.scalce_comm_unique_id.argtypes = [C.c_char_p]
     L.scalce_comm_create_rccl.argtypes = [i32, i32, i32, C.c_char_p, C.POINTER(vp)]
     L.scalce_comm_create_shm.argtypes = [i32, i32, i32, C.c_char_p, u64, C.POINTER(vp)]
@@ -496,9 +496,9 @@ class Batch:
         return self.ctx.to_host(p, n, dtype)
 
     def stats(self):
-        a = (C.c_uint32 * 5)()
+        a = (C.c_uint32 * 6)()
         self._check(self.L.scalce_batch_stats(self.h, a))
-        return dict(tie_reads=a[0], events=a[1], jacobi_iters=a[2], chunks=a[3], order_run_members=a[4])
+        return dict(tie_reads=a[0], events=a[1], jacobi_iters=a[2], chunks=a[3], order_run_members=a[4], tie_fallback=a[5])
 
     def stage_reset(self, enable=True):
         self.L.scalce_batch_stage_reset(self.h, int(enable))
