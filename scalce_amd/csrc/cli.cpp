@@ -33,6 +33,7 @@
 #include <csignal>
 
 #include "../../include/scalce_hip.h"
+#include "pargz.hpp"
 
 static const int EXIT_UNCUT = 3;  // a rank's exit status: -B does not cut the run (scalce_sharded_compress: SCALCE_ERR_UNCUT)
 
@@ -95,21 +96,35 @@ static const char *HELP_TEXT =
     "core table: --patterns-bin FILE or $SCALCE_PATTERNS or patterns.bin next to the executable\n";
 
 // ---- small I/O helpers ------------------------------------------------------------------------------
-static std::vector<uint8_t> read_maybe_gz(const std::string &path) {  // IO_GZIP reader (compress.cpp:756)
-  gzFile f = gzopen(path.c_str(), "rb");
-  if (!f) FAIL("Cannot read file %s\n", path.c_str());
-  gzbuffer(f, 1 << 20);
+static int g_threads_gz();
+static std::vector<uint8_t> read_maybe_gz(const std::string &path) {  // IO_GZIP reader (compress.cpp:756); plain files pass through
+  {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) FAIL("Cannot read file %s\n", path.c_str());
+    uint8_t mg[2] = {0, 0};
+    const bool gz = ::pread(fd, mg, 2, 0) == 2 && mg[0] == 0x1F && mg[1] == 0x8B;
+    std::vector<uint8_t> out;
+    if (!gz) {
+      struct stat st;
+      if (fstat(fd, &st) != 0) FAIL("Cannot read file %s\n", path.c_str());
+      out.resize((size_t)st.st_size);
+      size_t done = 0;
+      while (done < out.size()) { const ssize_t k = ::pread(fd, out.data() + done, out.size() - done, (off_t)done); if (k <= 0) FAIL("Read error on %s\n", path.c_str()); done += (size_t)k; }
+      ::close(fd);
+      return out;
+    }
+    ::close(fd);
+  }
+  scalce_host::ParGz z;  // members inflated by several threads (our own -c gz containers are 4 MiB members)
+  if (!z.open(path, g_threads_gz())) FAIL("Cannot read file %s\n", path.c_str());
   std::vector<uint8_t> out;
-  struct stat st;
-  if (stat(path.c_str(), &st) == 0) out.reserve((size_t)st.st_size + 64);
-  std::vector<uint8_t> chunk(8 << 20);
+  std::vector<uint8_t> chunk(64u << 20);
   for (;;) {
-    int k = gzread(f, chunk.data(), (unsigned)chunk.size());
+    const int64_t k = z.read(chunk.data(), chunk.size());
     if (k < 0) FAIL("Read error on %s\n", path.c_str());
     if (k == 0) break;
     out.insert(out.end(), chunk.begin(), chunk.begin() + k);
   }
-  gzclose(f);
   return out;
 }
 static int g_threads_io();
@@ -157,6 +172,7 @@ static bool second_file(const std::string &p, std::string &out) {  // get_second
 // the GPU, single-threaded deflate of .scalcer/.scalcen is what the wall clock of a run is made of).
 static int g_threads = 1;
 static int g_threads_io() { return std::max(1, std::min(g_threads, 8)); }
+static int g_threads_gz() { return std::max(1, std::min(g_threads, 32)); }
 struct OutFile {
   bool gz = false;
   FILE *f = nullptr;
@@ -281,7 +297,10 @@ struct MateSource {
   std::vector<std::string> files;
   size_t cur = 0;
   int fd = -1;
-  gzFile gz = nullptr;
+  scalce_host::ParGz pgz;     // gzip input: members inflated on several threads (pargz.hpp)
+  bool gz = false;
+  int gz_threads = 0;         // 0: g_threads (two mates read at once: the paired reader halves it)
+  uint64_t gz_parallel_windows = 0, gz_serial_bytes = 0;
   std::vector<uint8_t> peek;  // bytes read ahead for the quality sample, served first
   size_t peek_pos = 0;
   bool all_plain = true;
@@ -294,10 +313,10 @@ struct MateSource {
       const ssize_t k = ::pread(fd, mg, 2, 0);
       if (k == 2 && mg[0] == 0x1F && mg[1] == 0x8B) {
         all_plain = false;
-        gz = gzdopen(fd, "rb");
-        if (!gz) FAIL("Cannot read file %s\n", path.c_str());
-        gzbuffer(gz, 1 << 20);
+        ::close(fd);
         fd = -1;
+        if (!pgz.open(path, gz_threads > 0 ? gz_threads : std::max(1, g_threads))) FAIL("Cannot read file %s\n", path.c_str());
+        gz = true;
       } else {
 #ifdef POSIX_FADV_SEQUENTIAL
         posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
@@ -317,11 +336,11 @@ struct MateSource {
         fpos = 0;
       }
       int64_t k;
-      if (gz) k = gzread(gz, dst, (unsigned)std::min<uint64_t>(cap, 1u << 30));
+      if (gz) k = pgz.read(dst, cap);
       else k = read_plain(static_cast<uint8_t *>(dst), cap);
       if (k < 0) return -1;
       if (k > 0) return k;
-      if (gz) { gzclose(gz); gz = nullptr; } else { ::close(fd); fd = -1; }
+      if (gz) { gz_parallel_windows += pgz.parallel_windows; gz_serial_bytes += pgz.serial_bytes; pgz.close(); gz = false; } else { ::close(fd); fd = -1; }
     }
   }
   // A big request on a plain file is cut into slices read by several threads at once (pread): one thread copying out

@@ -168,3 +168,65 @@ def test_fastq_text_bytes_matches_the_text_it_sizes():
         lib = b"run_7"
         want = sum(len(b"@%s.%d\n" % (lib, i)) + rl + 3 + rl + 1 for i in range(n))
         assert L.scalce_fastq_text_bytes(rl, n, 0, lib) == want
+
+
+# ---------------------------------------------------------------- parallel gzip reader (scalce_amd/csrc/pargz.hpp)
+
+def _bgzf(data, block=60000):
+    """BGZF as bgzip writes it: members of <= 64 KiB with the 'BC' extra field that holds the member's size - 1"""
+    import struct
+    import zlib
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]     # (the last, empty member is BGZF's end-of-file marker)
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        size = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, size - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("kind", ["one_member", "many_members", "bgzf", "gz_inside_stored_block", "tiny", "empty_members"])
+def test_parallel_gzip_reader(kind, tmp_path):
+    """Every kind of gzip file through ParGz on 1, 3 and 16 threads equals Python's gzip: one member (streams through one
+    z_stream), many members (threads start at verified member starts), BGZF (the chain of BC fields is walked), a gzip
+    file stored verbatim inside another member (a member start that is NOT one: the chain check drops it), members of
+    zero bytes.  A cut file is an error, not a short read."""
+    import gzip
+    import subprocess
+    import zlib
+    cat = os.path.join(ROOT, "scalce_amd", "bin", "pargz_cat")
+    if not os.path.exists(cat):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "scalce_amd", "csrc"), "../bin/pargz_cat"], check=True)
+    rng = np.random.default_rng(5)
+    text = np.frombuffer(b"ACGTN\n@+IFHD0123", dtype=np.uint8)[rng.integers(0, 16, size=6_000_000)].tobytes()
+    if kind == "one_member":
+        data = gzip.compress(text, 6)
+    elif kind == "many_members":
+        data = b"".join(gzip.compress(text[a:a + 300_000], 1 + (a // 300_000) % 9) for a in range(0, len(text), 300_000))
+    elif kind == "bgzf":
+        data = _bgzf(text)
+    elif kind == "gz_inside_stored_block":
+        inner = gzip.compress(text[:2_000_000], 6)          # looks like a member wherever it lies
+        c = zlib.compressobj(0, zlib.DEFLATED, 31)          # level 0: stored blocks, the inner file verbatim
+        data = gzip.compress(text[2_000_000:3_000_000]) + c.compress(inner * 3) + c.flush() + gzip.compress(text[3_000_000:])
+        text = text[2_000_000:3_000_000] + inner * 3 + text[3_000_000:]
+    elif kind == "tiny":
+        text = b"@r\nACGT\n+\nIIII\n"
+        data = gzip.compress(text)
+    else:
+        data = gzip.compress(b"") + gzip.compress(text[:100]) + gzip.compress(b"") * 3 + gzip.compress(text[100:5000]) + gzip.compress(b"")
+        text = text[:5000]
+    assert gzip.decompress(data) == text
+    path = tmp_path / "in.gz"
+    open(path, "wb").write(data)
+    for threads in (1, 3, 16):
+        r = subprocess.run([cat, str(path), str(threads)], capture_output=True)
+        assert r.returncode == 0 and r.stdout == text, f"{kind}, {threads} threads: {len(r.stdout)} of {len(text)} bytes, {r.stderr[-200:]}"
+    if kind in ("many_members", "bgzf"):
+        assert b"windows 1" in r.stderr and b"serial_bytes 0" in r.stderr, r.stderr   # it did go parallel
+    if kind != "tiny":
+        open(path, "wb").write(data[:-9])
+        r = subprocess.run([cat, str(path), "8"], capture_output=True)
+        assert r.returncode == 1
