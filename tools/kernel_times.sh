@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O && mkdir -p $O
 for kv in "$@"; do export "$kv"; done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 4 --warmup 1 --group 1 --inflight 1 --cpu-sample 0 --no-e2e > $O/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 4 --warmup 1 --group 1 --inflight 1 --cpu-sample 0 --no-e2e --no-verify > $O/stats.log 2>&1
 cd $R
 python3 tools/prof_summary.py stats $O/stats $R/gpurun_out/${TAG}_alone_kernel_stats.csv
 rm -rf $O/stats

@@ -13,6 +13,6 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o w -- python3 $R/bench.py --steps 3 --warmup 3 --cpu-sample 0 --no-e2e --no-verify > $O/write.log 2>&1
 cd $R
 python3 tools/prof_summary.py stats $O/stats $R/gpurun_out/${TAG}_bench50m_kernel_stats.csv
-python3 tools/prof_summary.py pmc $O/fetch $O/write $R/gpurun_out/${TAG}_bench50m_pmc_fetch_write.json 10
+python3 tools/prof_summary.py pmc $O/fetch $O/write $R/gpurun_out/${TAG}_bench50m_pmc_fetch_write.json
 tail -1 $O/stats.log | cut -c1-300
 rm -rf $O/stats $O/fetch $O/write   # the raw traces are large; the summaries are what travels back
