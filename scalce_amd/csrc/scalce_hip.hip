@@ -2115,13 +2115,20 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
     ca.W = W;
     memset(ca.rank, 0xFF, sizeof ca.rank);
     for (u32 r = 0; r < W; r++) { ca.hot[r] = (u8)order[r]; ca.rank[order[r]] = (u8)r; }
-    HIP_TRY(c, hipMalloc(&d_rows, sizeof(uint2) * 6400 * ca.S1));
+    HIP_TRY(c, hipMalloc(&d_rows, sizeof(uint2) * (6400 * ca.S1 + 64)));  // (+ 64: ac_decode_fast_k reads a row with all lanes)
+    HIP_TRY(c, hipMemsetAsync(d_rows + 6400 * (size_t)ca.S1, 0, sizeof(uint2) * 64, s));
     LAUNCH(ac_dec_rows_k, cdiv(6400u * ca.S1, 256), 256, 0, s, d_tab, smin, ca.S1, d_rows);
     ca.rows = d_rows;
     // Waves of a workgroup share the LDS cache of hot rows (one workgroup per CU): two chains per workgroup keep the
     // latency of a block lowest; from 512 blocks on, eight per workgroup -- two chains per SIMD interleave their issue
     // slots -- put four times as many blocks in flight.
-    if (nblk <= 512) LAUNCH(ac_decode_cached_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+    // symbol 79 in the span = rows with a "last symbol of its context" marker: the kernel with the second ballot
+    const bool fast = smax < AC_D - 1 && !getenv("SCALCE_AC_DECODE_OLD");
+    if (fast) {
+      if (nblk <= 512) LAUNCH(ac_decode_fast_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+      else if (nblk <= 1024) LAUNCH(ac_decode_fast_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
+      else LAUNCH(ac_decode_fast_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
+    } else if (nblk <= 512) LAUNCH(ac_decode_cached_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
     else if (nblk <= 1024) LAUNCH(ac_decode_cached_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
     else LAUNCH(ac_decode_cached_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
   } else {
