@@ -121,13 +121,19 @@ def main():
     # four shards per coder launch, two launches side by side, twelve shards in flight (234 GB): a launch of the
     # one-block-per-lane coder takes ~0.56 s whatever it holds and 60 CUs for four shards, so the pipeline needs two of
     # them running beside the front stages of the next four shards (profiles/README.md, r03 rows)
+    # A sharded run (several ranks, ONE archive) also holds, per shard in flight, its block range of the run-wide quality
+    # stream and the all-to-all buffers: 246 GB at six in flight (tools/mem_probe.sh).  It keeps round 2's shape -- three
+    # shards per launch, six in flight, one coder stream, eight blocks per chain wave: with one stream a launch of the
+    # one-block-per-lane coder (0.6 s whatever it holds) would be all there is to a step.
     G = args.group
     if G is None:
-        G = 4
+        G = 3 if sharded else 4
     G = max(1, G)
-    D = max(1, args.inflight) if args.inflight is not None else 3 * G
+    D = max(1, args.inflight) if args.inflight is not None else (2 * G if sharded else 3 * G)
     if G > 1:
         D = max(D, 2 * G)
+    if sharded and "SCALCE_AC_BLOCKS_PER_WG" not in os.environ and D < 3 * G:
+        os.environ["SCALCE_AC_BLOCKS_PER_WG"] = "8"
     # -B: the reference's default, 4 GiB of record bytes per spill chunk (main.cpp:68) -- 50 M reads of 100 bp are 3 chunks
     B = int(os.environ.get("SCALCE_BENCH_BUCKET_SET", str(4 << 30)))
     # the shards in flight share ONE set of front-stage buffers (rows, tokens, events, sort scratch: dead once a shard is
@@ -154,7 +160,7 @@ def main():
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
     pipe = ShardPipeline(batches, group=G, sharded=sharded, trace=mark if trace else None,
-                         coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "2" if G > 1 else "1")))
+                         coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "2" if (G > 1 and D >= 3 * G) else "1")))
     front = pipe.front
 
     def run(k):
