@@ -138,9 +138,19 @@ def main():
     B = int(os.environ.get("SCALCE_BENCH_BUCKET_SET", str(4 << 30)))
     # the shards in flight share ONE set of front-stage buffers (rows, tokens, events, sort scratch: dead once a shard is
     # emitted, and front stages run one at a time on the front stream): 15 GB instead of 35 GB of HBM per shard in flight
-    shared_ws = None if os.environ.get("SCALCE_BENCH_OWN_WORKSPACES") else host.Workspace(ctx)
-    batches = [host.Batch(ctx, L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B,
-                          workspace=shared_ws) for _ in range(D)]
+    # `fronts` host threads, each with a front stream, a context, a set of front-stage buffers and D / fronts of the batches
+    # of its own: the front stages are ~250 launches per shard with a dozen read-backs between them, and many of the
+    # launches (late tie-break sweeps, radix passes over a few thousand keys) leave most of the chip idle -- a second
+    # shard's front stages fill those holes
+    F = 1 if sharded else max(1, int(os.environ.get("SCALCE_BENCH_FRONTS", "1")))
+    if F > 1:
+        assert G > 1 and D % F == 0 and D // F >= 2 * G, "fronts: D / fronts >= 2 * group"
+    ctxs = [ctx] + [host.Context(local, patterns_bin=blob) for _ in range(F - 1)]
+    batches = []
+    for f in range(F):
+        ws = None if os.environ.get("SCALCE_BENCH_OWN_WORKSPACES") else host.Workspace(ctxs[f])
+        batches += [host.Batch(ctxs[f], L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B,
+                               workspace=ws) for _ in range(D // F)]
     batch = batches[0]
     state = {}
 
@@ -159,11 +169,34 @@ def main():
 
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
-    pipe = ShardPipeline(batches, group=G, sharded=sharded, trace=mark if trace else None,
-                         coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "2" if (G > 1 and D >= 3 * G) else "1")))
+    DF = D // F
+    pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
+                           coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "2" if (G > 1 and DF >= 3 * G) else "1")))
+             for f in range(F)]
+    pipe = pipes[0]
     front = pipe.front
 
     def run(k):
+        if F == 1:
+            return run_on(pipe, k)
+        import threading
+        errs = []
+
+        def body(f):
+            try:
+                torch.cuda.set_device(local)
+                run_on(pipes[f], len(range(f, k, F)))
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
+        ts = [threading.Thread(target=body, args=(f,)) for f in range(F)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    def run_on(pipe, k):
         for j in range(k):
             slot, b = pipe.acquire()
             mark(f"shard {j}: front (slot {slot})")
@@ -219,10 +252,10 @@ def main():
     if rank == 0 and not sharded and not args.no_verify:
         try:
             from scalce_amd import verify
-            last = batches[(pipe._next - 1) % D]            # the batch that holds the last timed shard
+            last = pipe.batches[(pipe._next - 1) % DF]      # the batch that holds the last timed shard (of the first front)
             tv0 = time.perf_counter()
             want = verify.record_digest(text)
-            back = verify.decode_shard(ctx, last, L, off, dev)
+            back = verify.decode_shard(last.ctx, last, L, off, dev)
             got = verify.record_digest(back)
             parity["full_shard"] = {"ok": bool(got == want and want[0] == n), "records": got[0],
                                     "what": "last timed shard: archive streams -> scalce_ac_decode + scalce_fastq_records on the "
@@ -242,7 +275,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_e2e:
         for b in batches:   # the CLI is a process of its own and needs the card's memory
             b.close()
-        del batches[:], pipe
+        del batches[:], pipe, pipes[:]
         try:
             e2e = end_to_end(text, nbytes)
         except Exception as ex:  # noqa: BLE001 - a side leg must not take the measured line with it
@@ -315,7 +348,7 @@ def main():
                        "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if not sharded else f": read ranges per rank, ONE archive; run-wide -B chunks / tie-break / quality model / 10 MiB blocks over {comm.world} rank(s) of " + ("shared memory (rehearsal)" if os.environ.get("SCALCE_COMM") == "shm" else "RCCL (all-gather, all-reduce, send/recv)")),
                        "bucket_set_size": B, "spill_chunks": stats["chunks"],
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
-                       "shards_in_flight": D, "shards_per_coder_launch": G, "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
+                       "shards_in_flight": D, "shards_per_coder_launch": G, "front_threads": F, "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
             # achieved = algorithmic bytes of a step (the FASTQ record read once + the three archive streams
             # written once: 308 B per read) / ms_per_step, against the HBM peak.  `kernel` = the dominant kernel on its own:
             # algorithmic bytes of a launch (symbols in + coded bytes out) / its HIP-event time, its counter traffic, and the

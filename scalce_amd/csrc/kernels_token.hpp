@@ -151,6 +151,85 @@ __global__ __launch_bounds__(TOK_THREADS) void tokenize_kmer_k(TokArgs a) {
   a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
 }
 
+// tokenize_kmer_k spends its time WAITING: the lanes of a wave diverge over its four ways to a transition (global row,
+// 8-mer bit table, rank, 7-mer table) and the compiler walks them one after the other, each behind its own s_waitcnt,
+// with the output word of the new state (another global gather) behind that -- ~1200 cycles per base per wave, whatever
+// the lanes do, and 24 waves per CU to hide them.  Here every lane issues ALL lookups of a base at once -- the table
+// lookups do not depend on the state, only the choice between them does --, there is ONE wait per base, and the output
+// word of the state reached is consumed a base later (it is not needed to go on).  The global loads are inline asm so
+// that the wait can stand where it belongs (the compiler's own bookkeeping drains the queue at every loop back-edge).
+// 1024 threads per workgroup: two workgroups = the CU's 32 waves share two copies of the tables.
+constexpr int TOKP_THREADS = 1024;
+__device__ __forceinline__ u32 tokp_load(const u32 *p) {
+  u32 v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void tokp_wait(u32 &x, u32 &y) {  // both loads have landed (and the compiler may not look at them earlier)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(x), "+v"(y)::"memory");
+}
+__global__ __launch_bounds__(TOKP_THREADS) void tokenize_kmer_pipe_k(TokArgs a) {
+  __shared__ u32 tab[KMER_WORDS];
+  for (u32 i = threadIdx.x; i < KMER_WORDS; i += TOKP_THREADS) tab[i] = a.kmer[i];
+  __syncthreads();
+  const u16 *t7 = reinterpret_cast<const u16 *>(tab);
+  const u32 *bits8 = tab + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
+  const u16 *rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+  const u64 r = (u64)blockIdx.x * TOKP_THREADS + threadIdx.x;
+  if (r >= a.nrec) return;
+  const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
+  const u32 *next = reinterpret_cast<const u32 *>(a.next);
+  const u32 id8 = a.id8_first;
+  u32 state = 0, best_lv = 0, best_b = a.root_bucket, best_pos = 0, hits = 0, tie = 0, code = 0;
+  u32 pend = 0, pend_pos = 0, pend_info = 0;
+  auto settle = [&]() {  // the output of the state reached a base ago
+    if (pend) {
+      const u32 lv = pend_info >> kLevelShiftD, b = pend_info & kBucketMaskD;
+      if (lv > best_lv) {
+        best_lv = lv; best_b = b; best_pos = pend_pos; hits = 1; tie = 0;
+      } else if (lv == best_lv) {
+        hits++;
+        if (b != best_b) tie = 1;
+      }
+    }
+  };
+  const int nw = (a.L + 15) >> 4;
+  u32 word = tokp_load(row);
+  tokp_wait(word, pend_info);
+  for (int w = 0; w < nw; w++) {
+    u32 word_next = 0;  // (asm as well: a load the compiler knows of makes it drain the queue at the head of every base)
+    if (w + 1 < nw) word_next = tokp_load(row + w + 1);
+    const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
+    for (int k = 0; k < cnt; k++) {
+      const int pos = 16 * w + k;
+      const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
+      code = ((code << 2) | c) & 0xFFFFu;  // the last 8 bases, the oldest one in the top bits
+      const bool deep = pos < 7 || state >= id8;
+      u32 tg = 0;
+      if (deep) tg = tokp_load(next + ((u64)state * 4 + c));
+      const u32 i5 = code >> 5, bit = code & 31u;
+      const u32 wd = bits8[i5], ob = out8[i5], rk = rank8[i5], e = t7[code & 0x3FFFu];
+      tokp_wait(tg, pend_info);
+      settle();
+      const u32 t8 = (id8 + rk + (u32)__popc(wd & ((1u << bit) - 1u))) | (((ob >> bit) & 1u) << 31);
+      const u32 t7v = (e & 0x7FFFu) | ((e >> 15) << 31);
+      const u32 tl = ((wd >> bit) & 1u) ? t8 : t7v;
+      const u32 t = deep ? tg : tl;
+      state = t & 0x7FFFFFFFu;
+      pend = t >> 31;
+      pend_pos = (u32)pos;
+      if (pend) pend_info = tokp_load(a.outinfo + state);
+    }
+    tokp_wait(word_next, pend_info);
+    word = word_next;
+  }
+  u32 none = 0;
+  tokp_wait(pend_info, none);
+  settle();
+  a.tok_bucket[r] = best_b;
+  a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
+}
+
 // second walk, tie reads only: the distinct cores of maximal length in order of first appearance
 struct TieArgs {
   const uint4 *next;
@@ -420,6 +499,150 @@ __global__ __launch_bounds__(256) void jacobi_k(JacobiArgs a) {
     }
     a.changed[0] = 1;  // plain store: every writer stores the same value
   }
+}
+
+// ---- the tie-break in windows ------------------------------------------------------------------------------------------
+// What the sweeps above cost is not the number of sweeps but what each one looks at: a decision becomes final once every
+// earlier decision in its candidate buckets is, so the settled prefix of the input grows by a slice per sweep (1/48 of a
+// 50 M-read shard) while every sweep re-evaluates ALL tie reads behind it -- 48 sweeps x 4.5 M evaluations on average, and a
+// rescan of the 20 M candidate events' prefix sums each time.  Here the tie reads are taken W at a time in input order:
+// the sweeps of a window only evaluate its W reads (everything in front is final, nothing behind is looked at), and only
+// the window's own events need new prefix sums.  For that the candidate events are laid out window by window, inside a
+// window bucket by bucket in input order ("cell" = window x bucket; the cells of a bucket are consecutive slices of its
+// segment of the bucket-sorted events, so a candidate's place is its old place plus one offset per cell).  The `chosen`
+// flags are a bitmap over that layout with a count in front of every 64-bit word (P64): reads of a bucket in front of a
+// candidate = earlier shards + fixed reads + choices of earlier windows (base) + rank(place) - rank(first place of the
+// cell).  A sweep is two launches: tie_window_sweep_k (one thread per tie read of the window) and tie_window_tail_k (one
+// workgroup: new counts for the window's few thousand words, or -- nothing moved -- the window's choices folded into
+// `base` and on to the next window).  Which window a launch works on is device state: the host enqueues sweeps in batches
+// and looks at the state once per batch.  Same fixed point as the global sweeps, reached window by window.
+struct TieWinState { u32 window, changed, finished, sweeps; };
+constexpr u32 TW_NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ u32 tw_rank(const u32 *P64, const u64 *bits, u32 e) {  // chosen flags in front of place e
+  const u32 w = e >> 6;
+  return P64[w] + (u32)__popcll(bits[w] & ((1ull << (e & 63u)) - 1ull));
+}
+// Cells.  The candidates of a bucket stand in input order in the bucket-sorted layout, so the candidates of one cell are
+// consecutive there: every candidate writes its cell at its place (tw_key_k), one pass over the places finds where cells
+// begin and end (tw_heads_k), a scan of the sizes gives the window layout (no atomics: 20 M of them on a few thousand hot
+// words took 1.7 ms).
+__global__ __launch_bounds__(256) void tw_key_k(u32 ntie, u32 W, u32 nb1, const u32 *tie_off, const u32 *tie_ncand, const u32 *cand_bucket,
+                                               const u32 *cand_place, u32 *key_c) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntie) return;
+  const u32 off = tie_off[t], k = tie_ncand[t];
+  const u32 row = (t / W) * nb1;
+  for (u32 j = 0; j < k; j++) key_c[cand_place[off + j]] = row + cand_bucket[off + j];
+}
+__global__ __launch_bounds__(256) void tw_heads_k(u32 ntev, const u32 *key_c, u32 *cell_first, u32 *cell_end) {
+  const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ntev) return;
+  const u32 cell = key_c[c];
+  if (c == 0 || key_c[c - 1] != cell) {
+    cell_first[cell] = c;
+    if (c) cell_end[key_c[c - 1]] = c;
+  }
+  if (c == ntev - 1) cell_end[cell] = ntev;
+}
+struct CellCount {
+  const u32 *first, *end;
+  __device__ u32 operator()(u64 i) const { return end[i] - first[i]; }
+};
+// first[cell] -> delta[cell] = first place of the cell in the window layout - its first place in the bucket-sorted layout
+__global__ __launch_bounds__(256) void tw_delta_k(u64 ncells, const u32 *cellstart, u32 *first_delta) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncells) first_delta[i] = cellstart[i] - first_delta[i];
+}
+__global__ __launch_bounds__(256) void tw_cand_k(u32 ntie, u32 W, u32 nb1, const u32 *tie_off, const u32 *tie_ncand, const u32 *cand_bucket,
+                                                const u32 *cand_place, const u32 *cellstart, const u32 *delta, u32 *wpos, u32 *rs) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntie) return;
+  const u32 off = tie_off[t], k = tie_ncand[t];
+  const u64 row = (u64)(t / W) * nb1;
+  for (u32 j = 0; j < k; j++) {
+    const u64 cell = row + cand_bucket[off + j];
+    wpos[off + j] = cand_place[off + j] + delta[cell];
+    rs[off + j] = cellstart[cell];
+  }
+}
+struct TieWinArgs {
+  u32 ntie, W;
+  const u32 *tie_off, *tie_ncand, *cand_bucket, *fixed_before, *wpos, *rs;
+  const u64 *prior;   // reads already in each bucket before this shard, or null
+  const u32 *base;    // tie reads of earlier windows per bucket
+  const u32 *P64;
+  const u64 *bits;
+  u32 *bits32;        // the same words, for the atomics
+  u32 *choice;
+  TieWinState *st;
+};
+__global__ __launch_bounds__(256) void tie_window_sweep_k(TieWinArgs a) {
+  if (a.st->finished) return;
+  const u32 w = a.st->window;
+  const u32 local = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 t64 = (u64)w * a.W + local;
+  if (local >= a.W || t64 >= a.ntie) return;
+  const u32 t = (u32)t64;
+  const u32 off = a.tie_off[t], k = a.tie_ncand[t];
+  if (k == 0) { a.choice[t] = 0; return; }
+  u32 best = 0;
+  u64 bestc = 0;
+  for (u32 j = 0; j < k; j++) {
+    const u32 bk = a.cand_bucket[off + j];
+    const u64 c = (a.prior ? a.prior[bk] : 0ull) + (u64)a.fixed_before[off + j] + (u64)a.base[bk] +
+                  (u64)(tw_rank(a.P64, a.bits, a.wpos[off + j]) - tw_rank(a.P64, a.bits, a.rs[off + j]));
+    if (j == 0 || c > bestc) {  // strict: an earlier candidate keeps the bucket on equal counts
+      best = j;
+      bestc = c;
+    }
+  }
+  const u32 old = a.choice[t];
+  if (best != old) {
+    if (old != TW_NONE) { const u32 e = a.wpos[off + old]; atomicAnd(&a.bits32[e >> 5], ~(1u << (e & 31u))); }
+    const u32 e = a.wpos[off + best];
+    atomicOr(&a.bits32[e >> 5], 1u << (e & 31u));
+    a.choice[t] = best;
+    a.st->changed = 1;  // plain store: every writer stores the same value
+  }
+}
+// one workgroup behind every sweep
+__global__ __launch_bounds__(1024) void tie_window_tail_k(TieWinState *st, u32 nwin, u32 nb1, const u32 *cellstart, const u64 *bits, u32 *P64,
+                                                         u32 *base) {
+  __shared__ u32 sm[16];
+  if (st->finished) return;
+  u32 w = st->window;
+  const u32 moved = st->changed;
+  __syncthreads();  // (everyone has read the state before thread 0 changes it)
+  if (threadIdx.x == 0) st->sweeps++;
+  if (!moved) {  // the window is settled: its choices count for the windows behind it
+    for (u32 b = threadIdx.x; b < nb1; b += 1024) {
+      const u64 cell = (u64)w * nb1 + b;
+      const u32 cs = cellstart[cell], ce = cellstart[cell + 1];
+      if (ce > cs) base[b] += tw_rank(P64, bits, ce) - tw_rank(P64, bits, cs);
+    }
+    w++;
+    if (threadIdx.x == 0) {
+      st->window = w;
+      if (w >= nwin) st->finished = 1;
+    }
+    if (w >= nwin) return;
+    __syncthreads();
+  }
+  // counts in front of the words of window w (its places, and the word its end falls into: rank(end) is asked for)
+  const u32 w0 = cellstart[(u64)w * nb1] >> 6, w1 = cellstart[(u64)(w + 1) * nb1] >> 6;
+  const u32 n = w1 - w0 + 1, per = (n + 1023) / 1024;
+  const u32 lo = w0 + threadIdx.x * per, hi = lo + per < w1 + 1 ? lo + per : w1 + 1;
+  u32 mine = 0;
+  for (u32 i = lo; i < hi; i++) mine += (u32)__popcll(bits[i]);
+  u32 tot;
+  u32 run = block_exclusive_sum<u32, 16>(mine, &tot, sm);
+  for (u32 i = lo; i < hi; i++) { P64[i] = run; run += (u32)__popcll(bits[i]); }
+  if (threadIdx.x == 0) st->changed = 0;
+}
+__global__ __launch_bounds__(256) void tw_counts_k(u32 nb1, const u32 *fixed_total, const u32 *base, u64 *counts) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb1) counts[b] = (u64)fixed_total[b] + (u64)base[b];
 }
 
 // The bounded way out.  A sweep makes at least the earliest undecided tie read final, so ntie + 1 sweeps always suffice --

@@ -241,13 +241,14 @@ struct scalce_workspace {
   DBuf bucket, endv, tokens, counts, bucket_first, bucket_off, chunk, chunk_start;
   DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   DBuf name_off;
+  DBuf tw_cells, tw_cand, tw_bits, tw_base;  // the tie-break in windows (tokenize_windows)
   void free_all() {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
                    &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
                    &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
                    &cand_place, &Gseg, &cand_fixed, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
                    &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
-                   &run_pos, &name_off};
+                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base};
     for (DBuf *d : all)
       if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
     row_cap = piece_rows_cap = 0;
@@ -267,7 +268,8 @@ struct scalce_batch {
         bucket(w->bucket), endv(w->endv), tokens(w->tokens), counts(w->counts), bucket_first(w->bucket_first), bucket_off(w->bucket_off),
         chunk(w->chunk), chunk_start(w->chunk_start), perm_a(w->perm_a), perm_b(w->perm_b), key_a(w->key_a), key_b(w->key_b), hist(w->hist),
         scan_ws(w->scan_ws), S(w->S), run_head(w->run_head), run_hcount(w->run_hcount), run_rank(w->run_rank), runid(w->runid),
-        run_items_a(w->run_items_a), run_items_b(w->run_items_b), run_pos(w->run_pos), name_off(w->name_off) {}
+        run_items_a(w->run_items_a), run_items_b(w->run_items_b), run_pos(w->run_pos), name_off(w->name_off),
+        tw_cells(w->tw_cells), tw_cand(w->tw_cand), tw_bits(w->tw_bits), tw_base(w->tw_base) {}
   scalce_ctx *ctx = nullptr;
   scalce_params p;
   u64 max_reads = 0, max_text = 0;
@@ -308,6 +310,7 @@ struct scalce_batch {
   u32 key_end_bits = 0, key_bucket_shift = 0, key_bucket_mask = 0;
   DBuf &perm_a, &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b, &run_pos;
   DBuf &name_off;
+  DBuf &tw_cells, &tw_cand, &tw_bits, &tw_base;
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, ac_tab[2], ac_tab8[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
   AcBlockDesc *ac_desc_host = nullptr;  // block descriptors of the last coder launch this shard led: pinned, so that the
@@ -578,6 +581,10 @@ static int launch_failed(scalce_ctx *c) {
   set_err(c, "launch of %s failed: %s", g_launch_what, hipGetErrorString(g_launch_err));
   g_launch_err = hipSuccess;
   return SCALCE_ERR_HIP;
+}
+static bool tok_pipelined() {  // SCALCE_TOK_PLAIN=1: the branching walk (tokenize_kmer_k), for comparisons
+  static const bool v = getenv("SCALCE_TOK_PLAIN") == nullptr;
+  return v;
 }
 static inline u32 cdiv(u64 a, u64 b) {
   const u64 q = (a + b - 1) / b;
@@ -872,7 +879,8 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     const size_t sh = (size_t)a.lds_states * 20;
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+    if (c->d_kmer && tok_pipelined()) LAUNCH(tokenize_kmer_pipe_k, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
     else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
   }
@@ -1115,9 +1123,95 @@ extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
   return SCALCE_OK;
 }
 
+// The tie-break of a batch on its own (fixed prior counts), window by window: see tie_window_sweep_k.  *settled = false
+// when the sweeps allowed (tie_max_sweeps() per window) did not get through: the caller decides in input order instead.
+static u32 tie_window_reads() {
+  const char *e = getenv("SCALCE_TIE_WINDOW");  // tie reads per window; 0 = the global sweeps (jacobi_k)
+  const long v = e ? atol(e) : 131072;
+  return (u32)(v < 0 ? 0 : v > (1l << 30) ? (1l << 30) : v);
+}
+static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *settled, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  const u32 nb1 = (u32)c->A.n_buckets + 1, ntie = b->ntie, ncap = b->ncand_cap, ntev = b->ntev;
+  *settled = false;
+  if (b->tok_base) {  // reads of this batch's earlier pieces count as well (bin_size is cumulative, reads.cpp:246)
+    if (d_prior) {
+      LAUNCH(add_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, reinterpret_cast<const u64 *>(d_prior), b->counts_total.as<u64>(), b->prior_buf.as<u64>());
+      d_prior = b->prior_buf.as<uint64_t>();
+    } else {
+      d_prior = b->counts_total.as<uint64_t>();
+    }
+  }
+  u32 W = tie_window_reads();
+  const u64 max_cells = 64ull << 20;  // (a million-core table: fewer, larger windows)
+  if ((u64)cdiv(ntie, W) * nb1 > max_cells) W = (u32)cdiv(ntie, max_cells / nb1 ? max_cells / nb1 : 1);
+  const u32 nwin = cdiv(ntie, W);
+  const u64 ncells = (u64)nwin * nb1;
+  const u64 nwords = ((u64)ntev >> 6) + 4;
+  ENSURE(b, b->tw_cells, sizeof(u32) * (3 * ncells + 8));
+  ENSURE(b, b->tw_cand, sizeof(u32) * (2 * (u64)ncap + 8));
+  ENSURE(b, b->tw_bits, (sizeof(u64) + sizeof(u32)) * nwords);
+  ENSURE(b, b->tw_base, sizeof(u32) * ((u64)nb1 + 16));
+  ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(ncells) + 1024));
+  u32 *first_delta = b->tw_cells.as<u32>(), *cell_end = first_delta + ncells, *cellstart = cell_end + ncells + 2;  // cellstart[ncells] = all candidates
+  u32 *wpos = b->tw_cand.as<u32>(), *rs = wpos + ncap + 2;
+  u64 *bits = b->tw_bits.as<u64>();
+  u32 *P64 = reinterpret_cast<u32 *>(bits + nwords);
+  u32 *base = b->tw_base.as<u32>();
+  TieWinState *st = reinterpret_cast<TieWinState *>(base + nb1 + 4);
+  const u32 *fixed_total = b->seg.as<u32>() + 2 * (nb1 + 2);
+  u32 *key_c = b->G.as<u32>();  // (the global sweeps' prefix sums: not in use here)
+  HIP_TRY(c, hipMemsetAsync(first_delta, 0, sizeof(u32) * 2 * ncells, s));  // empty cells: first = end = 0
+  HIP_TRY(c, hipMemsetAsync(bits, 0, (sizeof(u64) + sizeof(u32)) * nwords, s));
+  HIP_TRY(c, hipMemsetAsync(base, 0, sizeof(u32) * ((u64)nb1 + 16), s));  // (and the state behind it)
+  HIP_TRY(c, hipMemsetAsync(b->choice.p, 0xFF, sizeof(u32) * ntie, s));   // nobody has chosen yet
+  LAUNCH(tw_key_k, cdiv(ntie, 256), 256, 0, s, ntie, W, nb1, b->tie_off.as<u32>(), b->tie_ncand.as<u32>(), b->cand_bucket.as<u32>(),
+         b->cand_place.as<u32>(), key_c);
+  if (ntev) LAUNCH(tw_heads_k, cdiv(ntev, 256), 256, 0, s, ntev, key_c, first_delta, cell_end);
+  exclusive_scan<u32>(CellCount{first_delta, cell_end}, ncells, StoreTo<u32>{cellstart}, b->scan_ws.as<u32>(), cellstart + ncells, s);
+  LAUNCH(tw_delta_k, cdiv(ncells, 256), 256, 0, s, ncells, cellstart, first_delta);
+  LAUNCH(tw_cand_k, cdiv(ntie, 256), 256, 0, s, ntie, W, nb1, b->tie_off.as<u32>(), b->tie_ncand.as<u32>(), b->cand_bucket.as<u32>(),
+         b->cand_place.as<u32>(), cellstart, first_delta, wpos, rs);
+  TieWinArgs a;
+  a.ntie = ntie; a.W = W; a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
+  a.fixed_before = b->cand_fixed.as<u32>(); a.wpos = wpos; a.rs = rs; a.prior = reinterpret_cast<const u64 *>(d_prior); a.base = base;
+  a.P64 = P64; a.bits = bits; a.bits32 = reinterpret_cast<u32 *>(bits); a.choice = b->choice.as<u32>(); a.st = st;
+  // A window settles in a handful of sweeps when sweeping works at all (the last one moves nothing), so the sweeps go out in
+  // batches sized for the windows still open, and the host looks at the device's state once per batch.
+  const u64 budget = (u64)tie_max_sweeps() * nwin;
+  const u32 grid = cdiv(W < ntie ? W : ntie, 256);
+  TieWinState h{0, 0, 0, 0};
+  while (!h.finished) {
+    if (h.sweeps >= budget) { b->jacobi_iters = h.sweeps; return SCALCE_OK; }  // not settled
+    u64 batch = 4ull * (nwin - h.window) + 4;
+    if (batch > 256) batch = 256;
+    if (batch > budget - h.sweeps) batch = budget - h.sweeps;
+    for (u64 i = 0; i < batch; i++) {
+      LAUNCH(tie_window_sweep_k, grid, 256, 0, s, a);
+      LAUNCH(tie_window_tail_k, 1, 1024, 0, s, st, nwin, nb1, cellstart, bits, P64, base);
+    }
+    int rc = read_u32(b, reinterpret_cast<const u32 *>(st), reinterpret_cast<u32 *>(&h), 4, s);
+    if (rc) return rc;
+  }
+  b->jacobi_iters = h.sweeps;
+  LAUNCH(tw_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, fixed_total, base, b->counts.as<u64>());
+  *settled = true;
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, void *stream) {
   int rc = scalce_batch_tokenize_begin(b, stream);
   if (rc) return rc;
+  if (b->tok_n && b->ntie && tie_window_reads()) {
+    hipStream_t ws = (hipStream_t)stream;
+    {
+      StageTimer tm(b, ST_TOKENIZE, ws);
+      bool settled = false;
+      if ((rc = tokenize_windows(b, d_prior, &settled, ws))) return rc;
+      if (!settled && (rc = tokenize_sequential(b, d_prior, ws))) return rc;
+    }
+    return scalce_batch_tokenize_end(b, stream);
+  }
   // Sweeps go out four at a time and the host looks at their flags once per batch: a sweep after the fixed point changes
   // nothing (and costs next to nothing), while a round trip per sweep left the stream idle 47 times per shard.
   hipStream_t s = (hipStream_t)stream;
@@ -1164,7 +1258,8 @@ extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint6
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
     const size_t sh = (size_t)a.lds_states * 20;
-    if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+    if (c->d_kmer && tok_pipelined()) LAUNCH(tokenize_kmer_pipe_k, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
     else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
   }

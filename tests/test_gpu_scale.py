@@ -58,6 +58,30 @@ def stress_inputs(kind, n, L, rng):
 
 
 @pytest.mark.parametrize("kind", ["pileup", "two_cores", "fourmers"])
+@pytest.mark.parametrize("window", ["0", "700", "40000"])
+def test_tie_break_windows(kind, window, monkeypatch):
+    """The tie-break in windows of W tie reads (tie_window_sweep_k; SCALCE_TIE_WINDOW=0: the global sweeps): windows much
+    smaller than the input, so that hundreds of them hand their counts on, give the oracle's tokens on the inputs of
+    test_tie_break_stress."""
+    rng = np.random.default_rng(23)
+    n, L = 60_000, 100
+    text = {"fourmers": "\n".join("".join(x) for x in itertools.product("ACGT", repeat=4)) + "\n",
+            "two_cores": "ACGTTGCAAC\nTTGACCAGTA\nGGGGGGGGGG\n"}.get(kind)
+    monkeypatch.setenv("SCALCE_TIE_WINDOW", window)
+    blob = open(bigtable.__file__.replace("bigtable.py", "golden/patterns.bin"), "rb").read()
+    ctx = host.Context(0, patterns_text=text.encode()) if text else host.Context(0, patterns_bin=blob)
+    trie = O.Trie(text=text.encode()) if text else O.Trie(blob=blob)
+    bases = stress_inputs(kind, n, L, rng)
+    b = run_tokens(ctx, bases, L)
+    st = b.stats()
+    pat, end = trie.tokenize(bases)
+    tok = b.output(host.OUT_TOKENS, 0, np.int32).reshape(-1, 2)
+    assert (tok[:, 0] == pat).all() and (tok[:, 1] == end).all(), f"{kind} window {window}: tokens differ ({st})"
+    assert (b.output(host.OUT_PERM, 0, np.uint32) == trie.order(bases, pat, end)).all()
+    print(f"{kind} window={window}: {st}")
+
+
+@pytest.mark.parametrize("kind", ["pileup", "two_cores", "fourmers"])
 @pytest.mark.parametrize("fallback", [False, True])
 def test_tie_break_stress(kind, fallback, monkeypatch):
     """Inputs on which the parallel sweeps are slow to settle, with and without the bounded way out (after
