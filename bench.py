@@ -27,6 +27,10 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# The pipeline keeps a front stream and up to three coder streams busy at once: HIP maps streams onto GPU_MAX_HW_QUEUES
+# hardware queues (default 4), and two streams that share a queue run one after the other -- a front-stage kernel behind a
+# 0.65 s coder launch.  Must be set before the runtime comes up.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -171,7 +175,7 @@ def main():
     # previous ones on another, `G` shards per coder launch, shards retired on events
     DF = D // F
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
-                           coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "2" if (G > 1 and DF >= 3 * G) else "1")))
+                           coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "3" if (G > 1 and DF >= 3 * G) else "1")))
              for f in range(F)]
     pipe = pipes[0]
     front = pipe.front

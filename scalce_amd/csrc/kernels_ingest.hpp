@@ -38,15 +38,13 @@ __device__ __forceinline__ u32 zero_bytes(u32 x) {
   return ~(t | x | 0x7F7F7F7Fu);
 }
 __device__ __forceinline__ u32 newline_mask16(uint4 v) {  // bit i = byte i is '\n'
-  u32 m = 0;
-  u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    u32 z = zero_bytes(w[k] ^ 0x0A0A0A0Au);  // 0x80 flags at bits 7,15,23,31
-    u32 bits = ((z >> 7) & 1) | ((z >> 14) & 2) | ((z >> 21) & 4) | ((z >> 28) & 8);
-    m |= bits << (4 * k);
-  }
-  return m;
+  // the 0x80 flags of a word become 4 mask bits through one dot product with the weights 1, 2, 4, 8 (v_dot4_u32_u8); the
+  // second word of a pair takes 16 .. 128 and adds the first one's bits in the same instruction
+  const u32 z0 = zero_bytes(v.x ^ 0x0A0A0A0Au) >> 7, z1 = zero_bytes(v.y ^ 0x0A0A0A0Au) >> 7;
+  const u32 z2 = zero_bytes(v.z ^ 0x0A0A0A0Au) >> 7, z3 = zero_bytes(v.w ^ 0x0A0A0A0Au) >> 7;
+  const u32 lo = __builtin_amdgcn_udot4(z1, 0x80402010u, __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false), false);
+  const u32 hi = __builtin_amdgcn_udot4(z3, 0x80402010u, __builtin_amdgcn_udot4(z2, 0x08040201u, 0u, false), false);
+  return lo | (hi << 8);
 }
 
 constexpr int IDX_THREADS = 256;
@@ -113,9 +111,8 @@ __device__ __forceinline__ u32 pack4(u32 v) {
   const u32 up = v & 0xDFDFDFDFu;                                // fold case
   const u32 code = ((v >> 1) ^ (v >> 2)) & 0x03030303u;          // A0 C1 G2 T3 on the letters themselves
   u32 ok = zero_bytes(up ^ 0x43434343u) | zero_bytes(up ^ 0x47474747u) | zero_bytes(up ^ 0x54545454u);
-  ok = (ok >> 7) * 3u;                                            // 0x80 flag -> 0x03 mask per byte
-  const u32 c = code & ok;
-  return ((c & 3u) << 6) | (((c >> 8) & 3u) << 4) | (((c >> 16) & 3u) << 2) | ((c >> 24) & 3u);
+  ok = (ok >> 7) | (ok >> 6);                                     // 0x80 flag -> 0x03 mask per byte (no multiply: quarter rate)
+  return __builtin_amdgcn_udot4(code & ok, 0x01041040u, 0u, false);  // first base x 64 + second x 16 + third x 4 + fourth
 }
 
 // aligned little-endian word; bytes at or past `n` read as 0
@@ -498,6 +495,290 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
     }
     __syncthreads();
   }
+}
+
+// The same pass with the unpack spread over all lanes.  ingest_tiles_k gives a record to two threads that walk its 4-byte
+// groups one after the other: a 16 KB tile holds ~70 records of 100 bp, so 140 of the 256 threads run 25-step loops while
+// the others wait -- three quarters of the kernel's issue slots.  Here one thread per record only looks at the record's
+// structure (lines, name); the bases are then packed in units of one output word (16 bases) and the qualities in units of
+// four symbols, units dealt to the lanes in order: every lane busy, consecutive lanes write consecutive words of the
+// packed rows and of the q' rows (both are back to back in memory), no staging of q' in LDS.  The smallest and largest q'
+// symbol of the tile fall out on the way (sym_range_k read all of q' again for them).
+struct Ingest2Args {
+  IngestArgs i;
+  u64 magic_s, magic_w;   // ceil(2^32 / S), ceil(2^32 / W): S = words per packed row, W = 16-symbol units per read
+  u32 step_ks, step_rs, step_kw, step_rw;  // 256 / S, 256 % S, 256 / W, 256 % W
+  u16 *tile_minmax;       // per tile: min | max << 8 of its q' symbols (255 | 0 << 8: none), or null
+};
+constexpr u32 ING2_RECMAX = ING_NLMAX / 4 + 4;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));  // sixteen bytes at a 4-byte boundary
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
+  return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
+  return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ u32 lds_fetch_u32(const u8 *text, u32 at) {  // unaligned little-endian fetch from the tile
+  const u32 *p = reinterpret_cast<const u32 *>(text + (at & ~3u));
+  return __builtin_amdgcn_alignbyte(p[1], p[0], at & 3u);
+}
+__global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
+  const IngestArgs &a = g.i;
+  __shared__ __attribute__((aligned(16))) u8 text[ING_TILE + ING_OVER + 32];
+  __shared__ u16 nl[ING_NLMAX];
+  __shared__ u16 rec_sb[ING2_RECMAX], rec_sq[ING2_RECMAX];
+  __shared__ u8 lut[128];
+  __shared__ u32 sm[ING_THREADS / 64];
+  __shared__ u32 s_count[2];
+  __shared__ u32 s_mm[2 * (ING_THREADS / 64)];
+  const int tid = threadIdx.x;
+  const u64 t0 = (u64)blockIdx.x * ING_TILE;                       // text offset of the tile
+  const u64 avail = a.u.nbytes - t0;
+  const u32 len = (u32)(avail < ING_TILE + ING_OVER ? avail : ING_TILE + ING_OVER);
+  if (tid < 128) lut[tid] = a.u.qlut[tid];
+  if (tid == 0) s_count[1] = 0;
+  for (u32 i = (u32)tid * 16; i < len + 8; i += ING_THREADS * 16) {
+    uint4 v;
+    if (t0 + i + 16 <= a.u.nbytes) v = *reinterpret_cast<const uint4 *>(a.u.text + t0 + i);
+    else {
+      u32 w[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 16; k++)
+        if (t0 + i + k < a.u.nbytes) w[k >> 2] |= (u32)a.u.text[t0 + i + k] << (8 * (k & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4 *>(text + i) = v;
+  }
+  __syncthreads();
+  // newline positions, in order: the tile proper (chunk = 64 bytes per thread), then the overlap (first 16 threads)
+  u32 base = 0;
+  for (int part = 0; part < 2; part++) {
+    const u32 off = part ? ING_TILE + (u32)tid * 64 : (u32)tid * 64;
+    u64 m = 0;
+    if ((part == 0 || tid < (int)(ING_OVER / 64)) && off < len) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(text + off);
+#pragma unroll
+      for (int c = 0; c < 4; c++) m |= (u64)newline_mask16(p[c]) << (16 * c);
+      if (off + 64 > len) m &= (len - off >= 64) ? ~0ull : ((1ull << (len - off)) - 1);
+    }
+    u32 tot;
+    u32 at = base + block_exclusive_sum<u32, ING_THREADS / 64>((u32)__popcll(m), &tot, sm);
+    while (m) {
+      const int bpos = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (at < ING_NLMAX) nl[at] = (u16)(off + bpos);
+      at++;
+    }
+    base += tot;
+  }
+  if (tid == 0) { s_count[0] = base; }
+  __syncthreads();
+  const u32 count = s_count[0];
+  if (count > ING_NLMAX) { if (tid == 0) atomicExch(a.slow, 1u); return; }
+  const u64 G0 = a.tile_base[(u64)blockIdx.x * (ING_TILE / IDX_TILE)];
+  const bool starts_line = t0 == 0 || a.u.text[t0 - 1] == '\n';
+  const u32 jmin = starts_line ? 0u : 1u;
+  const u32 j0 = jmin + (u32)((4 - ((G0 + jmin) & 3)) & 3);         // first name line that starts here
+  const u64 rid0 = (G0 + j0) >> 2;
+  const u32 nloc = j0 < count ? (count - j0 + 3) / 4 : 0u;         // name lines that END in tile + overlap
+  const int L = a.u.L;
+  // one thread per record: is it this tile's (it STARTS here and is whole), are its lines as long as they must be, its name
+  for (u32 k = (u32)tid; k < nloc; k += ING_THREADS) {
+    const u32 j = j0 + 4 * k;
+    const u64 rid = rid0 + k;
+    bool take = rid < a.u.nrec;
+    u32 ns = 0;
+    if (take) {
+      ns = j ? (u32)nl[j - 1] + 1 : 0u;
+      if (j && j - 1 >= count) take = false;
+      else if (ns >= ING_TILE) take = false;                        // starts in the next tile: that workgroup's record
+    }
+    if (take && j + 3 >= count) {                                   // its four lines must end inside tile + overlap
+      take = false;
+      atomicExch(a.slow, 1u);
+    }
+    if (!take) continue;
+    atomicAdd(&s_count[1], 1u);                                     // (the records taken are the first ones: a prefix of k)
+    const u32 p0 = nl[j], p1 = nl[j + 1], p2 = nl[j + 2], p3 = nl[j + 3];
+    if (rid + 1 == a.u.nrec) *a.consumed = t0 + p3 + 1;
+    if (p1 - p0 - 1 != (u32)L || p3 - p2 - 1 != (u32)L) {
+      dev_fail(a.u.err, E_READLEN, rid, p1 - p0 - 1);
+      rec_sb[k] = 0xFFFFu;                                          // nothing of it is unpacked
+      rec_sq[k] = 0xFFFFu;
+      if (a.u.mate == 0) {  // the run ends with an error; until the host sees it, later stages must find a well-formed row
+        a.u.namelen[rid] = 0;
+        if (a.u.namecell) *reinterpret_cast<uint4 *>(a.u.namecell + 16 * rid) = make_uint4(0, 0, 0, 0);
+      }
+      continue;
+    }
+    rec_sb[k] = (u16)(p0 + 1);
+    rec_sq[k] = (u16)(p2 + 1);
+    if (a.u.mate == 0) {
+      // output_name, names.cpp:55-57: characters after '@' up to the first space or the newline
+      u32 nlen = 0;
+      if (a.u.use_names) {
+        // the first space of the name line, four characters at a time (the newline at p0 ends the search)
+        u32 i = ns + 1;
+        for (; i < p0; i += 4) {
+          const u32 z = zero_bytes(lds_fetch_u32(text, i) ^ 0x20202020u);
+          if (z) { i += (u32)(__ffs((int)z) - 1) >> 3; break; }
+        }
+        if (i > p0) i = p0;
+        const u32 l = i - (ns + 1);
+        if (l > 255 || p0 <= ns) dev_fail(a.u.err, E_NAMELEN, rid);
+        nlen = l > 255 ? 0u : l;
+        if (a.u.namecell) {
+          // cell = [length][15 characters]: the 16 bytes from '@' on with the length in place of the '@', zero behind the name
+          u32 w[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const int keepb = (int)nlen + 1 - 4 * x;                // bytes of this word that belong to the cell
+            const u32 v = lds_fetch_u32(text, ns + 4 * (u32)x);
+            w[x] = keepb >= 4 ? v : keepb <= 0 ? 0u : (v & ((1u << (8 * keepb)) - 1));
+          }
+          w[0] = (w[0] & 0xFFFFFF00u) | nlen;
+          *reinterpret_cast<uint4 *>(a.u.namecell + 16 * rid) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        if (nlen > 15 && a.u.max_namelen) atomicMax(a.u.max_namelen, nlen);
+      }
+      a.u.namelen[rid] = (u8)nlen;
+    }
+  }
+  __syncthreads();
+  const u32 ntake = s_count[1];
+  // Units are dealt to the threads in order, 256 apart: (record, word) of a thread's next unit follow from the last one by
+  // additions (step_k, step_r = 256 / n, 256 % n from the host), and both outputs are back to back in memory -- unit u of
+  // the tile is word u behind the tile's first row.
+  // bases: one unit = one word of a packed row = 16 bases (zero behind the read)
+  {
+    const u32 S = (u32)a.u.stride / 4, units = ntake * S, wfull = (u32)L / 16;
+    u32 k = (u32)(((u64)(u32)tid * g.magic_s) >> 32), w = (u32)tid - k * S;
+    u32 *dst = reinterpret_cast<u32 *>(a.u.packed + rid0 * (u64)a.u.stride);
+    for (u32 u = (u32)tid; u < units; u += ING_THREADS) {
+      const u32 sb = rec_sb[k];
+      if (sb != 0xFFFFu) {
+        u32 acc = 0;
+        if (w < wfull) {  // sixteen bases of the read: five aligned words of the tile, four bytes of the row
+          const u32 at = sb + 16 * w, sh = at & 3u;
+          const u32 *p = reinterpret_cast<const u32 *>(text + (at & ~3u));
+          const u32 d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+          acc = pack4(__builtin_amdgcn_alignbyte(d1, d0, sh)) | (pack4(__builtin_amdgcn_alignbyte(d2, d1, sh)) << 8) |
+                (pack4(__builtin_amdgcn_alignbyte(d3, d2, sh)) << 16) | (pack4(__builtin_amdgcn_alignbyte(d4, d3, sh)) << 24);
+        } else {
+          const int i0 = 16 * (int)w;
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int i = i0 + 4 * m, rem = L - i;
+            if (rem > 0) {
+              u32 vb = lds_fetch_u32(text, sb + (u32)i);
+              if (rem < 4) vb &= (1u << (8 * rem)) - 1;             // bytes behind the line are not part of the read
+              acc |= pack4(vb) << (8 * m);
+            }
+          }
+        }
+        dst[u] = acc;
+      }
+      k += g.step_ks; w += g.step_rs;
+      if (w >= S) { w -= S; k++; }
+    }
+  }
+  // qualities: one unit = sixteen symbols (the last unit of a read: what is left); q' (qualities.cpp:183): exactly 'N' forces
+  // the offset, i.e. symbol 0
+  u32 lo_e = 0x00FF00FFu, lo_o = 0x00FF00FFu, hi_e = 0, hi_o = 0;   // smallest / largest symbol, even and odd bytes apart
+  {
+    const u32 W = ((u32)L + 15) / 16, units = ntake * W, wfull = (u32)L / 16;
+    const bool al = (L & 3) == 0;
+    const u32 aff = (u32)(a.u.q_affine >= 0 ? a.u.q_affine : 0) * 0x01010101u;
+    u32 k = (u32)(((u64)(u32)tid * g.magic_w) >> 32), w = (u32)tid - k * W;
+    u8 *qtile = a.u.q + rid0 * (u64)L;
+    u32 qoff = k * (u32)L + 16 * w;                                 // (a tile's q' rows: far below 2^32 bytes)
+    const u32 qstep = g.step_kw * (u32)L + 16 * g.step_rw, qwrap = (u32)L - 16 * W;
+    auto quality = [&](u32 vq) -> u32 {
+      if (a.u.q_affine >= 0)  // four subtractions in one word (see unpack_record_at)
+        return (((vq & 0x7F7F7F7Fu) | 0x80808080u) - aff) ^ 0x80808080u;
+      return (u32)lut[vq & 127] | ((u32)lut[(vq >> 8) & 127] << 8) | ((u32)lut[(vq >> 16) & 127] << 16) | ((u32)lut[(vq >> 24) & 127] << 24);
+    };
+    auto not_n = [&](u32 vb) -> u32 {  // 0xFF in every byte that is not 'N'
+      const u32 zN = zero_bytes(vb ^ 0x4E4E4E4Eu);
+      return ~(zN | (zN - (zN >> 7)));
+    };
+    auto range = [&](u32 ql, u32 qh) {  // ql: bytes that are not symbols hold 0xFF; qh: they hold 0
+      lo_e = pk_min_u16(lo_e, ql & 0x00FF00FFu); lo_o = pk_min_u16(lo_o, (ql >> 8) & 0x00FF00FFu);
+      hi_e = pk_max_u16(hi_e, qh & 0x00FF00FFu); hi_o = pk_max_u16(hi_o, (qh >> 8) & 0x00FF00FFu);
+    };
+    for (u32 u = (u32)tid; u < units; u += ING_THREADS) {
+      const u32 sb = rec_sb[k];
+      if (sb != 0xFFFFu) {
+        const u32 sq = rec_sq[k];
+        if (w < wfull) {
+          const u32 ab = sb + 16 * w, aq = sq + 16 * w, shb = ab & 3u, shq = aq & 3u;
+          const u32 *pb = reinterpret_cast<const u32 *>(text + (ab & ~3u)), *pq = reinterpret_cast<const u32 *>(text + (aq & ~3u));
+          const u32 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
+          const u32 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
+          const u32 r0 = quality(__builtin_amdgcn_alignbyte(q1, q0, shq)) & not_n(__builtin_amdgcn_alignbyte(b1, b0, shb));
+          const u32 r1 = quality(__builtin_amdgcn_alignbyte(q2, q1, shq)) & not_n(__builtin_amdgcn_alignbyte(b2, b1, shb));
+          const u32 r2 = quality(__builtin_amdgcn_alignbyte(q3, q2, shq)) & not_n(__builtin_amdgcn_alignbyte(b3, b2, shb));
+          const u32 r3 = quality(__builtin_amdgcn_alignbyte(q4, q3, shq)) & not_n(__builtin_amdgcn_alignbyte(b4, b3, shb));
+          u8 *qdst = qtile + qoff;
+          if (al) {
+            u32x4a v;
+            v.x = r0; v.y = r1; v.z = r2; v.w = r3;
+            *reinterpret_cast<u32x4a *>(qdst) = v;
+          } else {
+            const u32 rr[4] = {r0, r1, r2, r3};
+            for (int x = 0; x < 16; x++) qdst[x] = (u8)(rr[x >> 2] >> (8 * (x & 3)));
+          }
+          range(r0, r0); range(r1, r1); range(r2, r2); range(r3, r3);
+        } else {
+          for (u32 i = 16 * w; i < (u32)L; i += 4) {
+            const int rem = L - (int)i;
+            const u32 keep = rem < 4 ? (1u << (8 * rem)) - 1 : 0xFFFFFFFFu;
+            const u32 qq = quality(lds_fetch_u32(text, sq + i) & keep) & not_n(lds_fetch_u32(text, sb + i) & keep) & keep;
+            u8 *qdst = qtile + qoff + (i - 16 * w);
+            if (al) *reinterpret_cast<u32 *>(qdst) = qq;
+            else for (int x = 0; x < (rem < 4 ? rem : 4); x++) qdst[x] = (u8)(qq >> (8 * x));
+            range(qq | ~keep, qq);
+          }
+        }
+      }
+      k += g.step_kw; w += g.step_rw; qoff += qstep;
+      if (w >= W) { w -= W; k++; qoff += qwrap; }
+    }
+  }
+  u32 lo = pk_min_u16(lo_e, lo_o), hi = pk_max_u16(hi_e, hi_o);
+  lo = min(lo & 0xFFFFu, lo >> 16);
+  hi = max(hi & 0xFFFFu, hi >> 16);
+  for (int o = 32; o; o >>= 1) {
+    lo = min(lo, (u32)__shfl_xor((int)lo, o));
+    hi = max(hi, (u32)__shfl_xor((int)hi, o));
+  }
+  if (lane_id() == 0) { s_mm[2 * wave_id()] = lo; s_mm[2 * wave_id() + 1] = hi; }
+  __syncthreads();  // (also: the q' rows of the tile are written)
+  for (int w = 0; w < ING_THREADS / 64; w++) { lo = min(lo, s_mm[2 * w]); hi = max(hi, s_mm[2 * w + 1]); }
+  if (tid == 0 && g.tile_minmax) g.tile_minmax[blockIdx.x] = (u16)(lo | (hi << 8));
+  if (hi >= 80 && !a.u.no_ac) {  // a symbol the coder's tables have no row for (arithmetic.h:47): which record was it?
+    for (u32 k = (u32)tid; k < ntake; k += ING_THREADS) {
+      if (rec_sb[k] == 0xFFFFu) continue;
+      const u8 *qsrc = a.u.q + (rid0 + k) * (u64)L;
+      bool bad = false;
+      for (int x = 0; x < L; x++) bad |= qsrc[x] >= 80;
+      if (bad) { dev_fail(a.u.err, E_SYMBOL, rid0 + k); break; }
+    }
+  }
+}
+// smallest / largest q' symbol of the piece from the tiles' (what sym_range_k leaves in minmax; preset to 255.., 0)
+__global__ __launch_bounds__(256) void tile_minmax_reduce_k(const u16 *tile_minmax, u32 ntiles, u32 *minmax) {
+  u32 lo = 255, hi = 0;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < ntiles; i += gridDim.x * blockDim.x) {
+    const u32 v = tile_minmax[i];
+    lo = min(lo, v & 0xFFu);
+    hi = max(hi, v >> 8);
+  }
+  for (int o = 32; o; o >>= 1) {
+    lo = min(lo, (u32)__shfl_xor((int)lo, o));
+    hi = max(hi, (u32)__shfl_xor((int)hi, o));
+  }
+  if (lane_id() == 0) { atomicMin(&minmax[0], lo); atomicMax(&minmax[1], hi); }
 }
 
 // ---- trigram counters -------------------------------------------------------------------------

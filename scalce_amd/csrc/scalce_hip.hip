@@ -242,13 +242,14 @@ struct scalce_workspace {
   DBuf perm_a, perm_b, key_a, key_b, hist, scan_ws, S, run_head, run_hcount, run_rank, runid, run_items_a, run_items_b, run_pos;
   DBuf name_off;
   DBuf tw_cells, tw_cand, tw_bits, tw_base;  // the tie-break in windows (tokenize_windows)
+  DBuf tile_mm[2];                           // per text tile: smallest / largest q' symbol (ingest_tiles2_k)
   void free_all() {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
                    &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
                    &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
                    &cand_place, &Gseg, &cand_fixed, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
                    &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
-                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base};
+                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1]};
     for (DBuf *d : all)
       if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
     row_cap = piece_rows_cap = 0;
@@ -269,7 +270,7 @@ struct scalce_batch {
         chunk(w->chunk), chunk_start(w->chunk_start), perm_a(w->perm_a), perm_b(w->perm_b), key_a(w->key_a), key_b(w->key_b), hist(w->hist),
         scan_ws(w->scan_ws), S(w->S), run_head(w->run_head), run_hcount(w->run_hcount), run_rank(w->run_rank), runid(w->runid),
         run_items_a(w->run_items_a), run_items_b(w->run_items_b), run_pos(w->run_pos), name_off(w->name_off),
-        tw_cells(w->tw_cells), tw_cand(w->tw_cand), tw_bits(w->tw_bits), tw_base(w->tw_base) {}
+        tw_cells(w->tw_cells), tw_cand(w->tw_cand), tw_bits(w->tw_bits), tw_base(w->tw_base), tile_mm(w->tile_mm) {}
   scalce_ctx *ctx = nullptr;
   scalce_params p;
   u64 max_reads = 0, max_text = 0;
@@ -311,6 +312,8 @@ struct scalce_batch {
   DBuf &perm_a, &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b, &run_pos;
   DBuf &name_off;
   DBuf &tw_cells, &tw_cand, &tw_bits, &tw_base;
+  DBuf (&tile_mm)[2];
+  bool mm_valid[2] = {false, false};  // tile_mm[m] holds the symbol ranges of the piece ingested last
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, ac_tab[2], ac_tab8[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
   AcBlockDesc *ac_desc_host = nullptr;  // block descriptors of the last coder launch this shard led: pinned, so that the
@@ -653,15 +656,31 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
   // record turns out not to fit the tile overlap
   bool fused = a.L >= 16 && a.L <= 160 && !getenv("SCALCE_INGEST_INDEXED");
   u32 flags[2] = {0, 0};
+  b->mm_valid[mate] = false;
   if (fused) {
     IngestArgs ia;
     ia.u = a;
     ia.tile_base = b->tile[mate].as<u64>();
     ia.consumed = d_consumed;
     ia.slow = slow;
-    LAUNCH(ingest_tiles_k, cdiv(nbytes, ING_TILE), ING_THREADS, 0, s, ia);
+    if (getenv("SCALCE_INGEST_PAIRS")) {  // two threads per record (comparisons)
+      LAUNCH(ingest_tiles_k, cdiv(nbytes, ING_TILE), ING_THREADS, 0, s, ia);
+    } else {
+      const u32 ntiles2 = cdiv(nbytes, ING_TILE);
+      ENSURE(b, b->tile_mm[mate], sizeof(u16) * ((size_t)ntiles2 + 8));
+      Ingest2Args ga;
+      ga.i = ia;
+      const u64 S = (u64)a.stride / 4, W = ((u64)a.L + 15) / 16;
+      ga.magic_s = ((1ull << 32) + S - 1) / S;
+      ga.magic_w = ((1ull << 32) + W - 1) / W;
+      ga.step_ks = (u32)(ING_THREADS / S); ga.step_rs = (u32)(ING_THREADS % S);
+      ga.step_kw = (u32)(ING_THREADS / W); ga.step_rw = (u32)(ING_THREADS % W);
+      ga.tile_minmax = b->tile_mm[mate].as<u16>();
+      LAUNCH(ingest_tiles2_k, ntiles2, ING_THREADS, 0, s, ga);
+      b->mm_valid[mate] = true;
+    }
     { int rc = read_u32(b, b->d_small + 16, flags, 2, s); if (rc) return rc; }
-    if (flags[1]) fused = false;  // a record longer than the overlap: redo the piece the indexed way
+    if (flags[1]) { fused = false; b->mm_valid[mate] = false; }  // a record longer than the overlap: redo the piece the indexed way
   }
   if (!fused) {
     { int rc = ensure_line_index(b, mate, s); if (rc) return rc; }
@@ -812,7 +831,12 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     u32 *minmax = b->d_small + 24;  // smallest / largest symbol of the piece
     HIP_TRY(c, hipMemsetAsync(minmax, 0xFF, sizeof(u32), s));
     HIP_TRY(c, hipMemsetAsync(minmax + 1, 0, sizeof(u32), s));
-    LAUNCH(sym_range_k, 2048, 256, 0, s, q, n, minmax);
+    if (b->mm_valid[m]) {  // the ingest kernel left the range of every tile of the piece's text
+      const u32 nt = cdiv(b->text_bytes[m], ING_TILE);
+      LAUNCH(tile_minmax_reduce_k, cdiv(nt, 256 * 16) ? cdiv(nt, 256 * 16) : 1, 256, 0, s, b->tile_mm[m].as<u16>(), nt, minmax);
+    } else {
+      LAUNCH(sym_range_k, 2048, 256, 0, s, q, n, minmax);
+    }
     u32 *prev = b->d_small + 20 + 2 * m;  // the two symbols in front of this piece
     LAUNCH(tri_prev_k, 1, 1, 0, s, q, before, b->p.qprev[m][0], b->p.qprev[m][1], prev);
     u32 *range = b->d_small + 14;  // {lo, A}: span of the symbols that occur

@@ -434,6 +434,16 @@ def test_malformed_input_is_an_error(ctx):
     with pytest.raises(host.ScalceError):
         b2.compress(t2.data_ptr(), len(bad2))
         b2.finish()
+    # a quality character 80 or more above the offset: the coder's tables have no row for it (arithmetic.h:47)
+    for L in (40, 41):
+        b3_, q3 = synth.reads_and_quals(3000, L, seed=4)
+        q3[2345, L - 1] = 33 + 85
+        fq3 = synth.fastq_bytes_fast(b3_, q3)
+        t3 = device_bytes(fq3)
+        b3 = host.Batch(ctx, L, 3100, len(fq3) + 64, qmap=[(33, np.arange(128, dtype=np.int32))])
+        with pytest.raises(host.ScalceError, match="2345|symbol"):
+            b3.compress(t3.data_ptr(), len(fq3))
+            b3.finish()
 
 
 def test_empty_shard(ctx):
@@ -674,18 +684,24 @@ def test_lanes_coder_block_edges(nsym, ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["indexed_kernels", "records_longer_than_the_overlap", "short_reads_L16", "tile_edges"])
+@pytest.mark.parametrize("case", ["indexed_kernels", "records_longer_than_the_overlap", "short_reads_L16", "tile_edges",
+                                  "tile_edges_record_pairs", "odd_length_L75", "short_reads_L16_record_pairs"])
 def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
-    """The ingest stage reads the text once behind the newline count (ingest_tiles_k: 32 KB tiles + 1 KB overlap in LDS) and
+    """The ingest stage reads the text once behind the newline count (ingest_tiles2_k: 16 KB tiles + 1 KB overlap in LDS,
+    the unpack dealt to the lanes word by word; SCALCE_INGEST_PAIRS=1: ingest_tiles_k, two threads per record) and
     falls back to the indexed kernels (index_write_k + unpack_tiled_k) for read lengths outside 16..160 or when a record
-    does not fit the overlap.  Both paths, the fallback trigger, the shortest fused read length and records that straddle
-    tile boundaries in every phase against the oracle."""
+    does not fit the overlap.  All paths, the fallback trigger, the shortest fused read length, a read length that is not
+    a multiple of four and records that straddle tile boundaries in every phase against the oracle."""
     from gpu_util import hip_compress, oracle_streams
     rng = np.random.default_rng(17)
     L, n = 100, 40000
-    if case == "short_reads_L16":
+    if case.startswith("short_reads_L16"):
         L, n = 16, 150000
+    if case == "odd_length_L75":
+        L = 75
     bases, quals = synth.reads_and_quals(n, L, seed=55, n_frac=0.004, dup_frac=0.1)
+    if case.endswith("record_pairs"):
+        monkeypatch.setenv("SCALCE_INGEST_PAIRS", "1")
     if case == "indexed_kernels":
         monkeypatch.setenv("SCALCE_INGEST_INDEXED", "1")
     if case == "records_longer_than_the_overlap":   # names of up to 255 characters, repeated on the '+' line
@@ -694,7 +710,7 @@ def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
             nm = b"r%d_" % i + b"x" * int(rng.integers(0, 250 - 8))
             recs.append(b"@" + nm + b"\n" + bases[i].tobytes() + b"\n+" + nm + b"\n" + quals[i].tobytes() + b"\n")
         fq = b"".join(recs)
-    elif case == "tile_edges":                      # name lengths cycle so that record starts sweep through every tile phase
+    elif case.startswith("tile_edges"):             # name lengths cycle so that record starts sweep through every tile phase
         recs = [b"@" + b"n" * (1 + (i * 7) % 61) + b" c\n" + bases[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n" for i in range(n)]
         fq = b"".join(recs)
     else:
