@@ -174,8 +174,9 @@ def main():
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
     DF = D // F
+    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "3" if (G > 1 and DF >= 3 * G) else "1"))
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
-                           coder_streams=int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "3" if (G > 1 and DF >= 3 * G) else "1")))
+                           coder_streams=n_coder_streams)
              for f in range(F)]
     pipe = pipes[0]
     front = pipe.front

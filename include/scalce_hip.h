@@ -162,6 +162,10 @@ int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior_counts,
 /* nsweeps (1..16) sweeps against the same prior counts, one look at their flags: *changed = 1 if any of them moved a decision */
 int scalce_batch_tokenize_sweeps(scalce_batch *b, const uint64_t *d_prior_counts, int nsweeps, int *changed, void *stream);
 int scalce_batch_tokenize_end(scalce_batch *b, void *stream);
+/* scalce_batch_tokenize = _begin + _settle: _settle resolves the tie-break of this batch on its own against fixed prior
+ * counts (window by window in input order) and ends the tokenization.  Split so that a caller can enqueue other work of the
+ * shard on a second stream beside the tie-break's many small launches. */
+int scalce_batch_tokenize_settle(scalce_batch *b, const uint64_t *d_prior_counts, void *stream);
 /* Sharded runs: the cuts the -B rule makes inside this batch's rows when `carry_in` bytes of records are already in the
  * chunk that is open where they begin (the rows of the ranks before): cuts_host[i] = row in front of which chunk i + 1
  * begins (1 .. N; at most cap), carry_out = bytes in the chunk still open behind the last row.  Needs the rows ingested,

@@ -1226,6 +1226,16 @@ static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *sett
 extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, void *stream) {
   int rc = scalce_batch_tokenize_begin(b, stream);
   if (rc) return rc;
+  return scalce_batch_tokenize_settle(b, d_prior, stream);
+}
+
+// The rest of scalce_batch_tokenize behind _begin: the tie-break of this batch on its own (fixed prior counts), then _end.
+// A caller may put other work of the shard beside it (the quality statistics on a second stream were tried: the sweeps are
+// hundreds of small launches -- but bound by the host's launch rate, not by the chip: 95.0 against 94.7 ms per shard).
+extern "C" int scalce_batch_tokenize_settle(scalce_batch *b, const uint64_t *d_prior, void *stream) {
+  if (!b || !b->tok_open) return SCALCE_ERR_ARG;
+  HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
+  int rc;
   if (b->tok_n && b->ntie && tie_window_reads()) {
     hipStream_t ws = (hipStream_t)stream;
     {
@@ -1965,10 +1975,16 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
 
   int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);
   if (rc) return rc;
-  // The framing ([u32 size][bytes] per block: scan of the sizes + one copy kernel, ~5 ms per 50 M-read shard) is left to
-  // entropy_collect, i.e. to the stream the caller collects on: behind the coder on its own stream it lengthened every
-  // launch by the framing of all its shards, and the coder stream is the one the pipeline waits for.
-  for (auto &j : jobs) j.b->frame_deferred[j.m] = j.nblk;
+  // The framing ([u32 size][bytes] per block: a scan of the sizes + one copy kernel, ~1.5 ms per 50 M-read shard on an
+  // idle chip) is left to entropy_collect, i.e. to the stream the caller collects on.  Behind the coder on its own stream
+  // (SCALCE_AC_FRAME_BEHIND_CODER=1) it was measured slower with one coder stream (it lengthens the launch the pipeline
+  // waits for) and with three (95.6 against 93.0 ms per shard).
+  static const bool at_collect = getenv("SCALCE_AC_FRAME_BEHIND_CODER") == nullptr;
+  for (auto &j : jobs) {
+    if (at_collect) { j.b->frame_deferred[j.m] = j.nblk; continue; }
+    rc = ac_frame(j, s);
+    if (rc) return rc;
+  }
   return SCALCE_OK;
 }
 

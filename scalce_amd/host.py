@@ -119,6 +119,7 @@ def lib():
     L.scalce_batch_tokenize_begin.argtypes = [vp, vp]
     L.scalce_batch_tokenize_sweep.argtypes = [vp, vp, C.POINTER(i32), vp]
     L.scalce_batch_tokenize_end.argtypes = [vp, vp]
+    L.scalce_batch_tokenize_settle.argtypes = [vp, vp, vp]
     L.scalce_batch_set_chunks.argtypes = [vp, C.POINTER(u64), C.c_uint32]
     L.scalce_batch_entropy_stream.argtypes = [vp, i32, vp, vp, u64, vp]
     L.scalce_ac_scale.argtypes = [vp, vp, C.c_uint32, vp, vp]
@@ -433,6 +434,9 @@ class Batch:
         ch = C.c_int(0)
         self._check(self.L.scalce_batch_tokenize_sweep(self.h, d_prior_counts, C.byref(ch), stream))
         return ch.value
+
+    def tokenize_settle(self, d_prior_counts=None, stream=0):
+        self._check(self.L.scalce_batch_tokenize_settle(self.h, d_prior_counts, stream))
 
     def tokenize_end(self, stream=0):
         self._check(self.L.scalce_batch_tokenize_end(self.h, stream))
