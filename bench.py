@@ -133,7 +133,7 @@ def main():
     if G is None:
         G = 3 if sharded else 4
     G = max(1, G)
-    D = max(1, args.inflight) if args.inflight is not None else (2 * G if sharded else 3 * G)
+    D = max(1, args.inflight) if args.inflight is not None else (2 * G if sharded else 3 * G + 2)
     if G > 1:
         D = max(D, 2 * G)
     if sharded and "SCALCE_AC_BLOCKS_PER_WG" not in os.environ and D < 3 * G:

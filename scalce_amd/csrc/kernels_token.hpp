@@ -640,6 +640,126 @@ __global__ __launch_bounds__(1024) void tie_window_tail_k(TieWinState *st, u32 n
   for (u32 i = lo; i < hi; i++) { P64[i] = run; run += (u32)__popcll(bits[i]); }
   if (threadIdx.x == 0) st->changed = 0;
 }
+// One launch per sweep.  tie_window_tail_k is a launch of its own only because what it computes -- the ranks of the window's
+// words, and at the end of a window its choices folded into `base` -- must be the same for every workgroup of the next
+// sweep.  But it is little: a window's bitmap is a few thousand words.  Here EVERY workgroup of a sweep derives it again
+// for itself, into LDS: it reads what the launch before left behind (did anything move? which window?), and
+//   * something moved: the same window again -- ranks of its words from the bitmap as it stands now;
+//   * nothing moved: the window is settled.  The ranks of ITS words give each of its cells' totals; the workgroup goes on
+//     to the next window, whose own bitmap is still empty (nobody has chosen), so a candidate's count is
+//     base + the settled window's total of its bucket.  Workgroup 0 writes base + totals to the other copy of `base`.
+// No workgroup waits for another; what a launch leaves for the next one (changed flag, window, which copy of `base`) lives
+// in slots indexed by the launch number, so that nothing a late workgroup still reads is overwritten by an early one.
+struct TieFusedState { u32 changed[3]; u32 window[2]; u32 base_sel[2]; u32 sweeps; };
+struct TieFusedArgs {
+  TieWinArgs a;          // (a.base, a.P64, a.st unused)
+  u32 n;                 // launch number, from 0
+  u32 nwin, nb1, lds_words;
+  const u32 *cellstart;
+  u32 *base2;            // [2][nb1]
+  TieFusedState *fs;
+};
+constexpr int TWF_THREADS = 1024;
+__global__ __launch_bounds__(TWF_THREADS) void tie_window_fused_k(TieFusedArgs g) {
+  extern __shared__ u64 snap[];  // the words of one window as this workgroup found them, and (behind them) their ranks
+  __shared__ u32 sm[16];
+  const TieWinArgs &a = g.a;
+  const u32 n = g.n, prev = (n + 2) % 3;
+  const u32 moved = g.fs->changed[prev];
+  const u32 w = g.fs->window[(n + 1) & 1];
+  const u32 sel = g.fs->base_sel[(n + 1) & 1];
+  const bool first_wg = blockIdx.x == 0;
+  if (w >= g.nwin) {  // all windows settled: hand the state on as it is
+    if (first_wg && threadIdx.x == 0) { g.fs->window[n & 1] = w; g.fs->base_sel[n & 1] = sel; }
+    return;
+  }
+  if (first_wg && threadIdx.x == 0) { g.fs->changed[(n + 1) % 3] = 0; g.fs->sweeps++; }  // (read by nobody in this launch)
+  // Window `w` -- the one to sweep again, or the one that has just settled: a copy of its words, then their ranks.  Both
+  // come from ONE reading of the bitmap, so a count taken from them is exact for every cell whose flags are no longer
+  // moving, whatever other workgroups do to other cells meanwhile: a tie read whose predecessors are settled is decided
+  // right in every sweep, and the settled prefix of a window only grows.
+  const u32 w0 = g.cellstart[(u64)w * g.nb1] >> 6, w1 = g.cellstart[(u64)(w + 1) * g.nb1] >> 6;
+  const u32 nw = w1 - w0 + 1, per = (nw + TWF_THREADS - 1) / TWF_THREADS;
+  u32 *pre = reinterpret_cast<u32 *>(snap + g.lds_words);
+  {
+    const u32 lo = threadIdx.x * per, hi = lo + per < nw ? lo + per : nw;
+    u32 mine = 0;
+    for (u32 i = lo; i < hi; i++) {
+      const u64 x = a.bits[w0 + i];
+      snap[i] = x;
+      mine += (u32)__popcll(x);
+    }
+    u32 tot;
+    u32 run = block_exclusive_sum<u32, 16>(mine, &tot, sm);
+    for (u32 i = lo; i < hi; i++) { pre[i] = run; run += (u32)__popcll(snap[i]); }
+  }
+  __syncthreads();
+  auto rank = [&](u32 e) -> u32 {  // chosen flags of the window in front of place e
+    const u32 wd = (e >> 6) - w0;
+    return pre[wd] + (u32)__popcll(snap[wd] & ((1ull << (e & 63u)) - 1ull));
+  };
+  const u32 *base_in = g.base2 + (u64)sel * g.nb1;
+  const bool settled = moved == 0;
+  if (settled) {
+    if (first_wg) {  // the settled window's choices count for every window behind it
+      u32 *base_out = g.base2 + (u64)(1 - sel) * g.nb1;
+      for (u32 b = threadIdx.x; b < g.nb1; b += TWF_THREADS) {
+        const u64 cell = (u64)w * g.nb1 + b;
+        const u32 cs = g.cellstart[cell], ce = g.cellstart[cell + 1];
+        base_out[b] = base_in[b] + (ce > cs ? rank(ce) - rank(cs) : 0u);
+      }
+    }
+    if (first_wg && threadIdx.x == 0) { g.fs->window[n & 1] = w + 1; g.fs->base_sel[n & 1] = 1 - sel; }
+    if (w + 1 >= g.nwin) return;
+  } else if (first_wg && threadIdx.x == 0) {
+    g.fs->window[n & 1] = w;
+    g.fs->base_sel[n & 1] = sel;
+  }
+  const u32 wt = settled ? w + 1 : w;  // the window whose tie reads are evaluated now
+  const u32 local = blockIdx.x * TWF_THREADS + threadIdx.x;
+  const u64 t64 = (u64)wt * a.W + local;
+  if (local >= a.W || t64 >= a.ntie) return;
+  const u32 t = (u32)t64;
+  const u32 off = a.tie_off[t], k = a.tie_ncand[t];
+  if (k == 0) { a.choice[t] = 0; return; }
+  u32 best = 0;
+  u64 bestc = 0;
+  for (u32 j = 0; j < k; j++) {
+    const u32 bk = a.cand_bucket[off + j];
+    u64 c = (a.prior ? a.prior[bk] : 0ull) + (u64)a.fixed_before[off + j] + (u64)base_in[bk];
+    if (settled) {  // first sweep of a window: its own bitmap is empty; the window in front of it is not in `base` yet
+      const u64 cell = (u64)w * g.nb1 + bk;
+      const u32 cs = g.cellstart[cell], ce = g.cellstart[cell + 1];
+      if (ce > cs) c += (u64)(rank(ce) - rank(cs));
+    } else {
+      c += (u64)(rank(a.wpos[off + j]) - rank(a.rs[off + j]));
+    }
+    if (j == 0 || c > bestc) {  // strict: an earlier candidate keeps the bucket on equal counts
+      best = j;
+      bestc = c;
+    }
+  }
+  const u32 old = a.choice[t];
+  if (best != old) {
+    if (old != TW_NONE) { const u32 e = a.wpos[off + old]; atomicAnd(&a.bits32[e >> 5], ~(1u << (e & 31u))); }
+    const u32 e = a.wpos[off + best];
+    atomicOr(&a.bits32[e >> 5], 1u << (e & 31u));
+    a.choice[t] = best;
+    g.fs->changed[n % 3] = 1;  // plain store: every writer stores the same value
+  }
+}
+// words of the largest window (sizes the LDS of tie_window_fused_k)
+__global__ __launch_bounds__(256) void tw_maxwin_k(u32 nwin, u32 nb1, const u32 *cellstart, u32 *out /* zeroed */) {
+  const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < nwin) atomicMax(out, (cellstart[(u64)(w + 1) * nb1] >> 6) - (cellstart[(u64)w * nb1] >> 6) + 1);
+}
+// after the last launch: base of the copy in use -> counts
+__global__ __launch_bounds__(256) void twf_counts_k(u32 nb1, const u32 *fixed_total, const u32 *base2, const TieFusedState *fs, u32 last_n,
+                                                   u64 *counts) {
+  const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb1) counts[b] = (u64)fixed_total[b] + (u64)base2[(u64)fs->base_sel[last_n & 1] * nb1 + b];
+}
+
 __global__ __launch_bounds__(256) void tw_counts_k(u32 nb1, const u32 *fixed_total, const u32 *base, u64 *counts) {
   const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb1) counts[b] = (u64)fixed_total[b] + (u64)base[b];

@@ -1151,7 +1151,7 @@ extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
 // when the sweeps allowed (tie_max_sweeps() per window) did not get through: the caller decides in input order instead.
 static u32 tie_window_reads() {
   const char *e = getenv("SCALCE_TIE_WINDOW");  // tie reads per window; 0 = the global sweeps (jacobi_k)
-  const long v = e ? atol(e) : 131072;
+  const long v = e ? atol(e) : 196608;
   return (u32)(v < 0 ? 0 : v > (1l << 30) ? (1l << 30) : v);
 }
 static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *settled, hipStream_t s) {
@@ -1175,7 +1175,7 @@ static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *sett
   ENSURE(b, b->tw_cells, sizeof(u32) * (3 * ncells + 8));
   ENSURE(b, b->tw_cand, sizeof(u32) * (2 * (u64)ncap + 8));
   ENSURE(b, b->tw_bits, (sizeof(u64) + sizeof(u32)) * nwords);
-  ENSURE(b, b->tw_base, sizeof(u32) * ((u64)nb1 + 16));
+  ENSURE(b, b->tw_base, sizeof(u32) * (2 * (u64)nb1 + 64));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(ncells) + 1024));
   u32 *first_delta = b->tw_cells.as<u32>(), *cell_end = first_delta + ncells, *cellstart = cell_end + ncells + 2;  // cellstart[ncells] = all candidates
   u32 *wpos = b->tw_cand.as<u32>(), *rs = wpos + ncap + 2;
@@ -1187,7 +1187,7 @@ static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *sett
   u32 *key_c = b->G.as<u32>();  // (the global sweeps' prefix sums: not in use here)
   HIP_TRY(c, hipMemsetAsync(first_delta, 0, sizeof(u32) * 2 * ncells, s));  // empty cells: first = end = 0
   HIP_TRY(c, hipMemsetAsync(bits, 0, (sizeof(u64) + sizeof(u32)) * nwords, s));
-  HIP_TRY(c, hipMemsetAsync(base, 0, sizeof(u32) * ((u64)nb1 + 16), s));  // (and the state behind it)
+  HIP_TRY(c, hipMemsetAsync(base, 0, sizeof(u32) * (2 * (u64)nb1 + 64), s));  // (and the state behind it)
   HIP_TRY(c, hipMemsetAsync(b->choice.p, 0xFF, sizeof(u32) * ntie, s));   // nobody has chosen yet
   LAUNCH(tw_key_k, cdiv(ntie, 256), 256, 0, s, ntie, W, nb1, b->tie_off.as<u32>(), b->tie_ncand.as<u32>(), b->cand_bucket.as<u32>(),
          b->cand_place.as<u32>(), key_c);
@@ -1203,6 +1203,45 @@ static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *sett
   // A window settles in a handful of sweeps when sweeping works at all (the last one moves nothing), so the sweeps go out in
   // batches sized for the windows still open, and the host looks at the device's state once per batch.
   const u64 budget = (u64)tie_max_sweeps() * nwin;
+  // one launch per sweep (tie_window_fused_k) when a window's words and their ranks fit a workgroup's LDS
+  if (!getenv("SCALCE_TIE_TWO_LAUNCHES")) {
+    TieFusedState *fs = reinterpret_cast<TieFusedState *>(base + 2 * (u64)nb1 + 16);
+    u32 *maxw_d = base + 2 * (u64)nb1 + 32;
+    LAUNCH(tw_maxwin_k, cdiv(nwin, 256), 256, 0, s, nwin, nb1, cellstart, maxw_d);
+    u32 maxw = 0;
+    { int rc = read_u32(b, maxw_d, &maxw, 1, s); if (rc) return rc; }
+    const size_t lds = (size_t)(maxw + 2) * 12;
+    if (lds <= 140 * 1024) {
+      if (lds > 48 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(tie_window_fused_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      static const u32 one = 1;
+      HIP_TRY(c, hipMemcpyAsync(&fs->changed[2], &one, sizeof(u32), hipMemcpyHostToDevice, s));  // launch 0: "something moved": sweep window 0
+      TieFusedArgs g;
+      g.a = a; g.nwin = nwin; g.nb1 = nb1; g.lds_words = maxw + 2; g.cellstart = cellstart; g.base2 = base; g.fs = fs;
+      const u32 fgrid = cdiv(W < ntie ? W : ntie, TWF_THREADS);
+      u32 n = 0;
+      TieFusedState h;
+      memset(&h, 0, sizeof h);
+      for (;;) {
+        if (h.sweeps >= budget) { b->jacobi_iters = h.sweeps; return SCALCE_OK; }  // not settled
+        const u32 win_now = n ? h.window[(n - 1) & 1] : 0u;
+        u64 batch = 4ull * (nwin - win_now) + 4;
+        if (batch > 256) batch = 256;
+        if (batch > budget - h.sweeps) batch = budget - h.sweeps;
+        for (u64 i = 0; i < batch; i++) {
+          g.n = n++;
+          LAUNCH(tie_window_fused_k, fgrid, TWF_THREADS, lds, s, g);
+        }
+        int rc = read_u32(b, reinterpret_cast<const u32 *>(fs), reinterpret_cast<u32 *>(&h), 8, s);
+        if (rc) return rc;
+        if (h.window[(n - 1) & 1] >= nwin) break;
+      }
+      b->jacobi_iters = h.sweeps;
+      LAUNCH(twf_counts_k, cdiv(nb1, 256), 256, 0, s, nb1, fixed_total, base, fs, n - 1, b->counts.as<u64>());
+      *settled = true;
+      return SCALCE_OK;
+    }
+  }
   const u32 grid = cdiv(W < ntie ? W : ntie, 256);
   TieWinState h{0, 0, 0, 0};
   while (!h.finished) {
@@ -1752,12 +1791,24 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
 }
 
 // framing: sizes -> offsets -> [u32 size][bytes] per block, all enqueued; the total is read back by entropy_collect
+static bool frames_at_collect() {
+  static const bool v = getenv("SCALCE_AC_FRAME_BEHIND_CODER") == nullptr;
+  return v;
+}
 static int ac_frame(AcJob &j, hipStream_t s) {
   scalce_batch *b = j.b;
   const int m = j.m;
   if (!j.nblk) return SCALCE_OK;
   exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, j.nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->ac_scan.as<u64>(),
                       b->d_small64 + 8 + m, s);
+  if (b->out_qual[m].cap < (size_t)j.nblk * (AC_STRIDE + 4) + 64) {
+    // the framed stream was not sized for the worst case (a grouped launch: twelve and more shards in flight, and 5 GB each
+    // of a capacity that is little more than half used is a shard less in flight): the size comes back first -- the coder has
+    // finished, this is a wait of microseconds -- and the buffer grows when a shard codes worse than any before it
+    u64 total = 0;
+    { int rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s); if (rc) return rc; }
+    if (b->out_qual[m].cap < total + 64) ENSURE(b, b->out_qual[m], (size_t)(total + total / 16) + (32u << 20));
+  }
   LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), j.nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), AC_STRIDE,
          b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
   b->ent_pending[m] = j.nblk;
@@ -1957,7 +2008,7 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
       AcJob j{b, m, b->ent_external[m] ? b->ent_sym[m] : b->qs[m].as<u8>(), b->ent_external[m] ? b->ent_nsym[m] : own, 0, false};
       if (!b->ent_external[m]) { int rc = ac_table_for(b, m, nullptr, own, ps); if (rc) return rc; }
       b->ent_external[m] = false;
-      int rc = ac_prepare(j, ps);
+      int rc = ac_prepare(j, ps, /*framed_output=*/!frames_at_collect());
       if (rc) return rc;
       jobs.push_back(j);
     }
@@ -1979,7 +2030,7 @@ extern "C" int scalce_batch_entropy_begin_group(scalce_batch **bs, int n, void *
   // idle chip) is left to entropy_collect, i.e. to the stream the caller collects on.  Behind the coder on its own stream
   // (SCALCE_AC_FRAME_BEHIND_CODER=1) it was measured slower with one coder stream (it lengthens the launch the pipeline
   // waits for) and with three (95.6 against 93.0 ms per shard).
-  static const bool at_collect = getenv("SCALCE_AC_FRAME_BEHIND_CODER") == nullptr;
+  const bool at_collect = frames_at_collect();
   for (auto &j : jobs) {
     if (at_collect) { j.b->frame_deferred[j.m] = j.nblk; continue; }
     rc = ac_frame(j, s);
