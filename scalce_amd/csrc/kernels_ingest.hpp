@@ -509,6 +509,10 @@ struct Ingest2Args {
   u64 magic_s, magic_w;   // ceil(2^32 / S), ceil(2^32 / W): S = words per packed row, W = 16-symbol units per read
   u32 step_ks, step_rs, step_kw, step_rw;  // 256 / S, 256 % S, 256 / W, 256 % W
   u16 *tile_minmax;       // per tile: min | max << 8 of its q' symbols (255 | 0 << 8: none), or null
+  // LOOKBACK (no count pass in front): ticket counter and one status word per tile, both zeroed; the tiles' line bases out
+  u32 *ticket;
+  u64 *status;
+  u64 *tile_base_out;
 };
 constexpr u32 ING2_RECMAX = ING_NLMAX / 4 + 4;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -523,6 +527,13 @@ __device__ __forceinline__ u32 lds_fetch_u32(const u8 *text, u32 at) {  // unali
   const u32 *p = reinterpret_cast<const u32 *>(text + (at & ~3u));
   return __builtin_amdgcn_alignbyte(p[1], p[0], at & 3u);
 }
+// LOOKBACK: no count pass in front (index_count_k read the whole text once more for the tiles' line bases).  The tiles are
+// taken in ticket order; a workgroup publishes the newline count of its tile as soon as it has it and adds up what the
+// tiles in front of it have published -- their counts, down to the first one that already knows its own base (decoupled
+// look-back: one 8-byte word {state, value} per tile, written by one store, polled by wave 0, 64 tiles at a time).  A tile
+// only ever waits for tiles with smaller tickets, and those are running or done.
+constexpr u64 LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1;
+template <bool LOOKBACK>
 __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   const IngestArgs &a = g.i;
   __shared__ __attribute__((aligned(16))) u8 text[ING_TILE + ING_OVER + 32];
@@ -532,8 +543,16 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   __shared__ u32 sm[ING_THREADS / 64];
   __shared__ u32 s_count[2];
   __shared__ u32 s_mm[2 * (ING_THREADS / 64)];
+  __shared__ u64 s_g0;
+  __shared__ u32 s_ticket;
   const int tid = threadIdx.x;
-  const u64 t0 = (u64)blockIdx.x * ING_TILE;                       // text offset of the tile
+  u32 ti = blockIdx.x;                                             // the tile
+  if (LOOKBACK) {
+    if (tid == 0) s_ticket = atomicAdd(g.ticket, 1u);
+    __syncthreads();
+    ti = s_ticket;
+  }
+  const u64 t0 = (u64)ti * ING_TILE;                               // text offset of the tile
   const u64 avail = a.u.nbytes - t0;
   const u32 len = (u32)(avail < ING_TILE + ING_OVER ? avail : ING_TILE + ING_OVER);
   if (tid < 128) lut[tid] = a.u.qlut[tid];
@@ -570,12 +589,40 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
       at++;
     }
     base += tot;
+    if (LOOKBACK && part == 0 && wave_id() == 0) {  // the tile's own count is known: publish it, then add up the tiles in front
+      const int lane = lane_id();
+      unsigned long long *st = reinterpret_cast<unsigned long long *>(g.status);
+      u64 excl = 0;
+      if (ti == 0) {
+        if (lane == 0) __hip_atomic_store(&st[0], LB_PREFIX | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (lane == 0) __hip_atomic_store(&st[ti], LB_AGG | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (long long j = (long long)ti - 1;;) {
+          const long long idx = j - lane;
+          const u64 v = idx >= 0 ? (u64)__hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;  // in front of tile 0: nothing
+          const u64 not_ready = __ballot((v >> 62) == 0), has_prefix = __ballot((v >> 62) == 2);
+          const int first_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : 64;
+          const int first_missing = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+          if (first_missing < first_prefix) { __builtin_amdgcn_s_sleep(2); continue; }  // a tile in front has not counted yet
+          u64 mine = lane <= first_prefix ? (v & LB_MASK) : 0ull;
+          for (int o = 32; o; o >>= 1) mine += (u64)__shfl_xor((long long)mine, o);
+          excl += mine;
+          if (first_prefix < 64) break;
+          j -= 64;
+        }
+        if (lane == 0) __hip_atomic_store(&st[ti], LB_PREFIX | (excl + (u64)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (lane == 0) {
+        s_g0 = excl;
+        g.tile_base_out[ti] = excl;   // (index_write_k wants the line bases when a name is longer than a cell)
+      }
+    }
   }
   if (tid == 0) { s_count[0] = base; }
   __syncthreads();
   const u32 count = s_count[0];
   if (count > ING_NLMAX) { if (tid == 0) atomicExch(a.slow, 1u); return; }
-  const u64 G0 = a.tile_base[(u64)blockIdx.x * (ING_TILE / IDX_TILE)];
+  const u64 G0 = LOOKBACK ? s_g0 : a.tile_base[(u64)ti * (ING_TILE / IDX_TILE)];
   const bool starts_line = t0 == 0 || a.u.text[t0 - 1] == '\n';
   const u32 jmin = starts_line ? 0u : 1u;
   const u32 j0 = jmin + (u32)((4 - ((G0 + jmin) & 3)) & 3);         // first name line that starts here
@@ -755,7 +802,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   if (lane_id() == 0) { s_mm[2 * wave_id()] = lo; s_mm[2 * wave_id() + 1] = hi; }
   __syncthreads();  // (also: the q' rows of the tile are written)
   for (int w = 0; w < ING_THREADS / 64; w++) { lo = min(lo, s_mm[2 * w]); hi = max(hi, s_mm[2 * w + 1]); }
-  if (tid == 0 && g.tile_minmax) g.tile_minmax[blockIdx.x] = (u16)(lo | (hi << 8));
+  if (tid == 0 && g.tile_minmax) g.tile_minmax[ti] = (u16)(lo | (hi << 8));
   if (hi >= 80 && !a.u.no_ac) {  // a symbol the coder's tables have no row for (arithmetic.h:47): which record was it?
     for (u32 k = (u32)tid; k < ntake; k += ING_THREADS) {
       if (rec_sb[k] == 0xFFFFu) continue;

@@ -632,11 +632,30 @@ static int ensure_line_index(scalce_batch *b, int mate, hipStream_t s) {
 }
 
 // the first `nrec` records of the text -> rows [base, base + nrec): 2-bit bases, q', names
-static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s) {
+// lines_out != null: the piece has not been counted (piece_count): `nrec` is the capacity in rows, the ingest kernel finds
+// the tiles' line bases itself (ingest_tiles2_k<true>) and *lines_out / *last_out are the text's line count and last byte
+// Measured at 50 M x 100 bp (10.2 GB of text): count pass 1.7 ms + ingest 6.2 ms against 9.2 ms for the one-pass kernel -- a
+// workgroup's wait for the tiles in front of it (they publish their counts at about the same time as it does, so the sum
+// is three polling rounds away) costs more than reading the text a second time at 6 TB/s.  Off unless SCALCE_INGEST_LOOKBACK=1.
+static bool ingest_lookback_ok(const scalce_batch *b, int mate) {
+  const int L = b->L[mate];
+  return getenv("SCALCE_INGEST_LOOKBACK") && L >= 16 && L <= 160 && !getenv("SCALCE_INGEST_INDEXED") && !getenv("SCALCE_INGEST_PAIRS");
+}
+static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s, u64 *lines_out = nullptr,
+                        u8 *last_out = nullptr) {
   scalce_ctx *c = b->ctx;
   b->piece_text[mate] = d_text;
   b->line_index_ok[mate] = false;
   b->piece_consumed[mate] = 0;
+  const bool lookback = lines_out != nullptr;
+  if (lookback) {
+    *lines_out = 0;
+    *last_out = '\n';
+    if (((uintptr_t)d_text & 15) != 0) { set_err(c, "FASTQ text must be 16-byte aligned"); return SCALCE_ERR_ARG; }
+    if (nbytes > b->max_text) b->max_text = nbytes;
+    b->text_bytes[mate] = nbytes;
+    if (!nbytes) return SCALCE_OK;
+  }
   if (!nrec) return SCALCE_OK;
   UnpackArgs a;
   a.text = d_text; a.nbytes = nbytes; a.line_end = nullptr; a.nrec = nrec;
@@ -664,6 +683,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
     ia.consumed = d_consumed;
     ia.slow = slow;
     if (getenv("SCALCE_INGEST_PAIRS")) {  // two threads per record (comparisons)
+      if (lookback) { set_err(c, "internal: ingest path"); return SCALCE_ERR_ARG; }
       LAUNCH(ingest_tiles_k, cdiv(nbytes, ING_TILE), ING_THREADS, 0, s, ia);
     } else {
       const u32 ntiles2 = cdiv(nbytes, ING_TILE);
@@ -676,10 +696,37 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
       ga.step_ks = (u32)(ING_THREADS / S); ga.step_rs = (u32)(ING_THREADS % S);
       ga.step_kw = (u32)(ING_THREADS / W); ga.step_rw = (u32)(ING_THREADS % W);
       ga.tile_minmax = b->tile_mm[mate].as<u16>();
-      LAUNCH(ingest_tiles2_k, ntiles2, ING_THREADS, 0, s, ga);
+      ga.ticket = nullptr; ga.status = nullptr; ga.tile_base_out = nullptr;
+      if (lookback) {
+        ENSURE(b, b->tile[mate], (ntiles2 + 8) * sizeof(u64));
+        ENSURE(b, b->scan_ws, ((size_t)ntiles2 + 64) * sizeof(u64));
+        ga.ticket = b->d_small + 18;
+        ga.status = b->scan_ws.as<u64>();
+        ga.tile_base_out = b->tile[mate].as<u64>();
+        ga.i.tile_base = nullptr;
+        HIP_TRY(c, hipMemsetAsync(ga.ticket, 0, sizeof(u32), s));
+        HIP_TRY(c, hipMemsetAsync(ga.status, 0, sizeof(u64) * ntiles2, s));
+        LAUNCH(ingest_tiles2_k<true>, ntiles2, ING_THREADS, 0, s, ga);
+        HIP_TRY(c, hipMemcpyAsync(lines_out, ga.status + (ntiles2 - 1), sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(last_out, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, s));
+      } else {
+        LAUNCH(ingest_tiles2_k<false>, ntiles2, ING_THREADS, 0, s, ga);
+      }
       b->mm_valid[mate] = true;
     }
     { int rc = read_u32(b, b->d_small + 16, flags, 2, s); if (rc) return rc; }
+    if (lookback) {
+      *lines_out &= LB_MASK;
+      // what the count pass would have said before anything was unpacked: the caller reports it; nothing below may run on
+      // a text that is not whole records, or on more records than the batch has rows for
+      if ((*lines_out & 3) || *last_out != '\n' || *lines_out / 4 > nrec) return SCALCE_OK;
+      nrec = *lines_out / 4;
+      a.nrec = nrec;
+      if (mate == 0) b->N = b->NP = nrec;  // (the line index and the long-name store below are sized by it)
+      else if (nrec != b->N) return SCALCE_OK;  // mates of different length: the caller's error
+      b->piece_consumed[mate] = nbytes;
+      if (!nrec) return SCALCE_OK;
+    }
     if (flags[1]) { fused = false; b->mm_valid[mate] = false; }  // a record longer than the overlap: redo the piece the indexed way
   }
   if (!fused) {
@@ -692,7 +739,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
     LAUNCH(last_record_end_k, 1, 1, 0, s, a.line_end, nrec, d_consumed);
     { int rc = read_u32(b, b->d_small + 16, flags, 1, s); if (rc) return rc; }
   }
-  { u64 v = 0; int rc = read_u64(b, d_consumed, &v, 1, s); if (rc) return rc; b->piece_consumed[mate] = v; }
+  if (!lookback) { u64 v = 0; int rc = read_u64(b, d_consumed, &v, 1, s); if (rc) return rc; b->piece_consumed[mate] = v; }
   if (mate == 0 && b->p.use_names) {
     // names that do not fit their 16-byte cell go to the long-name store (input order): the text is not needed again
     const u32 maxlen = flags[0];
@@ -740,6 +787,21 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
   if (mate == 0) batch_restart(b);  // one piece = the whole shard
   u64 nlines = 0;
   u8 last = '\n';
+  if (ingest_lookback_ok(b, mate)) {  // one pass: the ingest kernel counts the lines of its tiles itself
+    int rc = piece_unpack(b, mate, d_text, nbytes, b->max_reads, s, &nlines, &last);
+    if (rc) return rc;
+    if ((nlines & 3) || last != '\n' || nlines / 4 > b->max_reads) HIP_TRY(c, hipMemsetAsync(b->d_err, 0, sizeof(DevErr), s));  // (what the kernel made of it)
+    if ((nlines & 3) || last != '\n') {
+      set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)nlines);
+      return SCALCE_ERR_FORMAT;
+    }
+    const u64 nrec1 = nlines / 4;
+    if (nrec1 > b->max_reads) { set_err(c, "%llu records exceed the batch capacity", (unsigned long long)nrec1); return SCALCE_ERR_CAPACITY; }
+    if (mate == 0) { b->N = b->NP = nrec1; }
+    else if (nrec1 != b->N) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
+    b->ingested[mate] = true;
+    return SCALCE_OK;
+  }
   { int rc = piece_count(b, mate, d_text, nbytes, s, &nlines, &last); if (rc) return rc; }
   HIP_TRY(c, hipStreamSynchronize(s));
   if ((nlines & 3) || last != '\n') {

@@ -685,10 +685,12 @@ def test_lanes_coder_block_edges(nsym, ctx, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["indexed_kernels", "records_longer_than_the_overlap", "short_reads_L16", "tile_edges",
-                                  "tile_edges_record_pairs", "odd_length_L75", "short_reads_L16_record_pairs"])
+                                  "tile_edges_record_pairs", "odd_length_L75", "short_reads_L16_record_pairs",
+                                  "tile_edges_lookback", "records_longer_than_the_overlap_lookback", "short_reads_L16_lookback"])
 def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
     """The ingest stage reads the text once behind the newline count (ingest_tiles2_k: 16 KB tiles + 1 KB overlap in LDS,
-    the unpack dealt to the lanes word by word; SCALCE_INGEST_PAIRS=1: ingest_tiles_k, two threads per record) and
+    the unpack dealt to the lanes word by word; lookback: no count pass, the tiles' line bases by look-back between the
+    workgroups; SCALCE_INGEST_PAIRS=1: ingest_tiles_k, two threads per record) and
     falls back to the indexed kernels (index_write_k + unpack_tiled_k) for read lengths outside 16..160 or when a record
     does not fit the overlap.  All paths, the fallback trigger, the shortest fused read length, a read length that is not
     a multiple of four and records that straddle tile boundaries in every phase against the oracle."""
@@ -702,9 +704,11 @@ def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
     bases, quals = synth.reads_and_quals(n, L, seed=55, n_frac=0.004, dup_frac=0.1)
     if case.endswith("record_pairs"):
         monkeypatch.setenv("SCALCE_INGEST_PAIRS", "1")
+    if case.endswith("lookback"):      # no count pass in front (index_count_k): the tiles' line bases by look-back inside the ingest kernel
+        monkeypatch.setenv("SCALCE_INGEST_LOOKBACK", "1")
     if case == "indexed_kernels":
         monkeypatch.setenv("SCALCE_INGEST_INDEXED", "1")
-    if case == "records_longer_than_the_overlap":   # names of up to 255 characters, repeated on the '+' line
+    if case.startswith("records_longer_than_the_overlap"):   # names of up to 255 characters, repeated on the '+' line
         recs = []
         for i in range(n):
             nm = b"r%d_" % i + b"x" * int(rng.integers(0, 250 - 8))
