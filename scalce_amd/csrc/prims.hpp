@@ -74,20 +74,26 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T *total, T *smem) {
 
 // ---------------------------------------------------------------------------------------------
 // exclusive scan: out(i) = sum_{j<i} f(j).  Three launches: per-tile sums, spine, downsweep.
-// Each thread owns SCAN_ITEMS consecutive elements (one 64-byte run for u32 input).
+// A workgroup's tile is SCAN_TILE consecutive elements.  Memory is touched in stripes -- instruction i of a thread reads
+// element i * SCAN_THREADS + thread of the tile, so a wavefront's access is one contiguous run -- while the prefix wants
+// every thread to own SCAN_ITEMS consecutive elements: the downsweep turns the tile through LDS (one spare slot per 16
+// keeps both views free of bank conflicts) on the way in and on the way out.  (With each thread reading its own 16
+// consecutive elements from memory, a wavefront's load touched 64 different cache lines per instruction and a scan of
+// 61 M eight-byte keys ran at 0.45 TB/s.)
 // ---------------------------------------------------------------------------------------------
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+__device__ __forceinline__ int scan_slot(int i) { return i + (i >> 4); }
 
 template <typename T, typename F>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_k(F f, u64 n, T *tile_sums) {
   __shared__ T sm[4];
-  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  const u64 base = (u64)blockIdx.x * SCAN_TILE + threadIdx.x;
   T s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++)
-    if (base + i < n) s += f(base + i);
+    if (base + (u64)i * SCAN_THREADS < n) s += f(base + (u64)i * SCAN_THREADS);
   T tot;
   block_exclusive_sum<T, 4>(s, &tot, sm);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
@@ -110,21 +116,35 @@ __global__ __launch_bounds__(1024) void scan_spine_k(T *sums, u32 nb, T *total_o
 
 template <typename T, typename F, typename O>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_down_k(F f, u64 n, const T *tile_offs, O out) {
+  __shared__ T tile[SCAN_TILE + SCAN_TILE / 16];
   __shared__ T sm[4];
-  const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_ITEMS;
+  const u64 base = (u64)blockIdx.x * SCAN_TILE;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const int e = i * SCAN_THREADS + t;
+    tile[scan_slot(e)] = (base + e < n) ? f(base + e) : T(0);
+  }
+  __syncthreads();
   T v[SCAN_ITEMS];
   T s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
-    v[i] = (base + i < n) ? f(base + i) : T(0);
+    v[i] = tile[scan_slot(t * SCAN_ITEMS + i)];
     s += v[i];
   }
   T tot;
   T run = tile_offs[blockIdx.x] + block_exclusive_sum<T, 4>(s, &tot, sm);
 #pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; i++) {
-    if (base + i < n) out(base + i, run);
+  for (int i = 0; i < SCAN_ITEMS; i++) {  // (a thread's own slots: nobody else reads them before the barrier)
+    tile[scan_slot(t * SCAN_ITEMS + i)] = run;
     run += v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; i++) {
+    const int e = i * SCAN_THREADS + t;
+    if (base + e < n) out(base + e, tile[scan_slot(e)]);
   }
 }
 
