@@ -46,8 +46,8 @@ def pmc(fd, wd, out, shards=None):
     fe, calls = counters(fd, "FETCH_SIZE")
     wr, _ = counters(wd, "WRITE_SIZE")
     rows = [{"kernel": k, "calls": calls[k], "FETCH_SIZE_KB": fe[k], "WRITE_SIZE_KB": wr.get(k, 0.0)} for k in fe]
-    if shards is None:  # one ingest_tiles_k call per shard that went through the front stages
-        shards = next((r["calls"] for r in rows if "ingest_tiles_k" in r["kernel"]), None)
+    if shards is None:  # one ingest_tiles call per shard that went through the front stages
+        shards = next((r["calls"] for r in rows if "ingest_tiles" in r["kernel"]), None)
     if shards:  # shards the profiled run pushed through every stage (a coder launch may hold several)
         for r in rows:
             r["shards"] = shards
