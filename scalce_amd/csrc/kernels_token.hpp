@@ -151,82 +151,83 @@ __global__ __launch_bounds__(TOK_THREADS) void tokenize_kmer_k(TokArgs a) {
   a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
 }
 
-// tokenize_kmer_k spends its time WAITING: the lanes of a wave diverge over its four ways to a transition (global row,
-// 8-mer bit table, rank, 7-mer table) and the compiler walks them one after the other, each behind its own s_waitcnt,
-// with the output word of the new state (another global gather) behind that -- ~1200 cycles per base per wave, whatever
-// the lanes do, and 24 waves per CU to hide them.  Here every lane issues ALL lookups of a base at once -- the table
-// lookups do not depend on the state, only the choice between them does --, there is ONE wait per base, and the output
-// word of the state reached is consumed a base later (it is not needed to go on).  The global loads are inline asm so
-// that the wait can stand where it belongs (the compiler's own bookkeeping drains the queue at every loop back-edge).
+// tokenize_kmer_k is bound by instruction issue (44 per base at 50 M x 100 bp): the lanes of a wave diverge over its four
+// ways to a transition (global row, 8-mer bit table, rank, 7-mer table) and the compiler walks them one after the other,
+// each behind its own s_waitcnt, with the output word of the new state (another global gather) behind that.  Here a base is
+// straight-line code: every lane issues ALL lookups of a base at once -- the table lookups do not depend on the state, only
+// the choice between them does; lanes that do not need the global row read row 0 (one line for the whole wave) --, the
+// bases of a 16-base word are unrolled (codes come from the byte-swapped words with one v_alignbit), and the output word of
+// the state reached is asked for at once and consumed a base later by arithmetic that treats "no output" as a word of 0.
+// No load sits behind a branch, so the compiler's own s_waitcnt counts them (a first version issued them from inline asm
+// behind branches: the register allocator copied a destination register before the load had landed).
 // 1024 threads per workgroup: two workgroups = the CU's 32 waves share two copies of the tables.
 constexpr int TOKP_THREADS = 1024;
-__device__ __forceinline__ u32 tokp_load(const u32 *p) {
-  u32 v;
-  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ void tokp_wait(u32 &x, u32 &y) {  // both loads have landed (and the compiler may not look at them earlier)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(x), "+v"(y)::"memory");
-}
+// T7_OUT: some state of depth <= 7 has an output (a core shorter than 8 bases): the 7-mer table's entries then carry a flag
+template <bool T7_OUT>
 __global__ __launch_bounds__(TOKP_THREADS) void tokenize_kmer_pipe_k(TokArgs a) {
-  __shared__ u32 tab[KMER_WORDS];
-  for (u32 i = threadIdx.x; i < KMER_WORDS; i += TOKP_THREADS) tab[i] = a.kmer[i];
+  // LDS: the 7-mer table as it comes (16 384 x u16) and, per 32 8-mers, ONE 16-byte entry {node bits, output bits,
+  // first state of depth 8 + nodes in front of the group} -- one read per base instead of three
+  __shared__ u32 t7w[KMER_T7_WORDS];
+  __shared__ uint4 g8[KMER_BITS_WORDS];
+  {
+    const u32 *bits8 = a.kmer + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
+    const u16 *rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+    for (u32 i = threadIdx.x; i < KMER_T7_WORDS; i += TOKP_THREADS) t7w[i] = a.kmer[i];
+    for (u32 i = threadIdx.x; i < KMER_BITS_WORDS; i += TOKP_THREADS) g8[i] = make_uint4(bits8[i], out8[i], a.id8_first + rank8[i], 0u);
+  }
   __syncthreads();
-  const u16 *t7 = reinterpret_cast<const u16 *>(tab);
-  const u32 *bits8 = tab + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
-  const u16 *rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+  const u16 *t7 = reinterpret_cast<const u16 *>(t7w);
   const u64 r = (u64)blockIdx.x * TOKP_THREADS + threadIdx.x;
   if (r >= a.nrec) return;
   const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
-  const u32 *next = reinterpret_cast<const u32 *>(a.next);
+  const char *next_b = reinterpret_cast<const char *>(a.next), *out_b = reinterpret_cast<const char *>(a.outinfo);  // (+ 32-bit byte offsets)
   const u32 id8 = a.id8_first;
-  u32 state = 0, best_lv = 0, best_b = a.root_bucket, best_pos = 0, hits = 0, tie = 0, code = 0;
-  u32 pend = 0, pend_pos = 0, pend_info = 0;
-  auto settle = [&]() {  // the output of the state reached a base ago
-    if (pend) {
-      const u32 lv = pend_info >> kLevelShiftD, b = pend_info & kBucketMaskD;
-      if (lv > best_lv) {
-        best_lv = lv; best_b = b; best_pos = pend_pos; hits = 1; tie = 0;
-      } else if (lv == best_lv) {
-        hits++;
-        if (b != best_b) tie = 1;
-      }
-    }
+  // the best core so far as its output word (level << 25 | bucket); an output word of 0 stands for "no output" and goes
+  // through the same arithmetic: while no core has been seen it only disturbs `hits` and `tie`, which the first real core
+  // resets (levels are lengths, >= 1) and the end clears if there was none
+  u32 state = 0, best_lv = 0, best_info = a.root_bucket, best_pos = 0, hits = 0, tie = 0;
+  u32 pend_raw = 0;   // what the output table holds for the state reached a base ago (asked for then, looked at now) ...
+  bool pend_has = false;  // ... and whether that state has an output at all
+  auto settle = [&](u32 info, u32 pos) {
+    const u32 lv = info >> kLevelShiftD;
+    if (__ballot(lv >= best_lv) == 0) return;  // most outputs are shorter cores than the best one so far: nothing to do
+    const bool gt = lv > best_lv, eq = lv == best_lv, other = info != best_info;
+    hits = gt ? 1u : hits + (eq ? 1u : 0u);
+    tie = gt ? 0u : (tie | ((eq && other) ? 1u : 0u));
+    best_pos = gt ? pos : best_pos;
+    best_info = gt ? info : best_info;
+    best_lv = gt ? lv : best_lv;
   };
   const int nw = (a.L + 15) >> 4;
-  u32 word = tokp_load(row);
-  tokp_wait(word, pend_info);
+  u32 prevs = 0;
   for (int w = 0; w < nw; w++) {
-    u32 word_next = 0;  // (asm as well: a load the compiler knows of makes it drain the queue at the head of every base)
-    if (w + 1 < nw) word_next = tokp_load(row + w + 1);
     const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
-    for (int k = 0; k < cnt; k++) {
-      const int pos = 16 * w + k;
-      const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
-      code = ((code << 2) | c) & 0xFFFFu;  // the last 8 bases, the oldest one in the top bits
-      const bool deep = pos < 7 || state >= id8;
-      u32 tg = 0;
-      if (deep) tg = tokp_load(next + ((u64)state * 4 + c));
-      const u32 i5 = code >> 5, bit = code & 31u;
-      const u32 wd = bits8[i5], ob = out8[i5], rk = rank8[i5], e = t7[code & 0x3FFFu];
-      tokp_wait(tg, pend_info);
-      settle();
-      const u32 t8 = (id8 + rk + (u32)__popc(wd & ((1u << bit) - 1u))) | (((ob >> bit) & 1u) << 31);
-      const u32 t7v = (e & 0x7FFFu) | ((e >> 15) << 31);
-      const u32 tl = ((wd >> bit) & 1u) ? t8 : t7v;
-      const u32 t = deep ? tg : tl;
-      state = t & 0x7FFFFFFFu;
-      pend = t >> 31;
-      pend_pos = (u32)pos;
-      if (pend) pend_info = tokp_load(a.outinfo + state);
+    const u32 curs = __builtin_bswap32(row[w]);  // base 0 of the word in bits 31-30
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < cnt) {
+        const int pos = 16 * w + k;
+        const u32 code = __builtin_amdgcn_alignbit(prevs, curs, 30 - 2 * k) & 0xFFFFu;  // the last 8 bases, the oldest in the top bits
+        const bool deep = pos < 7 || state >= id8;
+        const u32 tg = *reinterpret_cast<const u32 *>(next_b + (deep ? (state << 4) | ((code & 3u) << 2) : 0u));  // (lanes on the table path: row 0, one line for all of them)
+        const uint4 g = g8[code >> 5];
+        const u32 e = t7[code & 0x3FFFu];
+        const u32 bit = code & 31u;
+        settle(pend_has ? pend_raw : 0u, (u32)(pos - 1));
+        const u32 t8 = (g.z + (u32)__popc(g.x & ((1u << bit) - 1u))) | (((g.y >> bit) & 1u) << 31);
+        const u32 t7v = T7_OUT ? (e & 0x7FFFu) | ((e >> 15) << 31) : e;
+        const u32 tl = ((g.x >> bit) & 1u) ? t8 : t7v;
+        const u32 t = deep ? tg : tl;
+        state = t & 0x7FFFFFFFu;
+        pend_has = (t >> 31) != 0;
+        pend_raw = *reinterpret_cast<const u32 *>(out_b + (pend_has ? state << 2 : 0u));
+      }
     }
-    tokp_wait(word_next, pend_info);
-    word = word_next;
+    prevs = curs;
   }
-  u32 none = 0;
-  tokp_wait(pend_info, none);
-  settle();
-  a.tok_bucket[r] = best_b;
+  settle(pend_has ? pend_raw : 0u, (u32)(a.L - 1));
+  if (best_lv == 0) { hits = 0; tie = 0; }
+  a.tok_bucket[r] = best_info & kBucketMaskD;
   a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
 }
 

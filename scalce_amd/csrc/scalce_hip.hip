@@ -28,6 +28,7 @@ struct scalce_ctx {
   int32_t *d_bucket_pattern = nullptr;
   u32 *d_bucket_level = nullptr;
   u32 *d_kmer = nullptr;      // k-mer tables of tokenize_kmer_k, or null when the core table does not qualify
+  bool kmer_t7_out = false;   // some state of depth <= 7 has an output
   u32 id8_first = 0;
   int tok_lds_states = 0;
   u32 *d_simd_load = nullptr;  // per (XCC, SE, SH, CU, SIMD): coder waves resident there (ac_encode_k's role choice)
@@ -136,6 +137,7 @@ static int upload_tables(scalce_ctx *c) {
     }
     if (ok && id8 > 32768) ok = false;  // t7 keeps a state in 15 bits
     std::vector<u32> tab(KMER_WORDS, 0);
+    bool t7_out = false;  // a state of depth <= 7 with an output (a core of fewer than 8 bases in the table)
     if (ok) {
       u16 *t7 = reinterpret_cast<u16 *>(tab.data());
       u32 *bits8 = tab.data() + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
@@ -145,6 +147,7 @@ static int upload_tables(scalce_ctx *c) {
         for (int j = 0; j < 7; j++) st = A.next[(size_t)st * 4 + ((x >> (12 - 2 * j)) & 3)];
         if (st >= 32768 || st >= id8) ok = false;
         t7[x] = (u16)(st | (A.outinfo[st] != kNoOutD ? 0x8000u : 0u));
+        if (A.outinfo[st] != kNoOutD) t7_out = true;
       }
       u32 prev_code = 0;
       for (u32 i = 0; i < n8 && ok; i++) {  // the depth-8 states: ids id8 .. id8 + n8 - 1 in the order of their 8-mers
@@ -165,6 +168,7 @@ static int upload_tables(scalce_ctx *c) {
       HIP_TRY(c, hipMalloc(&c->d_kmer, sizeof(u32) * KMER_WORDS));
       HIP_TRY(c, hipMemcpy(c->d_kmer, tab.data(), sizeof(u32) * KMER_WORDS, hipMemcpyHostToDevice));
       c->id8_first = id8;
+      c->kmer_t7_out = t7_out;
     }
   }
   // stage as many leading (shallow) states as fit in 60 KiB of LDS: 2 workgroups per CU stay resident
@@ -965,7 +969,10 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     const size_t sh = (size_t)a.lds_states * 20;
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    if (c->d_kmer && tok_pipelined()) LAUNCH(tokenize_kmer_pipe_k, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    if (c->d_kmer && tok_pipelined()) {
+      if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+      else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    }
     else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
     else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
@@ -1393,7 +1400,10 @@ extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint6
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
     const size_t sh = (size_t)a.lds_states * 20;
-    if (c->d_kmer && tok_pipelined()) LAUNCH(tokenize_kmer_pipe_k, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    if (c->d_kmer && tok_pipelined()) {
+      if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+      else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    }
     else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
     else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
