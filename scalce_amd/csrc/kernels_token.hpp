@@ -305,6 +305,86 @@ __global__ __launch_bounds__(TOK_THREADS) void tie_candidates_k(TieArgs a) {
   a.tie_ncand[t] = k;
 }
 
+// The second walk in the shape of tokenize_kmer_pipe_k: straight-line code per base, the output word of the state reached
+// looked at a base later.  tie_candidates_k<false, true> walks the same reads with a wait per lookup and 24 waves per CU:
+// 1.25 us per base and wave, 2.9 ms for the 9 M tie reads of a 50 M-read shard.
+template <bool T7_OUT>
+__global__ __launch_bounds__(TOKP_THREADS) void tie_candidates_pipe_k(TieArgs a) {
+  __shared__ u32 t7w[KMER_T7_WORDS];
+  __shared__ uint4 g8[KMER_BITS_WORDS];
+  {
+    const u32 *bits8 = a.kmer + KMER_T7_WORDS, *out8 = bits8 + KMER_BITS_WORDS;
+    const u16 *rank8 = reinterpret_cast<const u16 *>(out8 + KMER_BITS_WORDS);
+    for (u32 i = threadIdx.x; i < KMER_T7_WORDS; i += TOKP_THREADS) t7w[i] = a.kmer[i];
+    for (u32 i = threadIdx.x; i < KMER_BITS_WORDS; i += TOKP_THREADS) g8[i] = make_uint4(bits8[i], out8[i], a.id8_first + rank8[i], 0u);
+  }
+  __syncthreads();
+  const u16 *t7 = reinterpret_cast<const u16 *>(t7w);
+  const u32 t = blockIdx.x * TOKP_THREADS + threadIdx.x;
+  if (t >= a.ntie) return;
+  const u32 r = a.tie_read[t], off = a.tie_off[t];
+  const u32 lvmax = a.bucket_level[a.tok_bucket[r]];
+  const u32 *row = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
+  const char *next_b = reinterpret_cast<const char *>(a.next), *out_b = reinterpret_cast<const char *>(a.outinfo);
+  const u32 id8 = a.id8_first;
+  // the first four candidates stay in registers and are written at the end: a store inside the walk would sit behind a
+  // branch, where the compiler cannot count it, and every base would end in a full wait
+  u32 state = 0, k = 0, c0 = 0xFFFFFFFFu, c1 = 0xFFFFFFFFu, c2 = 0xFFFFFFFFu, c3 = 0xFFFFFFFFu, p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  u32 pend_raw = 0;
+  bool pend_has = false;
+  auto settle = [&](u32 info, u32 pos) {  // a core of the longest length: a new candidate unless its bucket is one already
+    const bool cand = (info >> kLevelShiftD) == lvmax;  // (lvmax >= 1: a word of 0, "no output", never is)
+    const u32 bk = info & kBucketMaskD;
+    const bool fresh = cand && bk != c0 && bk != c1 && bk != c2 && bk != c3;
+    if (__ballot(fresh && k >= 4) != 0) {  // a fifth candidate somewhere in the wave: rare
+      if (fresh && k >= 4) {
+        bool seen = false;
+        for (u32 j = 4; j < k && !seen; j++) seen = a.cand_bucket[off + j] == bk;
+        if (!seen) { a.cand_bucket[off + k] = bk; a.cand_pos[off + k] = pos; k++; }
+      }
+    }
+    const bool add = fresh && k < 4;
+    c0 = (add && k == 0) ? bk : c0; p0 = (add && k == 0) ? pos : p0;
+    c1 = (add && k == 1) ? bk : c1; p1 = (add && k == 1) ? pos : p1;
+    c2 = (add && k == 2) ? bk : c2; p2 = (add && k == 2) ? pos : p2;
+    c3 = (add && k == 3) ? bk : c3; p3 = (add && k == 3) ? pos : p3;
+    k += add ? 1u : 0u;
+  };
+  const int nw = (a.L + 15) >> 4;
+  u32 prevs = 0;
+  for (int w = 0; w < nw; w++) {
+    const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
+    const u32 curs = __builtin_bswap32(row[w]);
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      if (kk < cnt) {
+        const int pos = 16 * w + kk;
+        const u32 code = __builtin_amdgcn_alignbit(prevs, curs, 30 - 2 * kk) & 0xFFFFu;
+        const bool deep = pos < 7 || state >= id8;
+        const u32 tg = *reinterpret_cast<const u32 *>(next_b + (deep ? (state << 4) | ((code & 3u) << 2) : 0u));
+        const uint4 g = g8[code >> 5];
+        const u32 e = t7[code & 0x3FFFu];
+        const u32 bit = code & 31u;
+        settle(pend_has ? pend_raw : 0u, (u32)(pos - 1));
+        const u32 t8 = (g.z + (u32)__popc(g.x & ((1u << bit) - 1u))) | (((g.y >> bit) & 1u) << 31);
+        const u32 t7v = T7_OUT ? (e & 0x7FFFu) | ((e >> 15) << 31) : e;
+        const u32 tl = ((g.x >> bit) & 1u) ? t8 : t7v;
+        const u32 tt = deep ? tg : tl;
+        state = tt & 0x7FFFFFFFu;
+        pend_has = (tt >> 31) != 0;
+        pend_raw = *reinterpret_cast<const u32 *>(out_b + (pend_has ? state << 2 : 0u));
+      }
+    }
+    prevs = curs;
+  }
+  settle(pend_has ? pend_raw : 0u, (u32)(a.L - 1));
+  if (k > 0) { a.cand_bucket[off] = c0; a.cand_pos[off] = p0; }
+  if (k > 1) { a.cand_bucket[off + 1] = c1; a.cand_pos[off + 1] = p1; }
+  if (k > 2) { a.cand_bucket[off + 2] = c2; a.cand_pos[off + 2] = p2; }
+  if (k > 3) { a.cand_bucket[off + 3] = c3; a.cand_pos[off + 3] = p3; }
+  a.tie_ncand[t] = k;
+}
+
 // events: one per fixed read (its bucket) and one per (tie read, candidate).  ev_off[r] = first
 // event of read r.  Events are created in read order, so a stable sort by bucket leaves every
 // bucket's events in input order.

@@ -1008,7 +1008,10 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.tie_ncand = b->tie_ncand.as<u32>();
     a.lds_states = (u32)c->tok_lds_states;
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    if (c->d_kmer) LAUNCH((tie_candidates_k<false, true>), cdiv(ntie, TOK_THREADS), TOK_THREADS, sizeof(u32) * KMER_WORDS, s, a);
+    if (c->d_kmer && tok_pipelined()) {
+      if (c->kmer_t7_out) LAUNCH(tie_candidates_pipe_k<true>, cdiv(ntie, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+      else LAUNCH(tie_candidates_pipe_k<false>, cdiv(ntie, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    } else if (c->d_kmer) LAUNCH((tie_candidates_k<false, true>), cdiv(ntie, TOK_THREADS), TOK_THREADS, sizeof(u32) * KMER_WORDS, s, a);
     else if (a.lds_states) LAUNCH(tie_candidates_k<true>, cdiv(ntie, TOK_THREADS), TOK_THREADS, (size_t)a.lds_states * 20, s, a);
     else LAUNCH(tie_candidates_k<false>, cdiv(ntie, TOK_THREADS), TOK_THREADS, 0, s, a);
     HIP_TRY(c, hipMemsetAsync(b->choice.p, 0, sizeof(u32) * ntie, s));
