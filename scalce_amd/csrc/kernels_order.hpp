@@ -344,6 +344,31 @@ __global__ __launch_bounds__(256) void emit_names_k(u64 nrec, const u32 *perm, c
   for (u32 i = 0; i < n; i++) dst[1 + i] = src[i];
 }
 
+// The same with the cells already in output order (name_cells_sorted_k): one gather through the permutation instead of two.
+__global__ __launch_bounds__(256) void name_cells_sorted_k(u64 nrec, const u32 *perm, const u8 *cells, u8 *cells_sorted, u8 *outlen) {
+  const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec) return;
+  const uint4 c = *reinterpret_cast<const uint4 *>(cells + 16 * (u64)perm[k]);
+  *reinterpret_cast<uint4 *>(cells_sorted + 16 * k) = c;
+  outlen[k] = (u8)(c.x & 0xFFu);
+}
+__global__ __launch_bounds__(256) void emit_names_sorted_k(u64 nrec, const u32 *perm, const u8 *cells_sorted, const u64 *store_off,
+                                                          const u8 *store, const u64 *name_off, u8 *out) {
+  const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nrec) return;
+  u8 *dst = out + name_off[k];
+  const uint4 c = *reinterpret_cast<const uint4 *>(cells_sorted + 16 * k);
+  const u32 n = c.x & 0xFFu;
+  if (n <= 15) {
+    const u32 w[4] = {c.x, c.y, c.z, c.w};
+    for (u32 i = 0; i <= n; i++) dst[i] = (u8)(w[i >> 2] >> (8 * (i & 3)));
+    return;
+  }
+  const u8 *src = store + store_off[perm[k]];
+  dst[0] = (u8)n;
+  for (u32 i = 0; i < n; i++) dst[1 + i] = src[i];
+}
+
 // row gather: out[k] = rows[perm[k]], `width` bytes per row, row stride `stride` in the source.  A thread produces 16
 // consecutive output bytes (one aligned 16-byte store; they span at most two rows when width >= 16) and the grid strides
 // over the output: 200 M rows of 150 bytes are 3e10 bytes, far beyond the 2^32 threads a launch may have.

@@ -247,13 +247,14 @@ struct scalce_workspace {
   DBuf name_off;
   DBuf tw_cells, tw_cand, tw_bits, tw_base;  // the tie-break in windows (tokenize_windows)
   DBuf tile_mm[2];                           // per text tile: smallest / largest q' symbol (ingest_tiles2_k)
+  DBuf cell_sorted;                          // name cells in output order (emit stage)
   void free_all() {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
                    &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
                    &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
                    &cand_place, &Gseg, &cand_fixed, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
                    &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
-                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1]};
+                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1], &cell_sorted};
     for (DBuf *d : all)
       if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
     row_cap = piece_rows_cap = 0;
@@ -274,7 +275,7 @@ struct scalce_batch {
         chunk(w->chunk), chunk_start(w->chunk_start), perm_a(w->perm_a), perm_b(w->perm_b), key_a(w->key_a), key_b(w->key_b), hist(w->hist),
         scan_ws(w->scan_ws), S(w->S), run_head(w->run_head), run_hcount(w->run_hcount), run_rank(w->run_rank), runid(w->runid),
         run_items_a(w->run_items_a), run_items_b(w->run_items_b), run_pos(w->run_pos), name_off(w->name_off),
-        tw_cells(w->tw_cells), tw_cand(w->tw_cand), tw_bits(w->tw_bits), tw_base(w->tw_base), tile_mm(w->tile_mm) {}
+        tw_cells(w->tw_cells), tw_cand(w->tw_cand), tw_bits(w->tw_bits), tw_base(w->tw_base), tile_mm(w->tile_mm), cell_sorted(w->cell_sorted) {}
   scalce_ctx *ctx = nullptr;
   scalce_params p;
   u64 max_reads = 0, max_text = 0;
@@ -317,6 +318,7 @@ struct scalce_batch {
   DBuf &name_off;
   DBuf &tw_cells, &tw_cand, &tw_bits, &tw_base;
   DBuf (&tile_mm)[2];
+  DBuf &cell_sorted;
   bool mm_valid[2] = {false, false};  // tile_mm[m] holds the symbol ranges of the piece ingested last
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, ac_tab[2], ac_tab8[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
@@ -1618,7 +1620,12 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
   if (b->p.use_names) {
     ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
     ENSURE(b, b->outlen, N + 64);
-    if (N) LAUNCH(name_outlen_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->outlen.as<u8>());
+    // the name cells are gathered through the permutation ONCE, into output order: their first byte is the length the scan
+    // wants, and emit_names_sorted_k then reads them in sequence (name_outlen_k + emit_names_k gathered twice)
+    const bool cells = b->namecell.p != nullptr && !getenv("SCALCE_EMIT_NAMES_TWO_GATHERS");
+    if (cells) ENSURE(b, b->cell_sorted, 16 * (N + 4));
+    if (N && cells) LAUNCH(name_cells_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namecell.as<u8>(), b->cell_sorted.as<u8>(), b->outlen.as<u8>());
+    else if (N) LAUNCH(name_outlen_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->outlen.as<u8>());
     exclusive_scan<u64>(NameLenSeq{b->outlen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
     ENSURE(b, b->bucket_name_bytes, sizeof(u64) * (nb1 + 1));
     LAUNCH(bucket_name_bytes_k, cdiv(nb1, 256), 256, 0, s, nb1, b->bucket_first.as<u64>(), counts, b->name_off.as<u64>(), b->d_small64 + 3, N,
@@ -1639,7 +1646,10 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
     a.key_end_bits = b->key_end_bits;
     LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
-    if (b->p.use_names)
+    if (b->p.use_names && b->namecell.p && !getenv("SCALCE_EMIT_NAMES_TWO_GATHERS"))
+      LAUNCH(emit_names_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->cell_sorted.as<u8>(), b->name_in_off.as<u64>(),
+             b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
+    else if (b->p.use_names)
       LAUNCH(emit_names_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namecell.as<u8>(), b->name_in_off.as<u64>(),
              b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
     for (int m = 0; m < b->nm; m++) {
@@ -1668,7 +1678,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
   } else if (b->nm == 2) b->out_reads_bytes[1] = 0;
   if (b->lean) {  // nothing behind this stage reads the rows, the tokens or the sort scratch
     HIP_TRY(c, hipStreamSynchronize(s));
-    DBuf *dead[] = {&b->packed[0], &b->packed[1], &b->namecell, &b->names_in, &b->name_in_off, &b->name_off, &b->outlen,
+    DBuf *dead[] = {&b->packed[0], &b->packed[1], &b->namecell, &b->names_in, &b->name_in_off, &b->name_off, &b->outlen, &b->cell_sorted,
                     &b->line_end[0], &b->line_end[1], &b->tile[0], &b->tile[1], &b->tok_bucket, &b->tok_pos, &b->tie_index,
                     &b->tie_read, &b->tie_off, &b->tie_ncand, &b->cand_bucket, &b->cand_pos, &b->choice, &b->ev_off,
                     &b->ev_bucket, &b->ev_init, &b->ev_sorted, &b->ev_tmp, &b->ev_place, &b->chosen, &b->G, &b->cand_place,
