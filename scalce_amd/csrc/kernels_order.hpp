@@ -376,6 +376,8 @@ __host__ __device__ inline u32 gather_grid(u64 nrec, u32 width) {
   const u64 chunks = (nrec * (u64)width + 15) / 16, blocks = (chunks + 255) / 256;
   return (u32)(blocks < (1u << 22) ? (blocks ? blocks : 1) : (1u << 22));
 }
+// (Four chunks per thread with all their loads in front of the stores were measured: 5.1 ms against 4.0 at 50 M x 100 --
+// the gather is not short of requests in flight, it is at what random 100-byte rows get out of the memory.)
 __global__ __launch_bounds__(256) void gather_rows_k(u64 nrec, const u32 *perm, const u8 *rows, u64 stride, u32 width,
                                                     u8 *out) {
   const u64 total = nrec * (u64)width;
