@@ -134,6 +134,15 @@ def main():
         G = 3 if sharded else 4
     G = max(1, G)
     D = max(1, args.inflight) if args.inflight is not None else (2 * G if sharded else 3 * G + 2)
+    if args.inflight is None and not sharded:
+        # what is free now decides how many shards fit: ~20 GB of shared front-stage buffers + the shard's text + ~15.3 GB per
+        # shard in flight at 50 M x 100 bp (measured: 243 GB at fourteen), with a margin for the self-check's buffers
+        free_b, _ = torch.cuda.mem_get_info()
+        per_slot = 15.3e9 * (n * L) / 5e9
+        fit = int((free_b - 22e9 * (n * L) / 5e9 - 14e9) // per_slot)
+        if fit < D:
+            print("bench: %.0f GB of HBM free: %d shards in flight instead of %d" % (free_b / 1e9, max(fit, 2 * G), D), file=sys.stderr)
+            D = fit
     if G > 1:
         D = max(D, 2 * G)
     if sharded and "SCALCE_AC_BLOCKS_PER_WG" not in os.environ and D < 3 * G:
