@@ -2398,8 +2398,11 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
     // symbol 79 in the span = rows with a "last symbol of its context" marker: the kernel with the second ballot
     const bool fast = smax < AC_D - 1 && !getenv("SCALCE_AC_DECODE_OLD");
     if (fast) {
-      if (nblk <= 512) LAUNCH(ac_decode_fast_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
-      else if (nblk <= 1024) LAUNCH(ac_decode_fast_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
+      int wpb = nblk <= 512 ? 2 : nblk <= 1024 ? 4 : nblk <= 2048 ? 8 : 16;  // 16 = four chains per SIMD: a chain issues one instruction in five cycles
+      if (const char *e = getenv("SCALCE_AC_DECODE_WPB")) wpb = atoi(e);     // (tests: the wide workgroups on a few blocks)
+      if (wpb == 2) LAUNCH(ac_decode_fast_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+      else if (wpb == 4) LAUNCH(ac_decode_fast_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
+      else if (wpb == 16) LAUNCH(ac_decode_fast_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
       else LAUNCH(ac_decode_fast_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
     } else if (nblk <= 512) LAUNCH(ac_decode_cached_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
     else if (nblk <= 1024) LAUNCH(ac_decode_cached_k<4>, cdiv(nblk, 4), 256, 0, s, ca);

@@ -530,13 +530,16 @@ def test_rows_coder_redo_path(blocks_per_wave, ctx, oracle_trie, monkeypatch):
     check_against_oracle(ctx, oracle_trie, bases, quals, label="poison" + blocks_per_wave)
 
 
-@pytest.mark.parametrize("case", ["narrow", "rare_outside", "wide", "top_symbol", "plain_kernel"])
+@pytest.mark.parametrize("case", ["narrow", "rare_outside", "wide", "top_symbol", "plain_kernel", "narrow_16_chains", "rare_outside_8_chains"])
 def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
     """scalce_ac_decode keeps compact rows (upper bounds of the symbols that occur) and the hot contexts' rows in LDS.
     Crafted tables drive every path: a narrow alphabet (all contexts cached), symbols whose count is 1 everywhere but
     which still occur (full-row path), an alphabet wider than one pass (the plain kernel), symbol 79 (the context's
     last interval).  Encoder and decoder are both checked against the oracle's coder with the same table."""
     import torch
+    if case.endswith("_chains"):   # the workgroup shapes of archives with thousands of blocks, on three
+        monkeypatch.setenv("SCALCE_AC_DECODE_WPB", case.split("_")[-2])
+        case = case.rsplit("_", 2)[0]
     rng = np.random.default_rng(77 + len(case))
     nsym = 2 * 10 * 1024 * 1024 + 12345  # three blocks, the last one short
     if case in ("narrow", "plain_kernel"):
