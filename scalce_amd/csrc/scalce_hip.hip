@@ -320,6 +320,7 @@ struct scalce_batch {
   DBuf (&tile_mm)[2];
   DBuf &cell_sorted;
   bool mm_valid[2] = {false, false};  // tile_mm[m] holds the symbol ranges of the piece ingested last
+  bool names_from_sorted_cells = false;
   u32 order_run_members = 0;
   DBuf out_reads[2], out_names, ac_tab[2], ac_tab8[2], ac_cum[2], ac_blocks[2], ac_sizes[2], ac_off[2], ac_desc, out_qual[2];
   AcBlockDesc *ac_desc_host = nullptr;  // block descriptors of the last coder launch this shard led: pinned, so that the
@@ -1622,7 +1623,10 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     ENSURE(b, b->outlen, N + 64);
     // the name cells are gathered through the permutation ONCE, into output order: their first byte is the length the scan
     // wants, and emit_names_sorted_k then reads them in sequence (name_outlen_k + emit_names_k gathered twice)
-    const bool cells = b->namecell.p != nullptr && !getenv("SCALCE_EMIT_NAMES_TWO_GATHERS");
+    // (not in lean mode: a run sized for most of HBM has no 16 bytes per read to spare, and allocating and releasing
+    //  3 GB costs more than the second gather)
+    const bool cells = b->namecell.p != nullptr && !b->lean && !getenv("SCALCE_EMIT_NAMES_TWO_GATHERS");
+    b->names_from_sorted_cells = cells;
     if (cells) ENSURE(b, b->cell_sorted, 16 * (N + 4));
     if (N && cells) LAUNCH(name_cells_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namecell.as<u8>(), b->cell_sorted.as<u8>(), b->outlen.as<u8>());
     else if (N) LAUNCH(name_outlen_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namelen.as<u8>(), b->outlen.as<u8>());
@@ -1646,7 +1650,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
     a.key_end_bits = b->key_end_bits;
     LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
-    if (b->p.use_names && b->namecell.p && !getenv("SCALCE_EMIT_NAMES_TWO_GATHERS"))
+    if (b->p.use_names && b->names_from_sorted_cells)
       LAUNCH(emit_names_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->cell_sorted.as<u8>(), b->name_in_off.as<u64>(),
              b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
     else if (b->p.use_names)
