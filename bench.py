@@ -117,14 +117,9 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-    # shards per coder launch / shards in flight: 3 / 6 (135 GB of the 288 GB HBM at 50 M reads per shard with the shared
-    # front-stage buffers).  A sharded run also holds every in-flight shard's block range of the run-wide quality stream
-    # (5 GB each) and, while a shard is worked on, the text it received from its neighbours and the all-to-all buffers
-    # (about 25 GB): 190 GB.  Larger groups do not pay yet: from four shards per launch on the front stages, not the coder,
-    # bound the pipeline.
-    # four shards per coder launch, two launches side by side, twelve shards in flight (234 GB): a launch of the
-    # one-block-per-lane coder takes ~0.56 s whatever it holds and 60 CUs for four shards, so the pipeline needs two of
-    # them running beside the front stages of the next four shards (profiles/README.md, r03 rows)
+    # four shards per coder launch, up to three launches side by side on three streams, fourteen shards in flight (243 GB):
+    # a launch of the one-block-per-lane coder takes 0.56-0.65 s whatever it holds and 40 CUs for four shards, so the
+    # pipeline needs them side by side beside the front stages of the next four shards
     # A sharded run (several ranks, ONE archive) also holds, per shard in flight, its block range of the run-wide quality
     # stream and the all-to-all buffers: 246 GB at six in flight (tools/mem_probe.sh).  It keeps round 2's shape -- three
     # shards per launch, six in flight, one coder stream, eight blocks per chain wave: with one stream a launch of the
