@@ -484,8 +484,10 @@ __global__ __launch_bounds__(256) void events_place_keys_k(u32 nev, const u32 *s
                                                           u8 *chosen_t) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nev) return;
-  ev_place[sorted[i]] = i;
-  if (keys[i] & 2u) chosen_t[cidx[i]] = (u8)(keys[i] & 1u);
+  if (keys[i] & 2u) {  // only a tie candidate's place is ever asked for (tie_place_k): a third of the scattered writes
+    ev_place[sorted[i]] = i;
+    chosen_t[cidx[i]] = (u8)(keys[i] & 1u);
+  }
 }
 // seg[b] = first sorted position of bucket b, seg_t[b] = first compact position, fixed_total[b] = its fixed reads
 __global__ __launch_bounds__(256) void events_compact_segments_k(u32 nb1, const u32 *seg, const u32 *cidx, u32 nev, u32 ntev, u32 *seg_t,
