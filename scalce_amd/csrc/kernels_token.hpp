@@ -394,7 +394,7 @@ struct EventArgs {
   const u32 *tie_index;  // read -> tie index (valid when tie bit set)
   const u32 *tie_off, *tie_ncand, *cand_bucket;
   const u32 *ev_off;
-  u32 *ev_bucket;
+  u32 *ev_bucket;        // (may be null together with ev_init: the sort on (key, event) pairs carries both in the key)
   u8 *ev_init;           // initial "chosen" flag: fixed reads 1, first candidate 1, others 0
   u64 *ev_key;           // bucket << 2 | candidate of a tie read << 1 | initial flag: what the sort by bucket carries along
 };
@@ -406,14 +406,12 @@ __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
     const u32 t = a.tie_index[r], off = a.tie_off[t], k = a.tie_ncand[t];
     for (u32 j = 0; j < k; j++) {
       const u32 bk = a.cand_bucket[off + j];
-      a.ev_bucket[e + j] = bk;
-      a.ev_init[e + j] = j == 0;
+      if (a.ev_bucket) { a.ev_bucket[e + j] = bk; a.ev_init[e + j] = j == 0; }
       if (a.ev_key) a.ev_key[e + j] = ((u64)bk << 2) | 2u | (j == 0 ? 1u : 0u);
     }
   } else {
     const u32 bk = a.tok_bucket[r];
-    a.ev_bucket[e] = bk;
-    a.ev_init[e] = 1;
+    if (a.ev_bucket) { a.ev_bucket[e] = bk; a.ev_init[e] = 1; }
     if (a.ev_key) a.ev_key[e] = ((u64)bk << 2) | 1u;
   }
 }

@@ -1025,8 +1025,6 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   u32 nev = 0;
   { int rc = read_u32(b, b->d_small + 2, &nev, 1, s); if (rc) return rc; }
   b->nev = nev;
-  ENSURE(b, b->ev_bucket, sizeof(u32) * (nev + 2));
-  ENSURE(b, b->ev_init, nev + 64);
   ENSURE(b, b->ev_sorted, sizeof(u32) * (nev + 2));
   ENSURE(b, b->ev_tmp, sizeof(u32) * (nev + 2));
   ENSURE(b, b->ev_place, sizeof(u32) * (nev + 2));
@@ -1039,7 +1037,7 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     EventArgs a;
     a.nrec = N; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>(); a.tie_index = b->tie_index.as<u32>();
     a.tie_off = b->tie_off.as<u32>(); a.tie_ncand = b->tie_ncand.as<u32>(); a.cand_bucket = b->cand_bucket.as<u32>();
-    a.ev_off = b->ev_off.as<u32>(); a.ev_bucket = b->ev_bucket.as<u32>(); a.ev_init = b->ev_init.as<u8>();
+    a.ev_off = b->ev_off.as<u32>(); a.ev_bucket = nullptr; a.ev_init = nullptr;  // (the keys carry bucket and flags)
     // the events are sorted by bucket as (key, event) pairs, like the order stage's records (sequential passes; the
     // index-only passes gathered the bucket through the index, and so did the two kernels behind them)
     ENSURE(b, b->key_a, sizeof(u64) * ((size_t)nev + 2));
