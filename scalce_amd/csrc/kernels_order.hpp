@@ -114,6 +114,52 @@ __global__ __launch_bounds__(256) void run_scatter_k(u32 m, const u32 *sorted, c
   if (keys && end_bits) keys[p] = ((keys[p] >> end_bits) << end_bits) | (u64)end[r];
 }
 
+// Phase 2 without passes.  On reads without many exact duplicates the runs are pairs and triples -- and long runs of
+// records whose key ENDS inside the prefix (core near the end of the read: nothing is left to sort them by, they are in
+// their final order already).  25 radix passes (21 remaining key digits + the run id) over 1.7 M members are 125 small
+// launches, 1.9 ms of launch latency.  Here the thread of a run's first member sorts a run of up to RUN_SMALL_MAX members
+// where it stands -- insertion sort on the remaining digits, most significant first, strictly-less so that equal keys keep
+// their phase-1 (= input) order.  Longer runs are left alone; a member of one that HAS bases behind the prefix sets
+// `any_large`, and the host then takes the radix passes for everything (heavy duplicates).
+constexpr u32 RUN_SMALL_MAX = 32;
+__global__ __launch_bounds__(256) void run_small_sort_k(u32 M, const u32 *pos_list, const u8 *head, u32 n, u32 *perm, u64 *keys /* or null */,
+                                                       u32 end_bits, const u8 *packed, const u16 *end, int L, int stride, int ndig1,
+                                                       int ndig, u32 *any_large) {
+  const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const u32 p = pos_list[m];
+  if (!head[p]) {  // not the first member of its run: does it make a long run one that needs sorting?
+    if ((int)end[perm[p]] + 4 * ndig1 >= L) return;       // no bases behind the prefix
+    u32 back = 1;
+    while (back <= RUN_SMALL_MAX && !head[p - back]) back++;   // (p - back is the run's first position when the loop ends on a head)
+    u32 fwd = 1;
+    while (fwd <= RUN_SMALL_MAX && p + fwd < n && !head[p + fwd]) fwd++;
+    if (back + fwd > RUN_SMALL_MAX) atomicOr(any_large, 1u);
+    return;
+  }
+  u32 len = 1;
+  while (p + len < n && !head[p + len] && len <= RUN_SMALL_MAX) len++;
+  if (len > RUN_SMALL_MAX) {
+    if ((int)end[perm[p]] + 4 * ndig1 < L) atomicOr(any_large, 1u);
+    return;
+  }
+  auto less = [&](u32 x, u32 y) -> bool {
+    for (int d = ndig1; d < ndig; d++) {
+      const u32 dx = KeyDigit{packed, end, L, stride, d}(x), dy = KeyDigit{packed, end, L, stride, d}(y);
+      if (dx != dy) return dx < dy;
+    }
+    return false;
+  };
+  for (u32 a = 1; a < len; a++) {
+    const u32 x = perm[p + a];
+    u32 j = a;
+    while (j > 0 && less(x, perm[p + j - 1])) { perm[p + j] = perm[p + j - 1]; j--; }
+    perm[p + j] = x;
+  }
+  if (keys && end_bits)  // the members of a run share the sorted part of the key; the `end` riding below it follows the record
+    for (u32 a = 0; a < len; a++) keys[p + a] = ((keys[p + a] >> end_bits) << end_bits) | (u64)end[perm[p + a]];
+}
+
 // spill chunks (compress.cpp:702-715): running size of the records since the last dump; when it
 // reaches -B the current read closes the chunk.  rec_size is scanned inclusively into S; the
 // boundaries are found by one thread with binary searches (there are few chunks).

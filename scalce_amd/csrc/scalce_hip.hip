@@ -1578,6 +1578,17 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
       ENSURE(b, b->run_pos, sizeof(u32) * (M + 2));
       LAUNCH(run_compact_k, cdiv(N, 256), 256, 0, s, (u32)N, head, b->run_rank.as<u32>(), b->run_hcount.as<u32>(), perm1,
              b->run_items_a.as<u32>(), b->run_pos.as<u32>(), b->runid.as<u32>());
+      bool small_done = false;
+      if (!getenv("SCALCE_ORDER_RUN_PASSES")) {  // runs of up to 32 members are sorted where they stand (run_small_sort_k)
+        u32 *any_large = b->d_small + 10;
+        HIP_TRY(c, hipMemsetAsync(any_large, 0, sizeof(u32), s));
+        LAUNCH(run_small_sort_k, cdiv(M, 256), 256, 0, s, M, b->run_pos.as<u32>(), head, (u32)N, perm1, sorted_keys, end_bits,
+               b->packed[0].as<u8>(), b->endv.as<u16>(), b->L[0], b->stride[0], ndig1, ndig, any_large);
+        u32 large = 0;
+        { int rc = read_u32(b, any_large, &large, 1, s); if (rc) return rc; }
+        small_done = large == 0;
+      }
+      if (!small_done) {
       const u32 *rs = b->run_items_a.as<u32>();
       u32 *rd = b->run_items_b.as<u32>(), *ralt = b->run_items_a.as<u32>();
       auto rflip = [&]() { rs = rd; u32 *t = rd; rd = ralt; ralt = t; };
@@ -1592,6 +1603,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
         rflip();
       }
       LAUNCH(run_scatter_k, cdiv(M, 256), 256, 0, s, M, rs, b->run_pos.as<u32>(), perm1, sorted_keys, end_bits, b->endv.as<u16>());
+      }
     }
   }
   b->perm = perm1;
