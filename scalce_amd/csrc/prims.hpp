@@ -259,18 +259,29 @@ inline void radix_pass(const u32 *in, u32 *out, u32 n, D digit, u32 *hist_ws, u3
 // travels with the payload, so every read is sequential (radix_pass's functor gathers through the
 // payload: 8 GB of sector fetches per pass for 50 M two-byte digits)
 // ---------------------------------------------------------------------------------------------
+// A workgroup counts RH_TILES consecutive tiles: the table is digit-major (hist[digit][tile], what the scan wants), so a
+// workgroup of one tile wrote 256 single words a whole row apart -- 64 bytes of HBM write per word.  Sixteen tiles make
+// every digit's words one 64-byte run.
+constexpr int RH_TILES = 16;
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_key_k(const u64 *keys, u32 n, u32 shift, u32 *hist, u32 ntiles) {
-  __shared__ u32 h[256];
-  h[threadIdx.x] = 0;
+  __shared__ u32 h[RH_TILES][256];
+  for (int i = threadIdx.x; i < RH_TILES * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
   __syncthreads();
-  const u32 base = blockIdx.x * RS_TILE;
+  const u32 tile0 = blockIdx.x * RH_TILES;
+  for (int j = 0; j < RH_TILES; j++) {
+    const u32 base = (tile0 + j) * RS_TILE;
+    if (base >= n) break;
 #pragma unroll
-  for (int i = 0; i < RS_ITEMS; i++) {
-    const u32 idx = base + i * RS_THREADS + threadIdx.x;
-    if (idx < n) atomicAdd(&h[(u32)(keys[idx] >> shift) & 0xFFu], 1u);
+    for (int i = 0; i < RS_ITEMS; i++) {
+      const u32 idx = base + i * RS_THREADS + threadIdx.x;
+      if (idx < n) atomicAdd(&h[j][(u32)(keys[idx] >> shift) & 0xFFu], 1u);
+    }
   }
   __syncthreads();
-  hist[(u64)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+  for (int i = threadIdx.x; i < RH_TILES * 256; i += RS_THREADS) {  // sixteen lanes = the sixteen tiles of one digit
+    const u32 d = (u32)i / RH_TILES, j = (u32)i % RH_TILES;
+    if (tile0 + j < ntiles) hist[(u64)d * ntiles + tile0 + j] = h[j][d];
+  }
 }
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_k(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out,
                                                                 u32 n, u32 shift, const u32 *offs, u32 ntiles) {
@@ -405,7 +416,7 @@ inline void radix_pass_kv(const u64 *keys_in, const u32 *vals_in, u64 *keys_out,
                           u32 *tile_ws, hipStream_t st) {
   if (!n) return;
   const u32 ntiles = (n + RS_TILE - 1) / RS_TILE;
-  hipLaunchKernelGGL(radix_hist_key_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
+  hipLaunchKernelGGL(radix_hist_key_k, dim3((ntiles + RH_TILES - 1) / RH_TILES), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
   exclusive_scan<u32>(LoadAs<u32, u32>{hist_ws}, (u64)256 * ntiles, StoreTo<u32>{hist_ws}, tile_ws, (u32 *)nullptr, st);
   static const bool direct = getenv("SCALCE_RADIX_DIRECT") != nullptr;
   if (!direct) hipLaunchKernelGGL(radix_scatter_kv_staged_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
