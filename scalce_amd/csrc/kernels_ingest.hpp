@@ -840,9 +840,12 @@ __global__ __launch_bounds__(256) void tile_minmax_reduce_k(const u16 *tile_minm
 // the two carried-in ones) is laid out, A^2 counters per leading symbol, so a 39-symbol alphabet (q' 2..40)
 // fits 20 leading symbols into 122 KB and needs 2 streaming passes instead of the 8 that 6400-counter rows
 // of the full 80-symbol alphabet took; a full alphabet still works (4 leading symbols per pass, 20 passes).
-// 512-thread workgroups: a 1024-thread one needs four free wave slots on every SIMD of a CU at once and is
-// not placed at all while another shard's arithmetic coder is resident.
-constexpr int TRI_THREADS = 512;
+// 1024-thread workgroups (one per CU: the counters take 122 KB): the kernel is half instruction issue (20 per symbol) and
+// half LDS atomics (2.7 per CU and cycle in this form, tools/ubench_lds_atomics.hip), and sixteen waves overlap the two
+// where eight did not: 5.5 -> 3.3 ms per 50 M x 100 bp.  (Rounds 1-2 ran 512 threads: a 1024-thread workgroup needs four
+// free wave slots on every SIMD of a CU at once and was not placed at all beside the rows coder, whose waves sat on every
+// CU; the one-block-per-lane coder keeps its CUs to itself and leaves the others empty between front-stage kernels.)
+constexpr int TRI_THREADS = 1024;
 constexpr int TRI_CAP = 30500;      // u32 counters in LDS (122 000 B of the CU's 160 KB)
 constexpr int TRI_MAX_PASSES = 20;  // A = 80: 4 leading symbols per pass
 
