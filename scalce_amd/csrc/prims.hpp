@@ -340,22 +340,27 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_k(const u64 *keys
 // The same scatter through LDS: the tile's pairs are first put in digit order in LDS, then leave in that order, so that a
 // wavefront's store instruction covers a few runs of consecutive addresses (8 pairs per digit and tile on average) instead
 // of 64 single pairs -- WRITE_SIZE of the direct version was 1.9 x the bytes it stores.
-__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_staged_k(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out,
-                                                                       u32 n, u32 shift, const u32 *offs, u32 ntiles) {
+// 512 threads on a tile of 2048 pairs: the staging buffers (37 KB) allow four workgroups per CU, and four items per thread
+// with eight waves each keep 32 waves resident where 256 threads kept 16.
+constexpr int RSK_THREADS = 512;
+constexpr int RSK_ITEMS = RS_TILE / RSK_THREADS;
+constexpr int RSK_WAVES = RSK_THREADS / 64;
+__global__ __launch_bounds__(RSK_THREADS) void radix_scatter_kv_staged_k(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out,
+                                                                        u32 n, u32 shift, const u32 *offs, u32 ntiles) {
   __shared__ u64 keys_s[RS_TILE];
   __shared__ u32 vals_s[RS_TILE], dest_s[RS_TILE];
-  __shared__ u32 wh[4][256];
+  __shared__ u32 wh[RSK_WAVES][256];
   __shared__ u32 gbase[256];
-  __shared__ u32 sm[4];
-  for (int i = threadIdx.x; i < 4 * 256; i += RS_THREADS) (&wh[0][0])[i] = 0;
+  __shared__ u32 sm[RSK_WAVES];
+  for (int i = threadIdx.x; i < RSK_WAVES * 256; i += RSK_THREADS) (&wh[0][0])[i] = 0;
   __syncthreads();
   const int w = wave_id(), lane = lane_id();
   const u64 lt = (1ull << lane) - 1;
-  const u32 tile0 = blockIdx.x * RS_TILE, base = tile0 + w * (64 * RS_ITEMS);
-  u64 key[RS_ITEMS];
-  u32 val[RS_ITEMS], pos[RS_ITEMS];
+  const u32 tile0 = blockIdx.x * RS_TILE, base = tile0 + w * (64 * RSK_ITEMS);
+  u64 key[RSK_ITEMS];
+  u32 val[RSK_ITEMS], pos[RSK_ITEMS];
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
+  for (int r = 0; r < RSK_ITEMS; r++) {
     const u32 idx = base + r * 64 + lane;
     const bool valid = idx < n;
     key[r] = valid ? keys_in[idx] : 0ull;
@@ -380,19 +385,26 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_staged_k(const u6
   }
   __syncthreads();
   {
+    // digit d of the tile starts behind all smaller digits; inside it the waves follow each other
+    u32 tot = 0;
     const u32 d = threadIdx.x;
-    const u32 c0 = wh[0][d], c1 = wh[1][d], c2 = wh[2][d], c3 = wh[3][d];
-    u32 tot;
-    const u32 ex = block_exclusive_sum<u32, 4>(c0 + c1 + c2 + c3, &tot, sm);  // where digit d starts in the tile
-    wh[0][d] = ex;
-    wh[1][d] = ex + c0;
-    wh[2][d] = ex + c0 + c1;
-    wh[3][d] = ex + c0 + c1 + c2;
-    gbase[d] = offs[(u64)d * ntiles + blockIdx.x] - ex;
+    u32 c[RSK_WAVES];
+    if (d < 256) {
+#pragma unroll
+      for (int i = 0; i < RSK_WAVES; i++) { c[i] = wh[i][d]; tot += c[i]; }
+    }
+    u32 all;
+    const u32 ex = block_exclusive_sum<u32, RSK_WAVES>(d < 256 ? tot : 0u, &all, sm);
+    if (d < 256) {
+      u32 run = ex;
+#pragma unroll
+      for (int i = 0; i < RSK_WAVES; i++) { wh[i][d] = run; run += c[i]; }
+      gbase[d] = offs[(u64)d * ntiles + blockIdx.x] - ex;
+    }
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++)
+  for (int r = 0; r < RSK_ITEMS; r++)
     if (pos[r] != 0xFFFFFFFFu) {
       const u32 d = pos[r] >> 16, l = wh[w][d] + (pos[r] & 0xFFFFu);
       keys_s[l] = key[r];
@@ -402,8 +414,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_staged_k(const u6
   __syncthreads();
   const u32 cnt = n - tile0 < (u32)RS_TILE ? n - tile0 : (u32)RS_TILE;
 #pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const u32 j = r * RS_THREADS + threadIdx.x;
+  for (int r = 0; r < RSK_ITEMS; r++) {
+    const u32 j = r * RSK_THREADS + threadIdx.x;
     if (j < cnt) {
       const u32 at = dest_s[j];
       keys_out[at] = keys_s[j];
@@ -419,7 +431,7 @@ inline void radix_pass_kv(const u64 *keys_in, const u32 *vals_in, u64 *keys_out,
   hipLaunchKernelGGL(radix_hist_key_k, dim3((ntiles + RH_TILES - 1) / RH_TILES), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
   exclusive_scan<u32>(LoadAs<u32, u32>{hist_ws}, (u64)256 * ntiles, StoreTo<u32>{hist_ws}, tile_ws, (u32 *)nullptr, st);
   static const bool direct = getenv("SCALCE_RADIX_DIRECT") != nullptr;
-  if (!direct) hipLaunchKernelGGL(radix_scatter_kv_staged_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+  if (!direct) hipLaunchKernelGGL(radix_scatter_kv_staged_k, dim3(ntiles), dim3(RSK_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
                                   hist_ws, ntiles);
   else
   hipLaunchKernelGGL(radix_scatter_kv_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
