@@ -433,7 +433,11 @@ __global__ __launch_bounds__(256) void gather_rows_k(u64 nrec, const u32 *perm, 
     u64 k = i0 / width;
     u32 w = (u32)(i0 - k * width);
     const u8 *src = rows + (u64)perm[k] * stride;
-    if (words) {  // rows are whole words: four 4-byte moves
+    if (words && w + 16 <= width && i0 + 16 <= total) {  // the chunk lies inside one row: one 16-byte load at a 4-byte boundary
+      typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      const u32x4u v = *reinterpret_cast<const u32x4u *>(src + w);
+      *reinterpret_cast<uint4 *>(out + i0) = make_uint4(v.x, v.y, v.z, v.w);
+    } else if (words) {  // rows are whole words: four 4-byte moves
       u32 v[4] = {0, 0, 0, 0};
       for (int j = 0; j < 4; j++) {
         if (i0 + 4 * j >= total) break;
