@@ -101,6 +101,7 @@ def lib():
     L.scalce_batch_entropy_stream_begin.argtypes = [vp, i32, vp, vp, u64, vp]
     L.scalce_batch_entropy_stream_prepare.argtypes = [vp, i32, vp, vp, u64, vp]
     L.scalce_batch_entropy_begin_group.argtypes = [C.POINTER(vp), i32, vp, vp]
+    L.scalce_batch_entropy_begin_group_last.argtypes = [C.POINTER(vp), i32, vp, vp, i32]
     L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
     L.scalce_batch_finish.argtypes = [vp, vp]
     L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
@@ -311,11 +312,11 @@ def shard_result_free(res):
     lib().scalce_shard_result_free(C.byref(res))
 
 
-def entropy_begin_group(batches, prep_stream=0, stream=0):
+def entropy_begin_group(batches, prep_stream=0, stream=0, last=False):
     """ONE coder launch over the blocks of several shards (scalce_batch_entropy_begin_group); each shard is completed
-    by its own entropy_end / finish on `stream`."""
+    by its own entropy_end / finish on `stream`.  last: nothing will be queued behind this launch (the end of a run)."""
     arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
-    batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group(arr, len(batches), prep_stream, stream))
+    batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group_last(arr, len(batches), prep_stream, stream, 1 if last else 0))
 
 
 class StreamStats(C.Structure):

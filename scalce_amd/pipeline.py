@@ -86,14 +86,16 @@ class ShardPipeline:
             return
         self._pending.append(slot)
         if len(self._pending) == self.G or flush:
-            self.flush()
+            self.flush(last=flush)
 
-    def flush(self):
+    def flush(self, last=False):
+        """last: the caller has no further shards (the end of a run): the launch is picked for its own latency."""
         if not self._pending:
             return
         coder = self.coders[self._launches % len(self.coders)]
         self._launches += 1
-        host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, coder.cuda_stream)
+        host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, coder.cuda_stream,
+                                 last=last and not self.sharded)
         ev = self.torch.cuda.Event()
         ev.record(coder)
         for sl in self._pending:
@@ -103,6 +105,6 @@ class ShardPipeline:
             self.trace("coder launched")
 
     def drain(self):
-        self.flush()
+        self.flush(last=True)
         for slot in range(self.D):
             self.retire(slot)
