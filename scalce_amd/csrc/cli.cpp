@@ -328,8 +328,14 @@ struct MateSource {
   }
   uint64_t fpos = 0;  // plain files: where the next read starts
   bool hold_at_file_end = false;  // fill_peek: the sample never runs into the next file
+  // The reference reads every file on its own, line by line (compress.cpp:756-811, gzgets): a file whose last line has no
+  // newline still ends there.  Concatenated byte-wise that line would run into the next file's '@name', so a file that
+  // does not end in a newline is given one.
+  uint8_t last_byte = '\n';
+  bool pending_newline = false;
   int64_t read_raw(void *dst, uint64_t cap) {
     for (;;) {
+      if (pending_newline && cap) { pending_newline = false; last_byte = '\n'; *static_cast<uint8_t *>(dst) = '\n'; return 1; }
       if (fd < 0 && !gz) {
         if (hold_at_file_end && cur >= 1) return 0;
         if (!open_next()) return 0;
@@ -339,8 +345,9 @@ struct MateSource {
       if (gz) k = pgz.read(dst, cap);
       else k = read_plain(static_cast<uint8_t *>(dst), cap);
       if (k < 0) return -1;
-      if (k > 0) return k;
+      if (k > 0) { last_byte = static_cast<uint8_t *>(dst)[k - 1]; return k; }
       if (gz) { gz_parallel_windows += pgz.parallel_windows; gz_serial_bytes += pgz.serial_bytes; pgz.close(); gz = false; } else { ::close(fd); fd = -1; }
+      if (last_byte != '\n') pending_newline = true;
     }
   }
   // A big request on a plain file is cut into slices read by several threads at once (pread): one thread copying out
@@ -919,10 +926,17 @@ static bool plain_single_input(const Options &o, const std::vector<std::string> 
   }
   return true;
 }
+// files the parent of a --gpus run must not leave behind, whichever way it ends (FAIL() is exit(1): atexit runs; the ranks
+// leave through _exit and never get here)
+static std::vector<std::string> g_unlink_at_exit;
+static void unlink_at_exit() { for (auto &f : g_unlink_at_exit) unlink(f.c_str()); }
 static std::string materialize_inputs(Options &o, const std::vector<std::string> &files, const char *tag, std::vector<std::string> &made) {
   struct stat st;
   std::string dir = o.temp;
-  if (stat(dir.c_str(), &st) != 0 && mkdir(dir.c_str(), 0777) != 0) dir = "/tmp";
+  // (no silent fall-back to /tmp: at full size this is 100+ GB, and the user said where temporary files go)
+  if (stat(dir.c_str(), &st) != 0 && mkdir(dir.c_str(), 0777) != 0) FAIL("Cannot create temporary directory %s (-t)\n", dir.c_str());
+  static bool registered = false;
+  if (!registered) { atexit(unlink_at_exit); registered = true; }
   // the mate digit is the LAST '1' of the path (get_second_file, const.cpp:51-64): it closes the name
   std::string base = dir + "/scalce_gpus_" + tag + "_m";
   for (char &c : base) if (&c >= &base[dir.size()] && c == '1') c = 'x';
@@ -939,6 +953,7 @@ static std::string materialize_inputs(Options &o, const std::vector<std::string>
     FILE *f = fopen(out.c_str(), "wb");
     if (!f) FAIL("Cannot create %s\n", out.c_str());
     made.push_back(out);
+    g_unlink_at_exit.push_back(out);
     uint64_t total = 0;
     for (;;) {
       const size_t before = src.cur;
@@ -1025,7 +1040,12 @@ static int multi_gpu_compress(const Options &o_in, const std::vector<std::string
       for (pid_t o2 : kids) if (o2 > 0) kill(o2, SIGTERM);
     }
   }
-  if (bad) { fprintf(stderr, "(ERROR) a rank failed\n"); return 1; }
+  if (bad) {  // what the ranks had written so far is not an archive: nothing stays behind under the output name
+    for (int m = 0; m < (o.paired ? 2 : 1); m++)
+      for (const char *ext : {"r", "n", "q"}) unlink((o.out + "_" + std::to_string(m + 1) + ".scalce" + ext).c_str());
+    fprintf(stderr, "(ERROR) a rank failed\n");
+    return 1;
+  }
   if (uncut) return EXIT_UNCUT;  // every rank found the same: -B does not cut this run (the caller goes on with one GPU)
   if (o_in.container != 0) {  // compress.cpp:249: the arithmetic-coded stream is never containerised
     const int hw = (int)std::thread::hardware_concurrency();

@@ -11,6 +11,10 @@
 //   3. the chain is checked -- each thread must END exactly where the next one started (a "member" found inside another
 //      member's stored data would fail this) -- and where it does not, the rest of the window is redone by one thread.
 // A file that is ONE member (plain `gzip`, pigz) has no inner starts: it streams through a single z_stream, as before.
+// Behind a complete member, bytes that do not begin with the gzip magic end the stream, as they do for zlib's gzread
+// (gz_look: "trailing garbage is ignored" -- zero padding of block-aligned or tape-written files); a member header that
+// does begin with the magic but is damaged, or a damaged member body, is an error.  A member of more than MEMBER_CAP bytes
+// of text is never held whole: the parallel window ends in front of it and the one stream takes it piece by piece.
 // Output order is file order.  zlib only; nothing here knows about FASTQ.
 #pragma once
 #include <fcntl.h>
@@ -21,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -47,7 +52,9 @@ class ParGz {
     pos_ = 0;
     memset(&zs_, 0, sizeof zs_);
     zs_open_ = false;
+    members_done_ = false;
     parallel_windows = serial_bytes = 0;
+    if (const char *e = getenv("SCALCE_PARGZ_MEMBER_CAP")) MEMBER_CAP = (size_t)std::max(1ll, atoll(e));
     return true;
   }
   void close() {
@@ -78,6 +85,8 @@ class ParGz {
  private:
   static constexpr uint64_t WINDOW = 256ull << 20;
   static constexpr size_t SERIAL_OUT = 64u << 20;
+  size_t MEMBER_CAP = 1024u << 20;  // text bytes of one member a parallel window will hold (SCALCE_PARGZ_MEMBER_CAP: tests)
+  bool members_done_ = false;  // at least one member has been inflated completely: a non-gzip tail is the end of the file
   int fd_ = -1;
   const uint8_t *map_ = nullptr;
   uint64_t size_ = 0, pos_ = 0;
@@ -87,14 +96,20 @@ class ParGz {
   std::vector<std::vector<uint8_t>> outs_;
   size_t cur_ = 0, cur_off_ = 0;
 
-  static bool header_sane(const uint8_t *p, uint64_t left) {
-    if (left < 18 || p[0] != 0x1F || p[1] != 0x8B || p[2] != 8) return false;
-    if (p[3] & 0xE0) return false;                       // reserved flag bits
-    return p[8] == 0 || p[8] == 2 || p[8] == 4;          // XFL as deflate writers set it
+  static bool has_magic(const uint8_t *p, uint64_t left) { return left >= 2 && p[0] == 0x1F && p[1] == 0x8B; }
+  // the header of the member the stream stands at: what zlib itself insists on (method, reserved flag bits)
+  static bool header_ok(const uint8_t *p, uint64_t left) {
+    return left >= 18 && has_magic(p, left) && p[2] == 8 && !(p[3] & 0xE0);
   }
+  // a CANDIDATE start found by scanning compressed bytes: also XFL as deflate writers set it (fewer false starts to inflate)
+  static bool header_sane(const uint8_t *p, uint64_t left) {
+    return header_ok(p, left) && (p[8] == 0 || p[8] == 2 || p[8] == 4);
+  }
+  // behind a complete member: anything that does not begin with the magic ends the file (zlib gz_look)
+  bool at_tail_garbage() const { return members_done_ && pos_ < size_ && !has_magic(map_ + pos_, size_ - pos_); }
   // BGZF: extra subfield 'B','C' holds the member's size - 1
   static uint64_t bgzf_size(const uint8_t *p, uint64_t left) {
-    if (!header_sane(p, left) || !(p[3] & 4)) return 0;
+    if (!header_ok(p, left) || !(p[3] & 4)) return 0;
     const uint32_t xlen = p[10] | (p[11] << 8);
     if (12 + (uint64_t)xlen > left) return 0;
     for (uint32_t i = 0; i + 4 <= xlen;) {
@@ -106,7 +121,9 @@ class ParGz {
     return 0;
   }
   // one whole member at `at`, appended to out; returns the bytes it took, 0 if it is not a valid member
-  uint64_t inflate_member(uint64_t at, std::vector<uint8_t> &out, size_t give_up_at) const {
+  // (give_up_at: stop once the member has produced more text than that; *gave_up says it was that and not damage)
+  uint64_t inflate_member(uint64_t at, std::vector<uint8_t> &out, size_t give_up_at, bool *gave_up = nullptr) const {
+    if (gave_up) *gave_up = false;
     z_stream z;
     memset(&z, 0, sizeof z);
     if (inflateInit2(&z, 15 + 16) != Z_OK) return 0;
@@ -125,12 +142,13 @@ class ParGz {
       out.resize(out.capacity());
       z.next_out = out.data() + old;
       z.avail_out = (uInt)std::min<size_t>(room, 1u << 30);
+      if (give_up_at) z.avail_out = (uInt)std::min<size_t>(z.avail_out, give_up_at + 1 - std::min(give_up_at, old - start));  // (never past the cap in one call)
       const uInt offered = z.avail_out;
       rc = inflate(&z, Z_NO_FLUSH);
       out.resize(old + (offered - z.avail_out));
       in_done += fed - z.avail_in;
       if (rc != Z_OK && rc != Z_STREAM_END) break;
-      if (give_up_at && out.size() - start > give_up_at) { rc = Z_DATA_ERROR; break; }
+      if (give_up_at && out.size() - start > give_up_at && rc != Z_STREAM_END) { rc = Z_DATA_ERROR; if (gave_up) *gave_up = true; break; }
     }
     inflateEnd(&z);
     if (rc != Z_STREAM_END) { out.resize(start); return 0; }
@@ -143,7 +161,7 @@ class ParGz {
       if (!hit) break;
       c = (uint64_t)(static_cast<const uint8_t *>(hit) - map_);
       if (header_sane(map_ + c, size_ - c)) {
-        const uint64_t k = inflate_member(c, out, 512u << 20);  // (a false start usually dies within a few bytes)
+        const uint64_t k = inflate_member(c, out, std::min<size_t>(512u << 20, MEMBER_CAP));  // (a false start usually dies within a few bytes)
         if (k) { *len = k; return c; }
       }
       c++;
@@ -152,6 +170,7 @@ class ParGz {
   }
   bool serial_step() {  // up to SERIAL_OUT bytes through the one stream; it stays open inside a member
     if (!zs_open_) {
+      if (at_tail_garbage()) { pos_ = size_; return true; }
       memset(&zs_, 0, sizeof zs_);
       if (inflateInit2(&zs_, 15 + 16) != Z_OK) return false;
       zs_open_ = true;
@@ -169,7 +188,7 @@ class ParGz {
       const int rc = inflate(&zs_, Z_NO_FLUSH);
       got += offered - zs_.avail_out;
       pos_ += fed - zs_.avail_in;
-      if (rc == Z_STREAM_END) { inflateEnd(&zs_); zs_open_ = false; break; }  // a member boundary: the next window may go parallel
+      if (rc == Z_STREAM_END) { inflateEnd(&zs_); zs_open_ = false; members_done_ = true; break; }  // a member boundary: the next window may go parallel
       if (rc != Z_OK) return false;
     }
     out.resize(got);
@@ -180,12 +199,13 @@ class ParGz {
   bool fill() {
     if (zs_open_ || threads_ == 1) return serial_step();
     if (pos_ >= size_) return true;
-    if (!header_sane(map_ + pos_, size_ - pos_)) return false;
+    if (at_tail_garbage()) { pos_ = size_; return true; }
+    if (!header_ok(map_ + pos_, size_ - pos_)) return serial_step();  // (zlib decides: a short or odd header is its to judge)
     const uint64_t wend = std::min(size_, pos_ + WINDOW);
     const int T = (int)std::min<uint64_t>((uint64_t)threads_, std::max<uint64_t>(1, (wend - pos_) >> 20));
     std::vector<uint64_t> start(T, ~0ull), first_len(T, 0), end(T, 0);
     std::vector<std::vector<uint8_t>> out(T);
-    std::vector<char> ok(T, 1);
+    std::vector<char> ok(T, 1), stopped(T, 0);
     start[0] = pos_;
     const uint64_t seg = (wend - pos_ + T - 1) / T;
     const bool bgzf = bgzf_size(map_ + pos_, size_ - pos_) != 0;
@@ -223,8 +243,10 @@ class ParGz {
         uint64_t at = start[i];
         if (first_len[i]) at += first_len[i];  // (its first member is already in out[i])
         while (at < stop && at < size_) {
-          const uint64_t k = inflate_member(at, out[i], 0);
-          if (!k) { ok[i] = 0; break; }
+          if (at != start[i] && !has_magic(map_ + at, size_ - at)) { stopped[i] = 1; break; }  // tail garbage behind a member: the next fill ends the file
+          bool big = false;
+          const uint64_t k = inflate_member(at, out[i], MEMBER_CAP, &big);
+          if (!k) { if (big) stopped[i] = 1; else ok[i] = 0; break; }  // too large to hold whole: the one stream takes it from here
           at += k;
         }
         end[i] = at;
@@ -232,14 +254,19 @@ class ParGz {
     for (auto &t : pool) t.join();
     // the chain: thread q must end where thread q + 1 began
     size_t good = 0;
+    const uint64_t pos0 = pos_;
     for (; good < idx.size(); good++) {
       const int i = idx[good];
-      if (!ok[i]) break;
+      if (!ok[i]) {  // damage: what the thread inflated before it is good (and is kept), the one stream reports the rest
+        if (end[i] > start[i]) { outs_.push_back(std::move(out[i])); pos_ = end[i]; members_done_ = true; good++; }
+        break;
+      }
       outs_.push_back(std::move(out[i]));
       pos_ = end[i];
-      if (good + 1 < idx.size() && end[i] != start[idx[good + 1]]) { good++; break; }
+      if (end[i] > start[i]) members_done_ = true;
+      if (stopped[i] || (good + 1 < idx.size() && end[i] != start[idx[good + 1]])) { good++; break; }
     }
-    if (good == 0) return false;  // the member at pos_ itself is damaged
+    if (pos_ == pos0) return serial_step();  // the member at pos_ itself is too large for a window, or damaged: the one stream
     parallel_windows++;
     return true;  // (whatever was not taken is redone from pos_ by the next fill)
   }

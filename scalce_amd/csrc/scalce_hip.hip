@@ -247,6 +247,7 @@ struct scalce_workspace {
   DBuf name_off;
   DBuf tw_cells, tw_cand, tw_bits, tw_base;  // the tie-break in windows (tokenize_windows)
   DBuf tile_mm[2];                           // per text tile: smallest / largest q' symbol (ingest_tiles2_k)
+  const void *tile_mm_owner[2] = {nullptr, nullptr};  // the batch whose piece they describe (batches share a workspace)
   DBuf cell_sorted;                          // name cells in output order (emit stage)
   void free_all() {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
@@ -720,6 +721,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
         LAUNCH(ingest_tiles2_k<false>, ntiles2, ING_THREADS, 0, s, ga);
       }
       b->mm_valid[mate] = true;
+      b->ws->tile_mm_owner[mate] = b;
     }
     { int rc = read_u32(b, b->d_small + 16, flags, 2, s); if (rc) return rc; }
     if (lookback) {
@@ -900,7 +902,9 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     u32 *minmax = b->d_small + 24;  // smallest / largest symbol of the piece
     HIP_TRY(c, hipMemsetAsync(minmax, 0xFF, sizeof(u32), s));
     HIP_TRY(c, hipMemsetAsync(minmax + 1, 0, sizeof(u32), s));
-    if (b->mm_valid[m]) {  // the ingest kernel left the range of every tile of the piece's text
+    // the ingest kernel left the range of every tile of the piece's text -- in the WORKSPACE: if another batch that shares it
+    // has ingested since, the ranges are that batch's, and the piece's own q' rows are scanned instead
+    if (b->mm_valid[m] && b->ws->tile_mm_owner[m] == b) {
       const u32 nt = cdiv(b->text_bytes[m], ING_TILE);
       LAUNCH(tile_minmax_reduce_k, cdiv(nt, 256 * 16) ? cdiv(nt, 256 * 16) : 1, 256, 0, s, b->tile_mm[m].as<u16>(), nt, minmax);
     } else {

@@ -322,6 +322,37 @@ def test_cli_gpus_several_files_gzip_in_and_out(tmp_path, monkeypatch):
     assert not list((tmp_path / "tmpd").glob("scalce_gpus_*")), "the plain copy of the input was left behind"
 
 
+def test_cli_input_files_without_a_trailing_newline(tmp_path, monkeypatch):
+    """Several input files none of which ends in a newline: every file's last quality line still ends with the file
+    (concatenated byte-wise it ran into the next file's '@name').  The reference itself cannot read such a file
+    (it takes the read length from a line it assumes ends in a newline: 'read length: 99', then fails), so the pin is the
+    archive of the same records WITH the newlines -- on one GPU and through --gpus (the plain copy under -t)."""
+    monkeypatch.setenv("SCALCE_COMM", "shm")
+    n, L = 30000, 100
+    b1, q1 = synth.reads_and_quals(n, L, seed=96, n_frac=0.004, dup_frac=0.1)
+    cuts = [0, 700, 20000, n]
+    with_nl, without = [], []
+    for k in range(3):
+        text = b"".join(b"@s.%d\n" % i + b1[i].tobytes() + b"\n+\n" + q1[i].tobytes() + b"\n" for i in range(cuts[k], cuts[k + 1]))
+        a, b = tmp_path / ("nl%c_1.fq" % (97 + k)), tmp_path / ("no%c_1.fq" % (97 + k))
+        open(a, "wb").write(text)
+        open(b, "wb").write(gzip.compress(text[:-1], 1) if k == 1 else text[:-1])
+        with_nl.append(a)
+        without.append(b)
+    flags = ["-c", "no", "-B", "1M", "-s", "5000"]
+    run_cli(*flags, "-o", tmp_path / "want", *with_nl, "--patterns-bin", PBIN)
+    run_cli(*flags, "-o", tmp_path / "got", *without, "--patterns-bin", PBIN)
+    run_cli(*flags, "--gpus", 2, "-t", tmp_path / "tmpd", "-o", tmp_path / "got2", *without, "--patterns-bin", PBIN)
+    for ext in "nrq":
+        want = open(tmp_path / f"want_1.scalce{ext}", "rb").read()
+        assert open(tmp_path / f"got_1.scalce{ext}", "rb").read() == want, ext
+        assert open(tmp_path / f"got2_1.scalce{ext}", "rb").read() == want, ext + " (--gpus 2)"
+    # --gpus: a temporary directory that cannot be made is an error, not a silent /tmp
+    r = subprocess.run([CLI, *flags, "--gpus", "2", "-t", str(tmp_path / "no" / "such" / "dir"), "-o", str(tmp_path / "x"), *map(str, without),
+                        "--patterns-bin", PBIN], capture_output=True, text=True)
+    assert r.returncode != 0 and "temporary directory" in r.stderr, r.stderr[-400:]
+
+
 def test_cli_gpus_over_rccl_when_there_are_two_gpus(tmp_path):
     """The N > 1 data path over RCCL (ncclAllGather / AllReduce / Send / Recv between processes that own a GPU each): runs
     wherever two GPUs are visible -- the driver's 8-GPU box -- and is skipped on a one-GPU box, where the same code runs

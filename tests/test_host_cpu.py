@@ -230,3 +230,29 @@ def test_parallel_gzip_reader(kind, tmp_path):
         open(path, "wb").write(data[:-9])
         r = subprocess.run([cat, str(path), "8"], capture_output=True)
         assert r.returncode == 1
+    # Behind a complete member anything that does not begin with the gzip magic ends the file, as for zlib's gzread
+    # (gz_look ignores trailing garbage: zero padding of block-aligned or tape-written files), whatever XFL the writer set.
+    for tail in (b"\0" * 4096, b"\0", b"trailing garbage, not gzip" * 100):
+        open(path, "wb").write(data + tail)
+        for threads in (1, 8):
+            r = subprocess.run([cat, str(path), str(threads)], capture_output=True)
+            assert r.returncode == 0 and r.stdout == text, f"{kind} + {len(tail)} tail bytes, {threads} threads: {r.stderr[-200:]}"
+    if kind == "many_members":   # a writer that sets another XFL (zlib only writes 0, 2, 4) is still a member where the stream stands
+        odd = bytearray(data)
+        odd[8] = 3
+        open(path, "wb").write(bytes(odd))
+        r = subprocess.run([cat, str(path), "8"], capture_output=True)
+        assert r.returncode == 0 and r.stdout == text
+        # a member too large to be held whole by a window (cap lowered for the test) goes through the one stream, in order
+        big = gzip.compress(text[:300_000], 1) * 7 + gzip.compress(text[:2_500_000], 1) + data
+        open(path, "wb").write(big)
+        env = dict(os.environ, SCALCE_PARGZ_MEMBER_CAP=str(1 << 20))
+        r = subprocess.run([cat, str(path), "8"], capture_output=True, env=env)
+        assert r.returncode == 0 and r.stdout == gzip.decompress(big) and b"serial_bytes 0" not in r.stderr, r.stderr
+        # a member whose body is damaged in the middle of the file is still an error
+        bad = bytearray(data)
+        for k in range(len(bad) // 2, len(bad) // 2 + 64):
+            bad[k] ^= 0x5A
+        open(path, "wb").write(bytes(bad))
+        r = subprocess.run([cat, str(path), "8"], capture_output=True)
+        assert r.returncode == 1
