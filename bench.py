@@ -53,6 +53,11 @@ def main():
     ap.add_argument("--stage-times", action="store_true", help="also print per-stage HIP-event times to stderr")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> archive leg (the `scalce` binary on the same shard written to a file)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the last timed shard (device decode + record digest)")
+    ap.add_argument("--shared-input", action="store_true",
+                    help="every shard in flight reads the SAME text tensor (rounds 1-3; more shards fit).  Default: one distinct text per shard in flight")
+    ap.add_argument("--ref-full-shard", action="store_true",
+                    help="also run the reference's own compress() -T 1 on the whole bench shard on this box's host (~5 min for 50 M reads) and "
+                         "compare its three archive files with the product's, byte for byte (parity.ref_full_shard)")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,7 +83,8 @@ def main():
     n, L = args.reads, args.length
     blob = open(os.path.join(ROOT, "tests", "golden", "patterns.bin"), "rb").read()
     ctx = host.Context(local, patterns_bin=blob)
-    text = synth_gpu.fastq_on_device(n, L, dev, seed=20261003 + rank, first_index=rank * n)
+    SEED0 = 20261003
+    text = synth_gpu.fastq_on_device(n, L, dev, seed=SEED0 + rank, first_index=rank * n)
     nbytes = text.numel()
     # quality model from the first 100 000 records of the shard (quality_mapping_init's sample)
     head = text[: min(nbytes, 100000 * (2 * L + 20))].cpu().numpy().tobytes()
@@ -129,17 +135,29 @@ def main():
         G = 3 if sharded else 4
     G = max(1, G)
     D = max(1, args.inflight) if args.inflight is not None else (2 * G if sharded else 3 * G + 2)
-    if args.inflight is None and not sharded:
-        # what is free now decides how many shards fit: ~20 GB of shared front-stage buffers + the shard's text + ~15.3 GB per
-        # shard in flight at 50 M x 100 bp (measured: 243 GB at fourteen), with a margin for the self-check's buffers
+    # Every shard in flight has a text of its OWN (round 4; VERDICT r3: fourteen jobs that read one tensor are not fourteen
+    # jobs a card can hold).  What is free now decides how many fit: ~20 GB of shared front-stage buffers + per shard in
+    # flight its text (10.8 GB) and ~12.2 GB of the batch's own (reordered q' 5, coder blocks 5 sized for the worst case,
+    # records 1.25, names 0.54, tables; the framed stream is no longer a second copy: scalce_batch_set_frame_on_demand).
+    own_text = not args.shared_input
+    if args.inflight is None:
         free_b, _ = torch.cuda.mem_get_info()
-        per_slot = 15.3e9 * (n * L) / 5e9
-        fit = int((free_b - 22e9 * (n * L) / 5e9 - 14e9) // per_slot)
+        scale = (n * L) / 5e9
+        per_slot = (12.3e9 if not sharded else 36e9) * scale + (nbytes if own_text else 0)
+        fit = int((free_b + (nbytes if own_text else 0) - 22e9 * scale - 5e9) // per_slot)
         if fit < D:
-            print("bench: %.0f GB of HBM free: %d shards in flight instead of %d" % (free_b / 1e9, max(fit, 2 * G), D), file=sys.stderr)
+            print("bench: %.0f GB of HBM free: %d shards in flight instead of %d" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D), file=sys.stderr)
             D = fit
     if G > 1:
         D = max(D, 2 * G)
+    # slot i reads texts[i]: different seeds, the same record shape (sizes are equal: names and lengths are)
+    texts = [text]
+    if own_text:
+        for i in range(1, D):
+            texts.append(synth_gpu.fastq_on_device(n, L, dev, seed=SEED0 + rank + 7919 * i, first_index=rank * n))
+            assert texts[-1].numel() == nbytes
+    else:
+        texts = [text] * D
     if sharded and "SCALCE_AC_BLOCKS_PER_WG" not in os.environ and D < 3 * G:
         os.environ["SCALCE_AC_BLOCKS_PER_WG"] = "8"
     # -B: the reference's default, 4 GiB of record bytes per spill chunk (main.cpp:68) -- 50 M reads of 100 bp are 3 chunks
@@ -159,6 +177,9 @@ def main():
         ws = None if os.environ.get("SCALCE_BENCH_OWN_WORKSPACES") else host.Workspace(ctxs[f])
         batches += [host.Batch(ctxs[f], L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B,
                                workspace=ws) for _ in range(D // F)]
+    if not sharded:
+        for b in batches:   # the coded blocks are framed when they are delivered (scalce_batch_qual_window), not by a copy pass
+            b.set_frame_on_demand(True)
     batch = batches[0]
     state = {}
 
@@ -178,7 +199,7 @@ def main():
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
     DF = D // F
-    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "3" if (G > 1 and DF >= 3 * G) else "1"))
+    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "3" if (G > 1 and DF >= 3 * G) else "2" if (G > 1 and DF >= 2 * G + 2 and not sharded) else "1"))
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
                            coder_streams=n_coder_streams)
              for f in range(F)]
@@ -205,19 +226,22 @@ def main():
         if errs:
             raise errs[0]
 
+    slot_of_pipe = {id(p): f * DF for f, p in enumerate(pipes)}
+
     def run_on(pipe, k):
         for j in range(k):
             slot, b = pipe.acquire()
             mark(f"shard {j}: front (slot {slot})")
+            tx = texts[slot_of_pipe[id(pipe)] + slot]
             with torch.cuda.stream(pipe.front):
                 if not sharded:
-                    b.front(text.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream)
+                    b.front(tx.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream)
                 elif G == 1:
-                    state[slot] = host.sharded_compress(comm, ctx, b, text.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
+                    state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
                                                         stream=pipe.front.cuda_stream, coder_stream=pipe.coder.cuda_stream,
                                                         result=state.get(slot))
                 else:
-                    state[slot] = host.sharded_compress(comm, ctx, b, text.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
+                    state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
                                                         stream=pipe.front.cuda_stream, result=state.get(slot))
             mark(f"shard {j}: front done")
             pipe.submit(slot, tag=j, flush=j + 1 == k)
@@ -249,30 +273,75 @@ def main():
     stats = batch.stats()
     out_bytes = sum(batch.output_ptr(w, 0)[1] for w in (host.OUT_READS, host.OUT_NAMES, host.OUT_QUAL))
 
+    # ---- the run proves its own output (never inside the timed region) ----
+    parity = {}
+    decode = None
+    if rank == 0 and not sharded and not args.no_verify:
+        from scalce_amd import verify
+        # the checks need room (5 GB of symbols, 10.8 GB of text, the digest's temporaries): everything but slot 0 and the slot
+        # of the last timed shard goes first
+        last_slot = (pipe._next - 1) % DF
+        for i, b in enumerate(batches):
+            if i not in (0, last_slot):
+                b.close()
+        for i in range(len(texts)):
+            if i not in (0, last_slot):
+                texts[i] = None
+        torch.cuda.empty_cache()
+        # (1) byte identity with the REFERENCE at full size.  tests/golden/full_size_ref.json holds the SHA-256 of the three
+        # files the reference's own compress() wrote for the text of slot 0 (made on a GPU box by tools/full_size_ref_check.py:
+        # 286 s of CPU).  Slot 0's batch still holds the archive streams of the last shard it took in the timed loop: with the
+        # file headers in front they must hash to the same three values -- bucket assignment, tie-break winners, in-bucket
+        # order, chunk merge and every coder byte.
+        gold_path = os.path.join(ROOT, "tests", "golden", "full_size_ref.json")
+        try:
+            gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
+            if gold and (gold["reads"], gold["length"], gold["seed"]) == (n, L, SEED0) and B == 4 << 30 and world == 1:
+                tv0 = time.perf_counter()
+                got = verify.archive_hashes(batches[0], L, off, n)
+                same = {k: got[k] == v["sha256"] for k, v in gold["files"].items()}
+                parity["reference_full_size"] = {
+                    "ok": all(same.values()), "files": same, "timed_shard": bool(args.steps >= D),
+                    "what": "slot 0's shard of the timed loop: SHA-256 of .scalce{n,r,q} (streams in HBM + file headers) equal to what the "
+                            "reference's own compress() -T 1 wrote for the same text (tests/golden/full_size_ref.json; 3 spill chunks, factor 2)",
+                    "seconds": round(time.perf_counter() - tv0, 2)}
+        except Exception as ex:  # noqa: BLE001
+            parity["reference_full_size"] = {"ok": False, "error": repr(ex)[:300]}
+        # (2) the LAST timed shard decoded on the device back to FASTQ text, record multiset equal to its input's; the two
+        # device stages of that are the decode leg of the measurement
+        try:
+            last = pipe.batches[last_slot]      # the batch that holds the last timed shard (of the first front)
+            tv0 = time.perf_counter()
+            want = verify.record_digest(texts[last_slot])
+            tm = {}
+            back = verify.decode_shard(last.ctx, last, L, off, dev, timings=tm)
+            got = verify.record_digest(back)
+            parity["full_shard"] = {"ok": bool(got == want and want[0] == n), "records": got[0],
+                                    "what": "last timed shard: archive streams -> scalce_ac_decode + scalce_fastq_records on the "
+                                            "device -> FASTQ text; (count, two 64-bit sums of per-record hashes) equal to the input's",
+                                    "seconds": round(time.perf_counter() - tv0, 2)}
+            dsec = tm["ac_decode"] + tm["records"]
+            nblk_dec = (tm["symbols"] + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024)
+            decode = {"value": round(tm["text_bytes"] / dsec / 1e6, 1), "unit": "MB/s of FASTQ restored", "seconds": round(dsec, 3),
+                      "ac_decode_ms": round(tm["ac_decode"] * 1e3, 1), "records_ms": round(tm["records"] * 1e3, 1),
+                      "ns_per_symbol_per_block": round(tm["ac_decode"] * 1e9 / min(tm["symbols"], 10 * 1024 * 1024), 1),
+                      "blocks": int(nblk_dec),
+                      "what": "the last timed shard's archive, coded stream resident in HBM: scalce_ac_decode (arithmetic.cpp:196-268, one "
+                              "serial chain per 10 MiB block) + scalce_fastq_records (decompress.cpp:240-366); one job alone on the card"}
+            del back
+        except Exception as ex:  # noqa: BLE001
+            parity["full_shard"] = {"ok": False, "error": repr(ex)[:300]}
     if args.stage_times and rank == 0:
         batch.stage_reset(True)
         batch.compress(text.data_ptr(), nbytes, None, 0, front.cuda_stream)
         batch.finish(front.cuda_stream)
         print("stage ms:", {s: round(v[0], 2) for s, v in batch.stage_ms().items()}, stats, file=sys.stderr)
         batch.stage_reset(False)
-
-    # ---- the run proves its own output (never inside the timed region) ----
-    parity = {}
-    if rank == 0 and not sharded and not args.no_verify:
+    if rank == 0 and world == 1 and args.ref_full_shard:
         try:
-            from scalce_amd import verify
-            last = pipe.batches[(pipe._next - 1) % DF]      # the batch that holds the last timed shard (of the first front)
-            tv0 = time.perf_counter()
-            want = verify.record_digest(text)
-            back = verify.decode_shard(last.ctx, last, L, off, dev)
-            got = verify.record_digest(back)
-            parity["full_shard"] = {"ok": bool(got == want and want[0] == n), "records": got[0],
-                                    "what": "last timed shard: archive streams -> scalce_ac_decode + scalce_fastq_records on the "
-                                            "device -> FASTQ text; (count, two 64-bit sums of per-record hashes) equal to the input's",
-                                    "seconds": round(time.perf_counter() - tv0, 2)}
-            del back
+            parity["ref_full_shard"] = ref_full_shard(text, nbytes)
         except Exception as ex:  # noqa: BLE001
-            parity["full_shard"] = {"ok": False, "error": repr(ex)[:300]}
+            parity["ref_full_shard"] = {"ok": False, "error": repr(ex)[:300]}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:
@@ -285,6 +354,8 @@ def main():
         for b in batches:   # the CLI is a process of its own and needs the card's memory
             b.close()
         del batches[:], pipe, pipes[:]
+        texts[1:] = []
+        torch.cuda.empty_cache()
         try:
             e2e = end_to_end(text, nbytes)
         except Exception as ex:  # noqa: BLE001 - a side leg must not take the measured line with it
@@ -357,7 +428,11 @@ def main():
                        "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if not sharded else f": read ranges per rank, ONE archive; run-wide -B chunks / tie-break / quality model / 10 MiB blocks over {comm.world} rank(s) of " + ("shared memory (rehearsal)" if os.environ.get("SCALCE_COMM") == "shm" else "RCCL (all-gather, all-reduce, send/recv)")),
                        "bucket_set_size": B, "spill_chunks": stats["chunks"],
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
-                       "shards_in_flight": D, "shards_per_coder_launch": G, "front_threads": F, "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
+                       "shards_in_flight": D, "shards_per_coder_launch": G, "coder_streams": n_coder_streams, "front_threads": F,
+                       "inputs": ("one text tensor per shard in flight: %d distinct synthetic shards of the same shape (seeds %d + 7919 k), "
+                                  "each resident in HBM before the timed region; step j reads the text of slot j mod %d" % (D, SEED0, D)) if own_text
+                                 else "ONE text tensor read by every shard in flight (--shared-input)",
+                       "hbm_used_gb": hbm_used_gb, "ms_single_shard_alone": round(single_ms, 3) if single_ms else None},
             # achieved = algorithmic bytes of a step (the FASTQ record read once + the three archive streams
             # written once: 308 B per read) / ms_per_step, against the HBM peak.  `kernel` = the dominant kernel on its own:
             # algorithmic bytes of a launch (symbols in + coded bytes out) / its HIP-event time, its counter traffic, and the
@@ -375,9 +450,11 @@ def main():
                                     "note": "serial coder chain per 10 MiB block: the time of a launch is 10.5 M steps of one wavefront, "
                                             "whatever the number of blocks beside it"}},
             "cpu_baseline": cpu,
+            "decode": (dict(decode, cpu_baseline=(cpu or {}).get("decompress")) if decode else None),
             "e2e": e2e,
-            "note": "value = device-resident steady state with %d shards (independent jobs of the configs[1] size) in flight; "
-                    "value_single_job = one such job alone, input already in HBM; e2e = the scalce binary, file in, archive out" % D,
+            "note": "value = device-resident steady state with %d shards (independent jobs of the configs[1] size, each with its own "
+                    "input text) in flight; value_single_job = one such job alone, input already in HBM; decode = the inverse path on "
+                    "the last shard; e2e = the scalce binary, file in, archive out" % D,
         }
         print(json.dumps(line))
     if world > 1:
@@ -452,6 +529,51 @@ def end_to_end(text, nbytes):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def ref_full_shard(text, nbytes):
+    """--ref-full-shard: the reference's own compress() -T 1 on the WHOLE bench shard (as a file in /dev/shm) beside the
+    `scalce` binary on the same file; SHA-256 of the three archive files.  Minutes of CPU: off by default (the recorded
+    result of the same run is what parity.reference_full_size checks the timed shard against)."""
+    import hashlib
+    import shutil
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_full")
+    cli = os.path.join(ROOT, "scalce_amd", "bin", "scalce")
+    pbin = os.path.join(ROOT, "tests", "golden", "patterns.bin")
+    if not (os.path.exists(ref) and os.path.exists(cli)):
+        return {"ok": False, "error": "oracle/_ref/ref_full or the scalce binary is missing"}
+    d = tempfile.mkdtemp(prefix="scalce_refshard_", dir="/dev/shm" if os.access("/dev/shm", os.W_OK) else None)
+    try:
+        fq = os.path.join(d, "in_1.fq")
+        with open(fq, "wb") as f:
+            for a in range(0, nbytes, 1 << 30):
+                f.write(text[a:min(nbytes, a + (1 << 30))].cpu().numpy().tobytes())
+        p = subprocess.Popen([ref, "compress", pbin, fq, os.path.join(d, "ref"), "-c", "no", "-T", "1", "-t", os.path.join(d, "tmp")],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t0 = time.perf_counter()
+        r = subprocess.run([cli, "-c", "no", "-o", os.path.join(d, "hip"), fq, "--patterns-bin", pbin], capture_output=True, text=True)
+        if r.returncode:
+            p.kill()
+            return {"ok": False, "error": r.stderr[-300:]}
+        while p.poll() is None:
+            time.sleep(15)
+            print("bench: --ref-full-shard: the reference has been running for %.0f s" % (time.perf_counter() - t0), file=sys.stderr, flush=True)
+        if p.returncode:
+            return {"ok": False, "error": "ref_full failed"}
+        same = {}
+        for e in "nrq":
+            hs = []
+            for side in ("hip", "ref"):
+                h = hashlib.sha256()
+                with open(os.path.join(d, f"{side}_1.scalce{e}"), "rb") as f:
+                    for blk in iter(lambda: f.read(64 << 20), b""):
+                        h.update(blk)
+                hs.append(h.hexdigest())
+            same["scalce" + e] = hs[0] == hs[1]
+        return {"ok": all(same.values()), "files": same, "reference_seconds": round(time.perf_counter() - t0, 1),
+                "what": "`scalce -c no` and the reference's own compress() -T 1 on the whole bench shard as a file: SHA-256 of .scalce{n,r,q}"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def cpu_baseline(text, n, L, sample):
     """Time the CPU side on the first `sample` records of the same shard, on this box's host cores, and check the
     product against it on the same bytes.  Returns (cpu_baseline object, parity object).
@@ -502,7 +624,21 @@ def cpu_baseline(text, n, L, sample):
         dt4, rc4 = run_cpu(T, "cpuT") if T > 1 else (None, 1)
         what = ("oracle/_ref/ref_full compress -c no (the reference's own compress(), file in, archive out)" if use_ref
                 else "orc_cli compress -c no (C restatement)")
+        dec = None
+        if use_ref:   # the reference's own decompress() on the archive it has just written: the baseline of the decode leg
+            t0 = time.perf_counter()
+            r = subprocess.run([ref, "decompress", pbin, os.path.join(d, "cpu1_1.scalcen"), os.path.join(d, "back"), "-T", "1"], capture_output=True, text=True)
+            ddt = time.perf_counter() - t0
+            if r.returncode == 0 and os.path.exists(os.path.join(d, "back_1.fastq")):
+                dec = {"value": round(os.path.getsize(os.path.join(d, "back_1.fastq")) / ddt / 1e6, 2), "unit": "MB/s of FASTQ restored", "cores": 1,
+                       "kind": "reference", "sample": f"oracle/_ref/ref_full decompress -T 1 (the reference's own decompress()) on the archive of the same "
+                                                      f"{sample}-record sample, {ddt:.2f} s wall incl. file I/O on tmpfs"}
+                os.remove(os.path.join(d, "back_1.fastq"))
+        if not use_ref:
+            print("bench: oracle/_ref/ref_full is missing or did not run on this box: cpu_baseline and parity.sample use the C restatement "
+                  "(oracle/orc_cli, kind \"port\"), NOT the reference's own code", file=sys.stderr)
         cpu = {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
+               "decompress": dec,
                "sample": f"first {sample} records ({end} bytes) of the same shard, {what} -T 1, {dt:.2f} s wall incl. file I/O on tmpfs",
                "host_cpus": os.cpu_count(),
                "threads_default": None if rc4 != 0 else {

@@ -248,6 +248,16 @@ enum {
   SCALCE_OUT_BUCKET_NAME_BYTES = 11 /* (buckets+1) x u64: bytes of each bucket's records in SCALCE_OUT_NAMES (after emit) */
 };
 int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes);
+/* Framing on the way out (replaces the copy loop of ac_write, arithmetic.cpp:318-363: the reference frames each coded
+ * block -- [u32 size][bytes] -- as it writes it to the file).  With frame_on_demand set, the entropy stage leaves the coded
+ * blocks where the coder wrote them and only lays the frames out; scalce_batch_qual_window then delivers bytes
+ * [offset, offset + nbytes) of SCALCE_OUT_QUAL into dst -- device memory, or pinned host memory (4-byte aligned): the
+ * framing kernel's stores are the download -- so the stream never exists a second time in HBM.  Valid after
+ * scalce_batch_finish / _entropy_end.  A caller that asks scalce_batch_output for SCALCE_OUT_QUAL still gets the whole
+ * stream as one device buffer; it is put together at that moment. */
+int scalce_batch_set_frame_on_demand(scalce_batch *b, int on);
+int scalce_batch_qual_bytes(const scalce_batch *b, int mate, uint64_t *nbytes);  /* size of SCALCE_OUT_QUAL, nothing put together */
+int scalce_batch_qual_window(scalce_batch *b, int mate, uint64_t offset, uint64_t nbytes, void *dst, void *stream);
 uint64_t scalce_batch_reads(const scalce_batch *b);
 int scalce_batch_params(const scalce_batch *b, scalce_params *out);  /* the parameters it was created with */
 /* measurement hook for bench.py: accumulated device time (ms, hipEvent) and launch count of

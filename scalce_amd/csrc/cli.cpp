@@ -274,6 +274,23 @@ struct Downloader {
     SCOK(ctx, scalce_batch_output(b, which, mate, &d, &n));
     range_to_file(static_cast<const uint8_t *>(d), n, f);
   }
+  // the coded quality stream: framed on its way into the pinned slices (scalce_batch_qual_window), no copy in HBM
+  void qual_to_file(scalce_ctx *ctx, scalce_batch *b, int mate, OutFile &f) {
+    uint64_t total = 0;
+    SCOK(ctx, scalce_batch_qual_bytes(b, mate, &total));
+    const uint64_t nslices = (total + SLICE - 1) / SLICE;
+    auto start = [&](uint64_t i) {
+      const uint64_t off = i * SLICE, k = std::min<uint64_t>(SLICE, total - off);
+      SCOK(ctx, scalce_batch_qual_window(b, mate, off, k, pin[i & 1], s));
+      HIPOK(hipEventRecord(ev[i & 1], s));
+    };
+    if (nslices) start(0);
+    for (uint64_t i = 0; i < nslices; i++) {
+      HIPOK(hipEventSynchronize(ev[i & 1]));
+      if (i + 1 < nslices) start(i + 1);
+      f.write(pin[i & 1], (size_t)std::min<uint64_t>(SLICE, total - i * SLICE));
+    }
+  }
   void range_to_file(const uint8_t *src, uint64_t n, OutFile &f) {
     const uint64_t nslices = (n + SLICE - 1) / SLICE;
     auto start = [&](uint64_t i) {
@@ -529,6 +546,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   // (a run of up to 2048 blocks is one launch that takes as long as ONE block's serial chain, about 0.3 s)
   hipStream_t s_ent = nullptr;
   HIPOK(hipStreamCreateWithFlags(&s_ent, hipStreamNonBlocking));
+  SCOK(ctx, scalce_batch_set_frame_on_demand(b, 1));  // the coded blocks are framed on their way into the pinned slices
   SCOK(ctx, scalce_batch_entropy_begin(b, nullptr, s_ent));
 
   // final writer: headers of combine_and_compress_with_split (compress.cpp:263-343)
@@ -565,7 +583,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
       const uint64_t total = N * (uint64_t)p.read_len[m];
       fQ.write(&total, 8);
     }
-    down.to_file(ctx, b, SCALCE_OUT_QUAL, m, fQ);
+    down.qual_to_file(ctx, b, m, fQ);
     fQ.close();
     for (const char *ext : {"r", "q", "n"}) {
       snprintf(fn, sizeof fn, "%s_%d.scalce%s", o.out.c_str(), m + 1, ext);

@@ -1111,6 +1111,48 @@ __global__ __launch_bounds__(256) void ac_frame_k(const u8 *blocks, u64 stride, 
   }
 }
 
+// The same framing for a WINDOW [lo, hi) of the framed stream, written to out[0 .. hi - lo): what a caller takes out slice by
+// slice without the stream ever existing as a whole on the device (scalce_batch_qual_window; `out` may be pinned host
+// memory, the stores then go over the link in runs of 16 bytes per thread).  Block b's frame is the virtual byte string
+// V_b = [size, 4 bytes LE][its sz coded bytes] at stream offset dst_off[b]; the part of it inside the window goes out.
+// `out` is 4-byte aligned; output words are produced aligned to `out`.
+__global__ __launch_bounds__(256) void ac_frame_window_k(const u8 *blocks, u64 stride, const u32 *sizes, const u64 *dst_off,
+                                                        u64 lo, u64 hi, u8 *out, u32 first_block) {
+  const u32 b = first_block + blockIdx.y;                  // (the host knows which blocks the window touches)
+  const u32 sz = sizes[b];
+  const u64 f0 = dst_off[b], f1 = f0 + 4ull + sz;          // the frame's place in the stream
+  const u64 a = f0 > lo ? f0 : lo, e = f1 < hi ? f1 : hi;  // its part inside the window
+  if (a >= e) return;
+  const u8 *sb = blocks + (u64)b * stride;                 // 16-byte aligned (stride is a multiple of 16)
+  const u32 *src = reinterpret_cast<const u32 *>(sb);
+  auto vbyte = [&](u64 p) -> u8 {                          // byte of the stream at offset p, f0 <= p < f1
+    const u64 r = p - f0;
+    return r < 4 ? (u8)(sz >> (8 * r)) : sb[r - 4];
+  };
+  // words: stream offsets p with (p - lo) % 4 == 0, wholly inside [max(a, f0 + 4), e)
+  const u64 d0 = a > f0 + 4 ? a : f0 + 4;                  // first data byte inside the window
+  u64 w_lo = lo + (((d0 - lo) + 3) & ~3ull);               // first aligned position at or behind it
+  if (w_lo > e) w_lo = e;
+  const u64 nwords = (e - w_lo) >> 2;
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0)
+    for (u64 p = a; p < w_lo; p++) out[p - lo] = vbyte(p);
+  if (t == 1)
+    for (u64 p = w_lo + 4 * nwords; p < e; p++) out[p - lo] = vbyte(p);
+  const u64 s0 = w_lo - f0 - 4;                            // source byte of the first word (>= 0 whenever nwords > 0)
+  const u32 sh = (u32)(s0 & 3) * 8;
+  u32 *dw = reinterpret_cast<u32 *>(out + (w_lo - lo));
+  for (u64 w0 = t * 4; w0 < nwords; w0 += (u64)gridDim.x * blockDim.x * 4) {
+    const u64 j = (s0 >> 2) + w0;
+    u32 sv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) sv[k] = src[j + k];        // the block buffer is padded beyond its 10 MiB
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (w0 + k < nwords) dw[w0 + k] = sh ? ((sv[k] >> sh) | (sv[k + 1] << (32 - sh))) : sv[k];
+  }
+}
+
 // follows the [u32 size][bytes] chain of a framed stream: out[2i] = byte offset of block i's data, out[2i+1] = its size;
 // out[2 nblk] != 0 when the stream ends before `nblk` frames do
 __global__ void ac_frame_walk_k(const u8 *in, u64 nbytes, u32 nblk, u64 *out) {

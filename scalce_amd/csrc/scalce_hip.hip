@@ -4,6 +4,7 @@
 // There is NO CPU fallback: every stage runs on the device or returns an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -350,6 +351,13 @@ struct scalce_batch {
   bool prof_lanes = false;
   u32 ent_pending[2] = {0, 0};
   u32 frame_deferred[2] = {0, 0};  // blocks coded by a grouped launch and not framed yet (entropy_collect frames them)
+  // Framing on demand (scalce_batch_set_frame_on_demand): the coded blocks stay where the coder wrote them; entropy_collect
+  // only lays the frames out (ac_off: where block k's [u32 size][bytes] begins in the stream).  The stream itself is
+  // produced on its way out -- scalce_batch_qual_window, into device or pinned host memory -- or, for callers that ask for
+  // SCALCE_OUT_QUAL as a device pointer, once, at that moment.
+  bool frame_on_demand = false;
+  u32 frame_virtual[2] = {0, 0};   // blocks whose frames are laid out but not copied (0: out_qual holds the stream)
+  std::vector<u64> frame_off_host[2];  // where block k's frame begins (host copy, taken when the stage is collected)
   // symbol stream to code per mate: the shard's own reordered stream, or one the caller assembled (sharded runs)
   const u8 *ent_sym[2] = {nullptr, nullptr};
   u64 ent_nsym[2] = {0, 0};
@@ -1901,9 +1909,15 @@ static bool frames_at_collect() {
 static int ac_frame(AcJob &j, hipStream_t s) {
   scalce_batch *b = j.b;
   const int m = j.m;
+  b->frame_virtual[m] = 0;
   if (!j.nblk) return SCALCE_OK;
   exclusive_scan<u64>(AcFrameLen{b->ac_sizes[m].as<u32>()}, j.nblk, StoreTo<u64>{b->ac_off[m].as<u64>()}, b->ac_scan.as<u64>(),
                       b->d_small64 + 8 + m, s);
+  if (b->frame_on_demand) {  // the layout is all there is for now
+    b->frame_virtual[m] = j.nblk;
+    b->ent_pending[m] = j.nblk;
+    return SCALCE_OK;
+  }
   if (b->out_qual[m].cap < (size_t)j.nblk * (AC_STRIDE + 4) + 64) {
     // the framed stream was not sized for the worst case (a grouped launch: twelve and more shards in flight, and 5 GB each
     // of a capacity that is little more than half used is a shard less in flight): the size comes back first -- the coder has
@@ -1965,6 +1979,10 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
     }
     if (!b->ent_pending[m]) continue;
     u64 total = 0;
+    if (b->frame_virtual[m]) {  // (one wait for both: the layout and the total)
+      b->frame_off_host[m].resize(b->frame_virtual[m]);
+      HIP_TRY(b->ctx, hipMemcpyAsync(b->frame_off_host[m].data(), b->ac_off[m].p, sizeof(u64) * b->frame_virtual[m], hipMemcpyDeviceToHost, s));
+    }
     { int rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s); if (rc) return rc; }
     b->out_qual_bytes[m] = total;
     b->k_out_bytes += total - 4ull * b->ent_pending[m];
@@ -2245,9 +2263,66 @@ extern "C" int scalce_batch_params(const scalce_batch *b, scalce_params *out) {
   return SCALCE_OK;
 }
 
+extern "C" int scalce_batch_set_frame_on_demand(scalce_batch *b, int on) {
+  if (!b) return SCALCE_ERR_ARG;
+  b->frame_on_demand = on != 0;
+  return SCALCE_OK;
+}
+
+extern "C" int scalce_batch_qual_bytes(const scalce_batch *b, int mate, uint64_t *nbytes) {
+  if (!b || !nbytes || mate < 0 || mate >= b->nm) return SCALCE_ERR_ARG;
+  *nbytes = b->out_qual_bytes[mate];
+  return SCALCE_OK;
+}
+
+// bytes [offset, offset + nbytes) of mate's framed quality stream -> dst (device memory, or pinned host memory: the
+// kernel's stores go over the link), straight from the coder's block buffers when the frames are only laid out
+extern "C" int scalce_batch_qual_window(scalce_batch *b, int mate, uint64_t offset, uint64_t nbytes, void *dst, void *stream) {
+  if (!b || mate < 0 || mate >= b->nm || (nbytes && !dst)) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (b->ent_pending[mate] || b->frame_deferred[mate]) { set_err(c, "collect the entropy stage first (scalce_batch_finish)"); return SCALCE_ERR_ARG; }
+  if (offset > b->out_qual_bytes[mate] || nbytes > b->out_qual_bytes[mate] - offset) { set_err(c, "window beyond the stream"); return SCALCE_ERR_ARG; }
+  if (!nbytes) return SCALCE_OK;
+  if (b->p.no_ac || !b->frame_virtual[mate]) {  // the stream exists as such
+    const u8 *src = b->p.no_ac ? b->qs[mate].as<u8>() : b->out_qual[mate].as<u8>();
+    HIP_TRY(c, hipMemcpyAsync(dst, src + offset, nbytes, hipMemcpyDefault, s));
+    return SCALCE_OK;
+  }
+  if ((uintptr_t)dst & 3) { set_err(c, "window destination must be 4-byte aligned"); return SCALCE_ERR_ARG; }
+  // the blocks whose frames meet the window
+  const std::vector<u64> &off = b->frame_off_host[mate];
+  const u32 nblk = b->frame_virtual[mate];
+  if (off.size() != (size_t)nblk) { set_err(c, "internal: frame layout not collected"); return SCALCE_ERR_ARG; }
+  const u32 b0 = (u32)(std::upper_bound(off.begin(), off.end(), (u64)offset) - off.begin()) - 1u;  // off[0] = 0 <= offset
+  const u32 b1 = (u32)(std::lower_bound(off.begin(), off.end(), (u64)(offset + nbytes)) - off.begin());
+  LAUNCH(ac_frame_window_k, dim3(cdiv(AC_STRIDE, 16 * 256), b1 - b0), 256, 0, s, b->ac_blocks[mate].as<u8>(), AC_STRIDE,
+         b->ac_sizes[mate].as<u32>(), b->ac_off[mate].as<u64>(), (u64)offset, (u64)(offset + nbytes), static_cast<u8 *>(dst), b0);
+  return launch_failed(c);
+}
+
+// SCALCE_OUT_QUAL as one device buffer for callers that want that: the frames laid out by entropy_collect are copied now
+static int materialize_frames(scalce_batch *b, int m) {
+  if (!b->frame_virtual[m]) return SCALCE_OK;
+  scalce_ctx *c = b->ctx;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
+  ENSURE(b, b->out_qual[m], (size_t)b->out_qual_bytes[m] + 64);
+  LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), b->frame_virtual[m]), 256, 0, (hipStream_t) nullptr, b->ac_blocks[m].as<u8>(), AC_STRIDE,
+         b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
+  HIP_TRY(c, hipDeviceSynchronize());
+  b->frame_virtual[m] = 0;
+  return launch_failed(c);
+}
+
 extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, const void **d_ptr, uint64_t *nbytes) {
   if (!b || !d_ptr || !nbytes || mate < 0 || mate >= b->nm) return SCALCE_ERR_ARG;
   const u32 nb1 = (u32)b->ctx->A.n_buckets + 1;
+  if (which == SCALCE_OUT_QUAL && !b->p.no_ac && b->frame_virtual[mate]) {
+    int rc = materialize_frames(const_cast<scalce_batch *>(b), mate);
+    if (rc) return rc;
+  }
   switch (which) {
     case SCALCE_OUT_READS: *d_ptr = b->out_reads[mate].p; *nbytes = b->out_reads_bytes[mate]; break;
     case SCALCE_OUT_NAMES: *d_ptr = b->out_names.p; *nbytes = b->out_names_bytes; break;

@@ -105,6 +105,9 @@ def lib():
     L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
     L.scalce_batch_finish.argtypes = [vp, vp]
     L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.scalce_batch_set_frame_on_demand.argtypes = [vp, i32]
+    L.scalce_batch_qual_bytes.argtypes = [vp, i32, C.POINTER(u64)]
+    L.scalce_batch_qual_window.argtypes = [vp, i32, u64, u64, vp, vp]
     L.scalce_batch_reads.argtypes = [vp]
     L.scalce_batch_reads.restype = u64
     L.scalce_batch_stage_ms.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(i32)]
@@ -499,6 +502,19 @@ class Batch:
     def output(self, which, mate=0, dtype=np.uint8):
         p, n = self.output_ptr(which, mate)
         return self.ctx.to_host(p, n, dtype)
+
+    def set_frame_on_demand(self, on=True):
+        """The coded blocks are framed on their way out (qual_window) instead of by a copy pass behind the coder."""
+        self._check(self.L.scalce_batch_set_frame_on_demand(self.h, int(on)))
+
+    def qual_bytes(self, mate=0):
+        n = C.c_uint64()
+        self._check(self.L.scalce_batch_qual_bytes(self.h, mate, C.byref(n)))
+        return n.value
+
+    def qual_window(self, mate, offset, nbytes, dst, stream=0):
+        """bytes [offset, offset + nbytes) of SCALCE_OUT_QUAL into dst (device or pinned host pointer, 4-byte aligned)"""
+        self._check(self.L.scalce_batch_qual_window(self.h, mate, int(offset), int(nbytes), dst, stream))
 
     def stats(self):
         a = (C.c_uint32 * 6)()

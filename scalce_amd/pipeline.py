@@ -6,13 +6,14 @@ of one wavefront per 10 MiB block (or per four / eight blocks) that leaves the m
 the front stages (ingest .. emit, and in a sharded run their collectives) of the NEXT shards run beside it on another
 stream.  What the measurements on MI355X fixed:
 
-* exactly two streams, `front` and `coder`: HIP maps streams onto a handful of hardware queues, and any read-back that
-  lands in a queue behind a 0.4 s coder kernel waits for all of it;
+* one `front` stream and `coder_streams` coder streams (bench.py: three, and GPU_MAX_HW_QUEUES=8 so that no two of them
+  share a hardware queue): HIP maps streams onto a handful of hardware queues, and any read-back that lands in a queue
+  behind a 0.6 s coder kernel waits for all of it;
 * shards are retired on an EVENT recorded behind their coder launch and read back over the front stream;
-* one coder launch at a time (two side by side do not add throughput: where the dispatcher puts two chain waves on
-  one SIMD the younger one starves), but a launch takes `group` shards (scalce_batch_entropy_begin_group: several
-  blocks per chain wave, one workgroup per CU);
-* `slots >= 2 * group` batches, so that the front stages of one group run while the previous group is coded.
+* a launch takes `group` shards (scalce_batch_entropy_begin_group).  The one-block-per-lane coder holds ~10 CUs per shard
+  for ~0.6 s whatever the launch holds, so consecutive launches rotate over the coder streams and run side by side
+  (rounds 1-2, a wavefront per 1-8 blocks: one launch at a time on one stream);
+* `slots >= 2 * group` batches, so that the front stages of one group run while the previous groups are coded.
 
 Usage:
     pipe = ShardPipeline(batches, group=3)

@@ -64,23 +64,61 @@ def record_digest(text):
     return count, s1, s2
 
 
-def decode_shard(ctx, batch, read_len, phred, device):
-    """The finished single-end Batch's archive streams back to FASTQ text on the device (uint8 tensor)."""
+def decode_shard(ctx, batch, read_len, phred, device, timings=None):
+    """The finished single-end Batch's archive streams back to FASTQ text on the device (uint8 tensor).
+    timings (a dict, optional) receives the wall seconds of the two device stages: 'ac_decode' (scalce_ac_decode: the coded
+    stream, resident in HBM, back to q' symbols) and 'records' (scalce_fastq_records: records + names + symbols -> text;
+    the read and name streams go in as host buffers, as a decompressor that has just read the files holds them)."""
     import ctypes as C
+    import time
 
     import torch
     n = batch.n_reads
     nsym = n * read_len
     sym = torch.empty(nsym + 64, dtype=torch.uint8, device=device)
     p, nbytes = batch.output_ptr(host.OUT_QUAL, 0)
-    ctx.ac_decode(batch.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nsym, sym.data_ptr())
+    table = batch.output(host.OUT_TABLE, 0, np.uint32)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.ac_decode(table, p, nbytes, nsym, sym.data_ptr())
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
     reads = batch.output(host.OUT_READS, 0)
     names = batch.output(host.OUT_NAMES, 0)
     L = ctx.L
     cap = L.scalce_fastq_text_bytes(read_len, n, len(names), None)
     out = torch.empty(cap + 64, dtype=torch.uint8, device=device)
     nb = C.c_uint64(0)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
     ctx._check(L.scalce_fastq_records(ctx.h, read_len, 1, reads.ctypes.data, len(reads), n, sym.data_ptr(), int(phred),
                                       names.ctypes.data, len(names), b"", 0, out.data_ptr(), cap, C.byref(nb), None, 0))
     torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    if timings is not None:
+        timings.update(ac_decode=t1 - t0, records=t3 - t2, coded_bytes=int(nbytes), symbols=int(nsym), text_bytes=int(nb.value))
     return out[: nb.value]
+
+
+def archive_hashes(batch, read_len, phred, n_reads):
+    """SHA-256 of the three files a single-end Batch's streams make with the headers of compress.cpp:263-343 in front
+    (scalce_amd/format.py): what `sha256sum PREFIX_1.scalce{n,r,q}` would print for this shard."""
+    import hashlib
+    import struct
+
+    from . import format as fmt
+    p = batch.params
+    out = {}
+    h = hashlib.sha256(fmt.MAGIC + struct.pack("<ii", p.no_ac, read_len))
+    h.update(batch.output(host.OUT_READS, 0).tobytes())
+    out["1.scalcer"] = h.hexdigest()
+    h = hashlib.sha256(fmt.MAGIC + struct.pack("<q", phred))
+    if not p.no_ac:
+        h.update(batch.output(host.OUT_TABLE, 0).tobytes())
+        h.update(struct.pack("<Q", n_reads * read_len))
+    h.update(batch.output(host.OUT_QUAL, 0).tobytes())
+    out["1.scalceq"] = h.hexdigest()
+    h = hashlib.sha256(fmt.MAGIC + struct.pack("<B", 1 if p.use_names else 0))
+    h.update(batch.output(host.OUT_NAMES, 0).tobytes())
+    out["1.scalcen"] = h.hexdigest()
+    return out

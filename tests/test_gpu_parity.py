@@ -580,6 +580,70 @@ def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grouped", [False, True])
+def test_frames_on_the_way_out(grouped, ctx):
+    """scalce_batch_set_frame_on_demand: the coder's blocks are framed by the kernel that delivers them
+    (scalce_batch_qual_window) -- any window of the stream, into device memory and into pinned host memory, is the same
+    bytes as the stream framed behind the coder ([u32 size][bytes] per 10 MiB block, arithmetic.cpp:318-363); windows that
+    start and end inside size words, inside blocks, on block edges; a caller that asks for SCALCE_OUT_QUAL gets the whole
+    stream put together at that moment."""
+    import torch
+    from gpu_util import device_bytes
+    n, L = 330_000, 100                                   # four blocks, the last one short
+    bases, quals = synth.reads_and_quals(n, L, seed=77)
+    fq = synth.fastq_bytes_fast(bases, quals)
+    t = device_bytes(fq)
+
+    def run(on_demand):
+        b = host.Batch(ctx, L, n + 8, len(fq) + 64)
+        if on_demand:
+            b.set_frame_on_demand(True)
+        if grouped:
+            b.front(t.data_ptr(), len(fq))
+            host.entropy_begin_group([b])
+        else:
+            b.compress(t.data_ptr(), len(fq))
+        b.finish()
+        return b
+    want = run(False).output(host.OUT_QUAL, 0).copy()
+    b = run(True)
+    total = b.qual_bytes(0)
+    assert total == len(want)
+    sizes, pos = [], 0
+    while pos < total:                                    # the frames, from the expected stream
+        sz = int.from_bytes(want[pos:pos + 4].tobytes(), "little")
+        sizes.append((pos, sz))
+        pos += 4 + sz
+    assert len(sizes) == 4
+    rng = np.random.default_rng(3)
+    wins = [(0, total), (0, 1), (1, 2), (3, 9), (total - 5, 5), (total - 1, 1), (0, 0)]
+    for off, sz in sizes:                                 # around every frame edge
+        for a in (off - 7, off - 1, off, off + 1, off + 3, off + 4, off + 5):
+            for k in (1, 2, 3, 4, 5, 8, 13, 4096 + 3):
+                if a >= 0 and a + k <= total:
+                    wins.append((a, k))
+    for _ in range(40):
+        a = int(rng.integers(0, total))
+        wins.append((a, int(rng.integers(0, min(total - a, 3 << 20) + 1))))
+    dev = torch.empty(total + 64, dtype=torch.uint8, device="cuda:0")
+    pin = torch.empty(total + 64, dtype=torch.uint8).pin_memory()
+    for a, k in wins:
+        for buf in (dev, pin):
+            buf.fill_(0xEE)
+            torch.cuda.synchronize()
+            b.qual_window(0, a, k, buf.data_ptr())
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy() if buf is dev else buf.numpy()
+            assert (got[:k] == want[a:a + k]).all(), (a, k, "device" if buf is dev else "pinned")
+            assert (got[k:k + 32] == 0xEE).all(), (a, k, "wrote past the window")
+    got = b.output(host.OUT_QUAL, 0)                      # put together on request
+    assert len(got) == len(want) and (got == want).all()
+    b.qual_window(0, 5, 100, dev.data_ptr())              # ... and windows of the stream that now exists
+    torch.cuda.synchronize()
+    assert (dev[:100].cpu().numpy() == want[5:105]).all()
+
+
+@pytest.mark.gpu
 def test_rows_coder_repeated_launches(ctx, oracle_trie, monkeypatch):
     """The same two-block shard through the four- and eight-blocks-per-wave coder a dozen times, every result against
     the oracle's bytes.  (The hand-over of the first operand slot between helper and chain waves once raced: a block
