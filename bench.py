@@ -131,6 +131,7 @@ def main():
     # shards per launch, six in flight, one coder stream, eight blocks per chain wave: with one stream a launch of the
     # one-block-per-lane coder (0.6 s whatever it holds) would be all there is to a step.
     G = args.group
+    auto_group = G is None
     if G is None:
         G = 3 if sharded else 4
     G = max(1, G)
@@ -143,10 +144,15 @@ def main():
     if args.inflight is None:
         free_b, _ = torch.cuda.mem_get_info()
         scale = (n * L) / 5e9
-        per_slot = (12.3e9 if not sharded else 36e9) * scale + (nbytes if own_text else 0)
+        # (the batch's own: reordered q' 5 GB, coder blocks 3.5 GB sized from the table, records 1.25, names 0.54, tables)
+        per_slot = (10.7e9 if not sharded else 36e9) * scale + (nbytes if own_text else 0)
         fit = int((free_b + (nbytes if own_text else 0) - 22e9 * scale - 5e9) // per_slot)
         if fit < D:
-            print("bench: %.0f GB of HBM free: %d shards in flight instead of %d" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D), file=sys.stderr)
+            if auto_group and not sharded and fit < 14:
+                # fewer than fourteen fit: three shards per launch on three coder streams keep nine of them in the coder and the
+                # rest in front of it (tools/pipe_shapes_r4.sh: 91 ms per shard at 3 / 11 / 3 against 103 at 4 / 11 / 2)
+                G = 3
+            print("bench: %.0f GB of HBM free: %d shards in flight instead of %d, %d per coder launch" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D, G), file=sys.stderr)
             D = fit
     if G > 1:
         D = max(D, 2 * G)

@@ -43,13 +43,23 @@ __device__ __forceinline__ u64 recip_frac(u32 c, u32 d) {
 // `tab8` (may be null): the same fractions as one u64 per cumulative bound, [6400][81] -- g(c_hi) of a symbol is g(c_lo) of
 // the next, so the 16 bytes at &tab8[ctx * 81 + s] ARE symbol s's operands and the table is half the size (4.1 MB): the
 // one-block-per-lane coder gathers from it (kernels_acl.hpp; an XCD's 4 MB L2 holds the rows in use of one table, not of two).
-__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/, u32 *max_total, u64 *tab8 = nullptr) {
+// cost[0] += sum over the context's symbols of f * log2(tot / f) in 1/256 bit, cost[1] += tot: what coding the table's own
+// counts with the table costs -- the host sizes the coder's block buffers from it (ac_prepare)
+__global__ __launch_bounds__(64) void ac_table_k(const u32 *table, uint4 *tab, u32 *cum /*[6400][81]*/, u32 *max_total, u64 *tab8 = nullptr,
+                                                unsigned long long *cost = nullptr) {
   const u32 ctx = blockIdx.x * blockDim.x + threadIdx.x;
   if (ctx >= AC_D * AC_D) return;
   const u32 *f = table + (u64)ctx * AC_D;
   u32 tot = 0;
   for (int s = 0; s < AC_D; s++) tot += f[s];
   if (max_total) atomicMax(max_total, tot);
+  if (cost) {
+    const float lt = __log2f((float)tot);
+    float bits = 0.f;
+    for (int s = 0; s < AC_D; s++) bits += (float)f[s] * (lt - __log2f((float)f[s]));
+    atomicAdd(&cost[0], (unsigned long long)(bits * 256.f));
+    atomicAdd(&cost[1], (unsigned long long)tot);
+  }
   u32 run = 0;
   u64 glo = 1;  // c == 0 -> quotient 0
   cum[ctx * 81] = 0;
@@ -73,6 +83,8 @@ struct AcBlockDesc {
   DevErr *err;          // error word of the shard it belongs to
   u32 n;                // symbols in the block
   u32 index;            // block index inside its stream (error reports)
+  u32 cap;              // bytes the block may write at dst (multiple of 4)
+  u32 pad_;
 };
 struct AcEncArgs {
   const u8 *sym;
@@ -658,8 +670,9 @@ __global__ __launch_bounds__(128) void ac_encode_k(AcEncArgs a) {
       sink.pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
     }
     const u32 bytes = sink.finish(buf, lane, final_lo);
-    if (lane == 0) a.out_size[blk] = bytes;
-    if (__any(sink.over) && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
+    const bool over = __any(sink.over);  // (a block that ran out of room reports size 0: nothing frames bytes it does not hold)
+    if (lane == 0) a.out_size[blk] = over ? 0u : bytes;
+    if (over && lane == 0) dev_fail(a.err, E_ACOVERFLOW, blk, bytes);
   } else {
     // ================= chain wave: nothing but the coder state =================
     __syncthreads();  // operands of rounds 0 and 1 are in LDS
@@ -881,7 +894,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sp[e] = (const SCALCE_GLOBAL u8 *)dsc.sym;
       tabp[e] = (const SCALCE_GLOBAL u32x4 *)dsc.tab;
       sink[e].dst = (SCALCE_GLOBAL u32 *)dsc.dst;
-      sink[e].wcap = a.out_cap / 4;
+      sink[e].wcap = dsc.cap / 4;
       if (nb[e]) sink[e].carry = ((u32)sp[e][0] << 24) | ((nb[e] > 1 ? (u32)sp[e][1] : 0u) << 16);
       e62[e] = e63[e] = 0;
       const uint4 o0 = lookup(e, sym_at(e, lane), 0), o1 = lookup(e, sym_at(e, 64 + lane), 64);
@@ -958,8 +971,9 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       const u32 bytes = sink[e].finish(buf, lane, final_lo[2 * h + e]);
       const AcBlockDesc dsc = a.desc[blk0 + 2 * h + e];
-      if (lane == 0) *dsc.out_size = bytes;
-      if (__any(sink[e].over) && lane == 0) dev_fail(dsc.err, E_ACOVERFLOW, dsc.index, bytes);
+      const bool over = __any(sink[e].over);
+      if (lane == 0) *dsc.out_size = over ? 0u : bytes;
+      if (over && lane == 0) dev_fail(dsc.err, E_ACOVERFLOW, dsc.index, bytes);
     }
   } else {
     // ================= chain wave: NB coder states, one per group of R lanes =================

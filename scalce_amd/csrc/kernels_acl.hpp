@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
     {
       const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
       const u32 s0 = n ? (u32)sp[0] : 0u, s1 = n > 1 ? (u32)sp[1] : 0u;
-      sk.init((SCALCE_GLOBAL u32 *)dp->dst, sh.stage, lane, a.out_cap / 4, s0, s1);
+      sk.init((SCALCE_GLOBAL u32 *)dp->dst, sh.stage, lane, dp->cap / 4, s0, s1);
     }
     sh.pub[0][lane] = 0;
     sh.pub[1][lane] = 0;
@@ -456,13 +456,13 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
     barrier_lds_only();   // ... and they are in memory (its fence): the notes go on top
     if (have && n) {
       const u32 bytes = sk.finish(sh.final_lo[lane]);
-      *(SCALCE_GLOBAL u32 *)dp->out_size = bytes;
+      *(SCALCE_GLOBAL u32 *)dp->out_size = sk.over ? 0u : bytes;  // (a block that ran out of room: nothing frames bytes it does not hold)
       if (sk.over) dev_fail(dp->err, E_ACOVERFLOW, dp->index, bytes);
     }
   } else {
     // ================= writer: final words out of the staging ring =================
     SCALCE_GLOBAL u32 *dst = (SCALCE_GLOBAL u32 *)dp->dst;
-    const u32 wcap = a.out_cap / 4;
+    const u32 wcap = dp->cap / 4;
     u32 wo = 0;  // words of this lane's block in global memory (multiple of 32 until the end)
     auto word = [&](u32 k) -> u32 { return __builtin_bswap32(sh.stage[(k + 1u) & (ACL_RING - 1)][lane]); };
     // Whole 128-byte lines: 32 words per lane in eight 16-byte stores back to back.  (Sixteen bytes per lane and visit left

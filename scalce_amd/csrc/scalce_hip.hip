@@ -355,6 +355,13 @@ struct scalce_batch {
   // only lays the frames out (ac_off: where block k's [u32 size][bytes] begins in the stream).  The stream itself is
   // produced on its way out -- scalce_batch_qual_window, into device or pinned host memory -- or, for callers that ask for
   // SCALCE_OUT_QUAL as a device pointer, once, at that moment.
+  // Bytes per block of the coder's output buffers.  The reference gives every block 10 MiB (arithmetic.cpp:301); sized like that
+  // a 50 M-read shard holds 5 GB of which 2.9 are used.  ac_prepare sizes the stride from what the table says coding its own
+  // counts costs (+ 8 % + 64 KiB); a block that outgrows it reports E_ACOVERFLOW and the shard is coded again at the full
+  // stride when it is collected (entropy_recode_full) -- same bytes, one launch later.
+  u64 ac_stride[2] = {0, 0};
+  const u8 *ac_last_sym[2] = {nullptr, nullptr};  // what the last launch coded (for the recode)
+  u64 ac_last_nsym[2] = {0, 0};
   bool frame_on_demand = false;
   u32 frame_virtual[2] = {0, 0};   // blocks whose frames are laid out but not copied (0: out_qual holds the stream)
   std::vector<u64> frame_off_host[2];  // where block k's frame begins (host copy, taken when the stage is collected)
@@ -1735,29 +1742,44 @@ struct AcJob {
 static const u64 AC_STRIDE = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
 
 // table -> reciprocal fractions, buffers; one short wait for the largest context total
-static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true) {
+static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool full_stride = false) {
   scalce_batch *b = j.b;
   scalce_ctx *c = b->ctx;
   const int m = j.m;
   u32 *table = b->table[m].as<u32>();
   ENSURE(b, b->ac_tab[m], sizeof(uint4) * 512000);
   ENSURE(b, b->ac_cum[m], sizeof(u32) * 6400 * 81);
-  HIP_TRY(c, hipMemsetAsync(b->d_small + 12 + m, 0, sizeof(u32), s));
+  // one read-back for both: the largest context total (d_small64[12 + 4 m], low word) and the table's own coding cost
+  u64 *tinfo = b->d_small64 + 12 + 4 * m;
+  HIP_TRY(c, hipMemsetAsync(tinfo, 0, 3 * sizeof(u64), s));
   ENSURE(b, b->ac_tab8[m], sizeof(u64) * (6400 * 81 + 2));
-  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab[m].as<uint4>(), b->ac_cum[m].as<u32>(), b->d_small + 12 + m, b->ac_tab8[m].as<u64>());
-  u32 max_total = 0;
-  { int rc = read_u32(b, b->d_small + 12 + m, &max_total, 1, s); if (rc) return rc; }
+  LAUNCH(ac_table_k, cdiv(6400, 64), 64, 0, s, table, b->ac_tab[m].as<uint4>(), b->ac_cum[m].as<u32>(), reinterpret_cast<u32 *>(tinfo), b->ac_tab8[m].as<u64>(),
+         reinterpret_cast<unsigned long long *>(tinfo + 1));
+  u64 th[3] = {0, 0, 0};
+  { int rc = read_u64(b, tinfo, th, 3, s); if (rc) return rc; }
+  const u32 max_total = (u32)th[0];
   // above 2^30 a symbol's interval can collapse in the reference's 32-bit coder; only the general step
   // follows it there bit for bit
   j.general = max_total > (1u << 30) || getenv("SCALCE_AC_GENERAL") != nullptr;
   j.max_total = max_total;
   j.nblk = (u32)cdiv(j.nsym, AC_BLOCK_SYMS);
-  ENSURE(b, b->ac_blocks[m], (size_t)j.nblk * AC_STRIDE + 64);
+  {
+    u64 stride = AC_STRIDE;
+    const bool full = getenv("SCALCE_AC_FULL_STRIDE") != nullptr;
+    if (!full && !full_stride && th[2]) {
+      double bytes_per_symbol = (double)th[1] / 256.0 / 8.0 / (double)th[2];
+      if (const char *e = getenv("SCALCE_AC_STRIDE_SCALE")) bytes_per_symbol *= atof(e);  // test hook: too small on purpose
+      const u64 est = (u64)((double)AC_BLOCK_SYMS * bytes_per_symbol * 1.08) + 65536;
+      stride = std::min<u64>(AC_STRIDE, (est + 15) & ~15ull);
+    }
+    b->ac_stride[m] = stride;
+  }
+  ENSURE(b, b->ac_blocks[m], (size_t)j.nblk * b->ac_stride[m] + 4096 + 64);  // (the frame kernels read a few words past a block's bytes)
   ENSURE(b, b->ac_sizes[m], sizeof(u32) * (j.nblk + 2));
   ENSURE(b, b->ac_off[m], sizeof(u64) * (j.nblk + 2));
   // the framed stream is sized for the worst case (every block at its cap): no size has to come back from the
   // device before the frame kernel can be enqueued
-  if (framed_output) ENSURE(b, b->out_qual[m], (size_t)j.nblk * (AC_STRIDE + 4) + 64);
+  if (framed_output && !b->frame_on_demand) ENSURE(b, b->out_qual[m], (size_t)j.nblk * (b->ac_stride[m] + 4) + 64);
   ENSURE(b, b->ac_scan, sizeof(u64) * (scan_ws_elems(j.nblk ? j.nblk : 1) + 64));  // (the batch's own: framing runs at collect time,
   if (!j.nblk) b->out_qual_bytes[m] = 0;                                            //  beside another batch's front stages)
   return SCALCE_OK;
@@ -1824,7 +1846,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     scalce_batch *b = jobs[0].b;
     const int m = jobs[0].m;
     a.sym = jobs[0].sym; a.nsym = jobs[0].nsym; a.tab = b->ac_tab[m].as<uint4>(); a.out = b->ac_blocks[m].as<u8>();
-    a.out_stride = AC_STRIDE; a.out_cap = (u32)AC_STRIDE; a.out_size = b->ac_sizes[m].as<u32>(); a.err = b->d_err;
+    a.out_stride = b->ac_stride[m]; a.out_cap = (u32)b->ac_stride[m]; a.out_size = b->ac_sizes[m].as<u32>(); a.err = b->d_err;
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * total)); }
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
@@ -1862,7 +1884,9 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
         const u64 off = (u64)k * AC_BLOCK_SYMS;
         x.sym = jobs[i].sym + off;
         x.tab = lanes ? reinterpret_cast<const uint4 *>(b->ac_tab8[m].as<u64>()) : b->ac_tab[m].as<uint4>();
-        x.dst = reinterpret_cast<u32 *>(b->ac_blocks[m].as<u8>() + (u64)k * AC_STRIDE);
+        x.dst = reinterpret_cast<u32 *>(b->ac_blocks[m].as<u8>() + (u64)k * b->ac_stride[m]);
+        x.cap = (u32)b->ac_stride[m];
+        x.pad_ = 0;
         x.out_size = b->ac_sizes[m].as<u32>() + k;
         x.err = b->d_err;
         x.n = (u32)std::min<u64>(AC_BLOCK_SYMS, jobs[i].nsym - off);
@@ -1897,7 +1921,11 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
       lead->prof_lanes = blocks_per_wg == 64;
     }
   }
-  for (int i = 0; i < njobs; i++) lead->k_in_bytes += jobs[i].nsym;
+  for (int i = 0; i < njobs; i++) {
+    lead->k_in_bytes += jobs[i].nsym;
+    jobs[i].b->ac_last_sym[jobs[i].m] = jobs[i].sym;
+    jobs[i].b->ac_last_nsym[jobs[i].m] = jobs[i].nsym;
+  }
   return SCALCE_OK;
 }
 
@@ -1918,7 +1946,7 @@ static int ac_frame(AcJob &j, hipStream_t s) {
     b->ent_pending[m] = j.nblk;
     return SCALCE_OK;
   }
-  if (b->out_qual[m].cap < (size_t)j.nblk * (AC_STRIDE + 4) + 64) {
+  if (b->out_qual[m].cap < (size_t)j.nblk * (b->ac_stride[m] + 4) + 64) {
     // the framed stream was not sized for the worst case (a grouped launch: twelve and more shards in flight, and 5 GB each
     // of a capacity that is little more than half used is a shard less in flight): the size comes back first -- the coder has
     // finished, this is a wait of microseconds -- and the buffer grows when a shard codes worse than any before it
@@ -1926,7 +1954,7 @@ static int ac_frame(AcJob &j, hipStream_t s) {
     { int rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s); if (rc) return rc; }
     if (b->out_qual[m].cap < total + 64) ENSURE(b, b->out_qual[m], (size_t)(total + total / 16) + (32u << 20));
   }
-  LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), j.nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), AC_STRIDE,
+  LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), j.nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), b->ac_stride[m],
          b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
   b->ent_pending[m] = j.nblk;
   return SCALCE_OK;
@@ -1949,8 +1977,45 @@ static int encode_stream(scalce_batch *b, int m, const u8 *d_sym, u64 nsym, hipS
   return ac_frame(j, s);
 }
 
+// A block outgrew the stride its shard's table suggested (ac_prepare): the shard's streams are coded again with the
+// reference's own 10 MiB per block, now, on the collecting stream.  Rare by construction; the same bytes one launch later.
+static int entropy_recode_full(scalce_batch *b, hipStream_t s) {
+  std::vector<AcJob> jobs;
+  for (int m = 0; m < b->nm; m++) {
+    if (!b->ac_last_sym[m] || !b->ac_last_nsym[m]) continue;
+    AcJob j{b, m, b->ac_last_sym[m], b->ac_last_nsym[m], 0, false};
+    int rc = ac_prepare(j, s, /*framed_output=*/false, /*full_stride=*/true);
+    if (rc) return rc;
+    jobs.push_back(j);
+  }
+  if (jobs.empty()) return SCALCE_OK;
+  u32 total = 0;
+  for (auto &j : jobs) total += j.nblk;
+  int rc = ac_launch(jobs.data(), (int)jobs.size(), total <= 1024 ? 4 : 8, s, s);
+  if (rc) return rc;
+  for (auto &j : jobs) { b->frame_deferred[j.m] = j.nblk; b->ent_pending[j.m] = 0; }
+  return SCALCE_OK;
+}
+
 // second half of the entropy stage: wait for the coder and read the size of the framed stream(s)
 static int entropy_collect(scalce_batch *b, hipStream_t s) {
+  {
+    bool open = false, tight = false;
+    for (int m = 0; m < b->nm; m++) {
+      open |= b->frame_deferred[m] != 0 || b->ent_pending[m] != 0;
+      tight |= b->ac_stride[m] != 0 && b->ac_stride[m] < AC_STRIDE;
+    }
+    if (open && tight) {
+      DevErr e;
+      HIP_TRY(b->ctx, hipMemcpyAsync(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost, s));
+      HIP_TRY(b->ctx, hipStreamSynchronize(s));
+      if (e.code == E_ACOVERFLOW) {
+        HIP_TRY(b->ctx, hipMemsetAsync(b->d_err, 0, sizeof(DevErr), s));
+        int rc = entropy_recode_full(b, s);
+        if (rc) return rc;
+      }
+    }
+  }
   if (b->prof_ptr) {  // profiling only: share of the chain waves' time spent waiting at the barrier
     std::vector<u64> h(5 * (size_t)b->prof_n);
     HIP_TRY(b->ctx, hipMemcpy(h.data(), b->prof_ptr, sizeof(u64) * h.size(), hipMemcpyDeviceToHost));
@@ -2033,7 +2098,7 @@ static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, h
       const u64 off = (u64)w0 * AC_BLOCK_SYMS;
       const u64 n = std::min<u64>(nsym[m] - off, (u64)W * AC_BLOCK_SYMS);
       jobs[nj] = AcJob{b, m, b->qs[m].as<u8>() + off, n, 0, false};
-      int rc = ac_prepare(jobs[nj], s, /*framed_output=*/false);
+      int rc = ac_prepare(jobs[nj], s, /*framed_output=*/false, /*full_stride=*/true);  // (windows are collected as they go: no second try)
       if (rc) return rc;
       nj++;
     }
@@ -2051,7 +2116,7 @@ static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, h
         ENSURE(b, b->out_qual[m], est);
       }
       if ((rc = ensure_keep(b, b->out_qual[m], used[m] + total + 64, used[m], s))) return rc;
-      LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), jobs[i].nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), AC_STRIDE,
+      LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), jobs[i].nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), b->ac_stride[m],
              b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>() + used[m]);
       used[m] += total;
       b->k_out_bytes += total - 4ull * jobs[i].nblk;
@@ -2297,7 +2362,7 @@ extern "C" int scalce_batch_qual_window(scalce_batch *b, int mate, uint64_t offs
   if (off.size() != (size_t)nblk) { set_err(c, "internal: frame layout not collected"); return SCALCE_ERR_ARG; }
   const u32 b0 = (u32)(std::upper_bound(off.begin(), off.end(), (u64)offset) - off.begin()) - 1u;  // off[0] = 0 <= offset
   const u32 b1 = (u32)(std::lower_bound(off.begin(), off.end(), (u64)(offset + nbytes)) - off.begin());
-  LAUNCH(ac_frame_window_k, dim3(cdiv(AC_STRIDE, 16 * 256), b1 - b0), 256, 0, s, b->ac_blocks[mate].as<u8>(), AC_STRIDE,
+  LAUNCH(ac_frame_window_k, dim3(cdiv(b->ac_stride[mate], 16 * 256), b1 - b0), 256, 0, s, b->ac_blocks[mate].as<u8>(), b->ac_stride[mate],
          b->ac_sizes[mate].as<u32>(), b->ac_off[mate].as<u64>(), (u64)offset, (u64)(offset + nbytes), static_cast<u8 *>(dst), b0);
   return launch_failed(c);
 }
@@ -2309,7 +2374,7 @@ static int materialize_frames(scalce_batch *b, int m) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
   ENSURE(b, b->out_qual[m], (size_t)b->out_qual_bytes[m] + 64);
-  LAUNCH(ac_frame_k, dim3(cdiv(AC_STRIDE, 16 * 256), b->frame_virtual[m]), 256, 0, (hipStream_t) nullptr, b->ac_blocks[m].as<u8>(), AC_STRIDE,
+  LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), b->frame_virtual[m]), 256, 0, (hipStream_t) nullptr, b->ac_blocks[m].as<u8>(), b->ac_stride[m],
          b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
   HIP_TRY(c, hipDeviceSynchronize());
   b->frame_virtual[m] = 0;

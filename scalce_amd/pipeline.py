@@ -78,11 +78,14 @@ class ShardPipeline:
         self._tag[slot] = tag
         if self.G == 1:
             b = self.batches[slot]
+            coder = self.coder
             if not self.sharded:  # a sharded caller has already enqueued the coder on self.coder (ent_stream)
-                self.coder.wait_stream(self.front)
-                b.entropy_begin(None, self.coder.cuda_stream)
+                coder = self.coders[self._launches % len(self.coders)]
+                self._launches += 1
+                coder.wait_stream(self.front)
+                b.entropy_begin(None, coder.cuda_stream)
             ev = self.torch.cuda.Event()
-            ev.record(self.coder)
+            ev.record(coder)
             self._busy[slot] = ev
             return
         self._pending.append(slot)

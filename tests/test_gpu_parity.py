@@ -580,6 +580,39 @@ def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["1", "4", "8", "64", "grouped"])
+def test_coder_block_that_outgrows_its_buffer_is_coded_again(variant, ctx, monkeypatch):
+    """The coder's block buffers are sized from what the table says (ac_prepare), not at the reference's 10 MiB per block
+    (arithmetic.cpp:301).  With the estimate forced far too small every block overflows, the shard reports it, and the
+    collect step codes it again at the full stride: the same bytes as a run that had the room from the start."""
+    from gpu_util import device_bytes
+    n, L = 230_000, 100                                   # three blocks
+    bases, quals = synth.reads_and_quals(n, L, seed=78)
+    fq = synth.fastq_bytes_fast(bases, quals)
+    t = device_bytes(fq)
+    if variant != "grouped":
+        monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", variant)
+
+    def run():
+        b = host.Batch(ctx, L, n + 8, len(fq) + 64)
+        if variant == "grouped":
+            b.front(t.data_ptr(), len(fq))
+            host.entropy_begin_group([b])
+        else:
+            b.compress(t.data_ptr(), len(fq))
+        b.finish()
+        return b.output(host.OUT_QUAL, 0).copy()
+    want = run()
+    monkeypatch.setenv("SCALCE_AC_STRIDE_SCALE", "0.5")
+    got = run()
+    assert len(got) == len(want) and (got == want).all()
+    monkeypatch.setenv("SCALCE_AC_STRIDE_SCALE", "1.0")
+    monkeypatch.setenv("SCALCE_AC_FULL_STRIDE", "1")
+    got = run()
+    assert len(got) == len(want) and (got == want).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("grouped", [False, True])
 def test_frames_on_the_way_out(grouped, ctx):
     """scalce_batch_set_frame_on_demand: the coder's blocks are framed by the kernel that delivers them
