@@ -205,7 +205,10 @@ def main():
     # the scheduling loop (scalce_amd/pipeline.py): front stages of the next shards on one stream beside the coder of the
     # previous ones on another, `G` shards per coder launch, shards retired on events
     DF = D // F
-    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", "3" if (G > 1 and DF >= 3 * G) else "2" if (G > 1 and DF >= 2 * G + 2 and not sharded) else "1"))
+    # as many coder streams as groups fit the slots (every launch takes ~0.6 s whatever it holds: with a stream per group in
+    # rotation no group waits for another's launch to end; 3 / 4 / 12 measured 88.1 ms per shard against 90.0 at 3 / 3 / 12)
+    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(6, DF // G)) if (G > 1 and DF >= 3 * G and not sharded) else
+                                         "3" if (G > 1 and DF >= 3 * G) else "2" if (G > 1 and DF >= 2 * G + 2 and not sharded) else "1"))
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
                            coder_streams=n_coder_streams)
              for f in range(F)]

@@ -207,8 +207,10 @@ int scalce_batch_entropy_end(scalce_batch *b, void *stream);
  * enqueued on stream.  Each shard is completed by its own scalce_batch_entropy_end / scalce_batch_finish (on any
  * stream, after `stream` has reached the end of the launch). */
 int scalce_batch_entropy_begin_group(scalce_batch **batches, int n, void *prep_stream, void *stream);
-/* The same for the LAST launch of a run (last != 0: nothing will be queued behind it): picks the coder kernel by how soon
- * the launch is done instead of by how few CUs it holds beside the next shards' front stages.  Same bytes. */
+/* The same for the LAST launch of a run (last == 1: nothing will be queued behind it): picks the coder kernel by how soon
+ * the launch is done instead of by how few CUs it holds beside the next shards' front stages.  last == 2: a launch of one
+ * or two shards at the START of a run, with more shards on their way: the kernel that holds the fewest CUs whatever the
+ * size of the launch.  Same bytes. */
 int scalce_batch_entropy_begin_group_last(scalce_batch **batches, int n, void *prep_stream, void *stream, int last);
 /* Sharded runs: code a caller-assembled range of the run-wide reordered stream (it must start on a 10 MiB
  * block boundary) against the run-wide table; result in SCALCE_OUT_QUAL of `mate`. */

@@ -102,13 +102,13 @@ struct AclSink {
   u32 wcap;      // words the block may write
   u32 w2, w1, w0;
   u32 Qb;        // stream position of the next B's top bit
-  u32 ncar;      // carries out of w2 counted by step() in this round
+  u32 ncar;      // smallest w2 seen right after a step of this round added its carry: 0 = a carry may have left w2 (step())
   u32 nlog;      // notes in the log
   bool over;
   __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 (*r)[64], int l, u32 cap_words, u32 s0, u32 s1) {
     dst = d; ring = r; lane = l; wcap = cap_words;
     w2 = 0; w1 = (s0 << 24) | (s1 << 16); w0 = 0;  // the two raw symbols (arithmetic.cpp:110-120): 16 bits of X
-    Qb = 16; ncar = 0; nlog = 0; over = false;      // (w2 = the empty word in front of the block: ring slot 0, never taken out)
+    Qb = 16; ncar = ~0u; nlog = 0; over = false;    // (w2 = the empty word in front of the block: ring slot 0, never taken out)
   }
   __device__ __forceinline__ u32 final_words() const {  // the words in front of w2 are final
     const u32 wq = Qb >> 5;
@@ -124,13 +124,16 @@ struct AclSink {
     const u32 pos = Qb & 31u;
     const u32 b_hi = B >> pos;
     const u32 b_lo = __builtin_amdgcn_alignbit(B, 0u, pos);  // low word of {B, 0} >> pos: B << (32 - pos), 0 for pos = 0
-    u32 c0, c1, c2, c3;
+    u32 c0, c1;
     w0 = __builtin_addc(w0, b_lo, 0u, &c0);
     w1 = __builtin_addc(w1, b_hi, c0, &c1);
-    w2 = __builtin_addc(w2, 0u, c1, &c2);
-    ncar = __builtin_addc(ncar, 0u, c2, &c3);
+    // A carry out of w2 leaves w2 = 0 behind.  Instead of a fourth link in the carry chain (and the wait state in front of
+    // it) the step keeps the smallest w2 it has seen: a round that saw 0 is redone by careful().  (A word that is 0 for
+    // another reason -- the empty word in front of the block, a genuine all-zero word -- only costs that redo.)
+    w2 += c1;
+    ncar = w2 < ncar ? w2 : ncar;
     const u32 wq = Qb >> 5;
-    ring[wq & (ACL_RING - 1)][lane] = w2;  // final if this step completes w1, overwritten otherwise
+    ring[__builtin_amdgcn_ubfe(Qb, 5, 7)][lane] = w2;  // slot wq & (ACL_RING - 1); final if this step completes w1, overwritten otherwise
     const bool f = (Qa >> 5) != wq;
     w2 = f ? w1 : w2;
     w1 = f ? w0 : w1;
@@ -426,11 +429,11 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
 #pragma unroll
         for (int j = 0; j < ACL_STEPS; j++) v[j] = sh.rec[r & 1][j][lane];
         const u32 s2 = sk.w2, s1 = sk.w1, s0 = sk.w0, sq = sk.Qb;
-        sk.ncar = 0;
+        sk.ncar = ~0u;
 #pragma unroll
         for (int j = 0; j < ACL_STEPS; j++) sk.step(v[j].x, v[j].y);
-        if (__builtin_expect(__any(sk.ncar != 0u), 0)) {
-          if (sk.ncar != 0u) {
+        if (__builtin_expect(__any(sk.ncar == 0u), 0)) {
+          if (sk.ncar == 0u) {
             sk.w2 = s2; sk.w1 = s1; sk.w0 = s0; sk.Qb = sq;
 #pragma unroll 1
             for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[r & 1][j][lane].x, sh.rec[r & 1][j][lane].y);

@@ -1868,8 +1868,11 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
       if (lead->ac_desc_host) hipHostFree(lead->ac_desc_host);
       lead->ac_desc_host = nullptr;
       lead->ac_desc_cap = 0;
-      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&lead->ac_desc_host), sizeof(AcBlockDesc) * (size_t)(total + total / 2), hipHostMallocDefault));
-      lead->ac_desc_cap = total + total / 2;
+      // (room for any launch this shard is likely to lead: an allocation synchronises the whole device -- a shard that led a
+      //  launch of one shard and then one of three waited there for every coder that was running)
+      const u32 cap = std::max<u32>(total + total / 2, 8192u);
+      HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&lead->ac_desc_host), sizeof(AcBlockDesc) * (size_t)cap, hipHostMallocDefault));
+      lead->ac_desc_cap = cap;
     }
     // one block per lane only follows the reference while no interval can invert (kernels_acl.hpp)
     if (blocks_per_wg == 64 && general) blocks_per_wg = 8;
@@ -1894,7 +1897,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
         d[nd++] = x;
       }
     }
-    ENSURE(lead, lead->ac_desc, sizeof(AcBlockDesc) * total);
+    ENSURE(lead, lead->ac_desc, sizeof(AcBlockDesc) * (size_t)lead->ac_desc_cap);
     HIP_TRY(c, hipMemcpyAsync(lead->ac_desc.p, d, sizeof(AcBlockDesc) * total, hipMemcpyHostToDevice, ps));
     a.desc = lead->ac_desc.as<AcBlockDesc>();
     a.nblocks = total;
@@ -2212,8 +2215,10 @@ extern "C" int scalce_batch_entropy_begin_group_last(scalce_batch **bs, int n, v
   // one shard (477 blocks at 50 M x 100): four blocks per chain wave, the lowest latency that still leaves every chain wave a
   // SIMD of its own; from two shards on one block per LANE -- the launch then takes ~0.56 s whatever its size, but on a
   // sixth of the SIMD time per block, and the front stages of the next shards keep the chip
-  int bpw = total < 900 ? 4 : 64;
-  if (last && total >= 900 && total <= 2048) bpw = 8;
+  // last == 2: a small launch at the START of a run (more shards are on their way: the CUs belong to their front stages):
+  // one block per lane whatever the size
+  int bpw = (total < 900 && last != 2) ? 4 : 64;
+  if (last == 1 && total >= 900 && total <= 2048) bpw = 8;
   if (ac_blocks_per_wg() != 1) bpw = ac_blocks_per_wg();
 
   int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);

@@ -317,9 +317,10 @@ def shard_result_free(res):
 
 def entropy_begin_group(batches, prep_stream=0, stream=0, last=False):
     """ONE coder launch over the blocks of several shards (scalce_batch_entropy_begin_group); each shard is completed
-    by its own entropy_end / finish on `stream`.  last: nothing will be queued behind this launch (the end of a run)."""
+    by its own entropy_end / finish on `stream`.  last: 1 / True = nothing will be queued behind this launch (the end of a
+    run); 2 = a small launch at the start of a run (the kernel that holds the fewest CUs whatever the size)."""
     arr = (C.c_void_p * len(batches))(*[b.h for b in batches])
-    batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group_last(arr, len(batches), prep_stream, stream, 1 if last else 0))
+    batches[0]._check(batches[0].L.scalce_batch_entropy_begin_group_last(arr, len(batches), prep_stream, stream, int(last)))
 
 
 class StreamStats(C.Structure):

@@ -48,6 +48,8 @@ class ShardPipeline:
         self._tag = [None] * self.D
         self._pending = []
         self._next = 0
+        self.ramp = not sharded         # launches of 1, 2, .. shards at the start of a run
+        self._run_launches = 0          # launches since the pipeline was last drained
 
     # -- slots ---------------------------------------------------------------------------------------------
     def acquire(self):
@@ -89,17 +91,22 @@ class ShardPipeline:
             self._busy[slot] = ev
             return
         self._pending.append(slot)
-        if len(self._pending) == self.G or flush:
-            self.flush(last=flush)
+        # the first launches of a run are smaller (1, 2, .. shards): a launch takes ~0.6 s whatever it holds, and nothing is
+        # coded -- no slot comes back -- until the first one has gone out
+        target = min(self.G, self._run_launches + 1) if self.ramp else self.G
+        if len(self._pending) >= target or flush:
+            self.flush(last=flush, small=len(self._pending) < self.G and not flush)
 
-    def flush(self, last=False):
-        """last: the caller has no further shards (the end of a run): the launch is picked for its own latency."""
+    def flush(self, last=False, small=False):
+        """last: the caller has no further shards (the end of a run): the launch is picked for its own latency.
+        small: a launch of fewer than `group` shards with more on their way: the kernel that holds the fewest CUs."""
         if not self._pending:
             return
         coder = self.coders[self._launches % len(self.coders)]
         self._launches += 1
+        self._run_launches += 1
         host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, coder.cuda_stream,
-                                 last=last and not self.sharded)
+                                 last=0 if self.sharded else (1 if last else 2 if small else 0))
         ev = self.torch.cuda.Event()
         ev.record(coder)
         for sl in self._pending:
@@ -112,3 +119,4 @@ class ShardPipeline:
         self.flush(last=True)
         for slot in range(self.D):
             self.retire(slot)
+        self._run_launches = 0
