@@ -145,16 +145,28 @@ def main():
         free_b, _ = torch.cuda.mem_get_info()
         scale = (n * L) / 5e9
         # (the batch's own: reordered q' 5 GB, coder blocks 3.5 GB sized from the table, records 1.25, names 0.54, tables)
-        per_slot = (10.7e9 if not sharded else 36e9) * scale + (nbytes if own_text else 0)
+        # (a sharded rank also holds, per shard in flight, its block range of the run-wide quality stream and the exchange
+        #  buffers: 188.6 GB at five in flight with their texts, measured at world 1 over RCCL)
+        per_slot = (10.7e9 if not sharded else 24e9) * scale + (nbytes if own_text else 0)
         fit = int((free_b + (nbytes if own_text else 0) - 22e9 * scale - 5e9) // per_slot)
-        if fit < D:
+        if world > 1:   # every rank takes the same shape
+            tfit = torch.tensor([fit], dtype=torch.int64)
+            dist.all_reduce(tfit, op=dist.ReduceOp.MIN)
+            fit = int(tfit.item())
+        if sharded and fit < D:
+            # a sharded rank needs ~24 GB per shard in flight beside its text: seven fit a 288 GB card
+            if auto_group and fit < 2 * G:
+                G = max(1, fit // 2)
+            D = max(fit, 1)
+            print("bench: %.0f GB of HBM free: %d shards in flight, %d per coder launch" % (free_b / 1e9, D, G), file=sys.stderr)
+        elif fit < D:
             if auto_group and not sharded and fit < 14:
                 # fewer than fourteen fit: three shards per launch on three coder streams keep nine of them in the coder and the
                 # rest in front of it (tools/pipe_shapes_r4.sh: 91 ms per shard at 3 / 11 / 3 against 103 at 4 / 11 / 2)
                 G = 3
             print("bench: %.0f GB of HBM free: %d shards in flight instead of %d, %d per coder launch" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D, G), file=sys.stderr)
             D = fit
-    if G > 1:
+    if G > 1 and not (sharded and args.inflight is None):
         D = max(D, 2 * G)
     # slot i reads texts[i]: different seeds, the same record shape (sizes are equal: names and lengths are)
     texts = [text]
@@ -285,6 +297,20 @@ def main():
     # ---- the run proves its own output (never inside the timed region) ----
     parity = {}
     decode = None
+    if rank == 0 and sharded and world == 1 and not args.no_verify:
+        # the sharded path at world 1 (SCALCE_BENCH_FORCE_SHARDED=1: every collective a real RCCL call of one rank) builds the
+        # whole archive in one batch: the same three hashes must come out
+        from scalce_amd import verify
+        gold_path = os.path.join(ROOT, "tests", "golden", "full_size_ref.json")
+        try:
+            gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
+            if gold and (gold["reads"], gold["length"], gold["seed"]) == (n, L, SEED0) and B == 4 << 30:
+                got = verify.archive_hashes(batches[0], L, off, n)
+                same = {k: got[k] == v["sha256"] for k, v in gold["files"].items()}
+                parity["reference_full_size"] = {"ok": all(same.values()), "files": same,
+                                                 "what": "sharded path, one rank: SHA-256 of .scalce{n,r,q} of slot 0's shard equal to the reference's own compress() -T 1 files"}
+        except Exception as ex:  # noqa: BLE001
+            parity["reference_full_size"] = {"ok": False, "error": repr(ex)[:300]}
     if rank == 0 and not sharded and not args.no_verify:
         from scalce_amd import verify
         # the checks need room (5 GB of symbols, 10.8 GB of text, the digest's temporaries): everything but slot 0 and the slot

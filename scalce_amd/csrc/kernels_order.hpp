@@ -37,7 +37,8 @@ struct KeyDigit {
 // form "runs" and only those go through the remaining key digits (phase 2).  On reads without exact
 // duplicates almost nothing is left for phase 2, so the random digit gathers drop from ceil(L/4) passes to
 // PREFIX_DIGITS.
-constexpr int PREFIX_DIGITS = 4;
+constexpr int PREFIX_DIGITS = 3;            // (round 4: three digits = 12 key bases; with four the keys were 48 + 16 bits and phase 1 six passes, now five)
+constexpr int PREFIX_BITS = 8 * PREFIX_DIGITS;
 
 struct RunArgs {
   u32 n;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void order_keys_k(u32 n, const u32 *bucket, co
   if (chunk) hi = (hi << chunk_bits) | chunk[i];
   // where 16 bits are left below the sorted part, the record's `end` rides along: the emit stage then finds bucket and
   // end of the k-th record in the k-th key instead of gathering them through the permutation
-  keys[i] = (((hi << 32) | prefix) << end_bits) | (end_bits ? (u64)end[i] : 0ull);
+  keys[i] = (((hi << PREFIX_BITS) | prefix) << end_bits) | (end_bits ? (u64)end[i] : 0ull);
 }
 __global__ __launch_bounds__(256) void run_heads_keys_k(u32 n, const u64 *sorted_keys, u32 end_bits, u8 *head) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -373,6 +373,10 @@ struct scalce_batch {
 
 static int ensure(scalce_batch *b, DBuf &d, size_t bytes) {
   if (bytes <= d.cap) return SCALCE_OK;
+  // (an allocation synchronises the whole device: in a pipeline it waits for every coder that is running.  SCALCE_DEBUG_ALLOC=1
+  //  names the ones that still happen after the warm-up)
+  static const bool dbg = getenv("SCALCE_DEBUG_ALLOC") != nullptr;
+  if (dbg) fprintf(stderr, "scalce: batch %p grows a buffer from %zu to %zu bytes\n", (void *)b, d.cap, bytes);
   if (d.p) hipFree(d.p);
   d.p = nullptr; d.cap = 0;
   bytes = (bytes + 255) & ~size_t(255);
@@ -1538,16 +1542,16 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   // together with thousands of chunks): every pass then reads and writes sequentially.  The index-only passes below
   // gather a digit through the index in every pass: 8 GB of sector fetches per pass at 50 M reads, and the scattered
   // accesses are what slows a coder launch running beside the order stage most (tools/coder_beside.py).
-  const bool by_pairs = two_phase && 32 + cbits + bits <= 64 && !getenv("SCALCE_ORDER_INDEX_ONLY");
+  const bool by_pairs = two_phase && PREFIX_BITS + cbits + bits <= 64 && !getenv("SCALCE_ORDER_INDEX_ONLY");
   u64 *sorted_keys = nullptr;
-  const u32 end_bits = (48 + cbits + bits <= 64) ? 16u : 0u;
+  const u32 end_bits = (16 + PREFIX_BITS + cbits + bits <= 64) ? 16u : 0u;
   if (by_pairs) {
     ENSURE(b, b->key_a, sizeof(u64) * (N + 2));
     ENSURE(b, b->key_b, sizeof(u64) * (N + 2));
     u64 *ka = b->key_a.as<u64>(), *kb = b->key_b.as<u64>();
     LAUNCH(order_keys_k, cdiv(N, 256), 256, 0, s, (u32)N, b->bucket.as<u32>(), chunk_or_null, (u32)cbits, b->packed[0].as<u8>(),
            b->endv.as<u16>(), b->L[0], b->stride[0], ndig1, end_bits, ka);
-    for (int sh = (int)end_bits; sh < (int)end_bits + 32 + cbits + bits; sh += 8) {
+    for (int sh = (int)end_bits; sh < (int)end_bits + PREFIX_BITS + cbits + bits; sh += 8) {
       radix_pass_kv(ka, src, kb, dst, (u32)N, (u32)sh, b->hist.as<u32>(), ws32, s);
       flip();
       u64 *t = ka; ka = kb; kb = t;
@@ -1555,7 +1559,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
     sorted_keys = ka;
     b->sorted_keys = ka;
     b->key_end_bits = end_bits;
-    b->key_bucket_shift = end_bits + 32 + (u32)cbits;
+    b->key_bucket_shift = end_bits + PREFIX_BITS + (u32)cbits;
     b->key_bucket_mask = (1u << bits) - 1;
   } else {
     // phase 1: first ndig1 key digits (least significant first), then chunk, then bucket
@@ -2013,6 +2017,9 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
       HIP_TRY(b->ctx, hipMemcpyAsync(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost, s));
       HIP_TRY(b->ctx, hipStreamSynchronize(s));
       if (e.code == E_ACOVERFLOW) {
+        if (getenv("SCALCE_DEBUG_ALLOC"))
+          fprintf(stderr, "scalce: batch %p: block %llu outgrew its %llu-byte buffer (it needed %u): coding the shard again at the full stride\n",
+                  (void *)b, (unsigned long long)e.where, (unsigned long long)b->ac_stride[0], e.aux);
         HIP_TRY(b->ctx, hipMemsetAsync(b->d_err, 0, sizeof(DevErr), s));
         int rc = entropy_recode_full(b, s);
         if (rc) return rc;
