@@ -145,6 +145,12 @@ int scalce_stream_compress(scalce_ctx *ctx, const scalce_params *p, scalce_read_
  * exists, rows and sort scratch once the records are emitted): outputs 5, 6, 9 become unavailable, runs sized for most
  * of HBM fit. */
 void scalce_batch_set_lean(scalce_batch *b, int lean);
+/* Row layout of the batch.  A single-end batch with names keeps ONE row per read -- q' | name cell | packed bases, what the
+ * reference keeps per read in its bucket blob (reads.h:52-58, compress.cpp:675-706) -- so that the emit stage reaches
+ * everything it reorders through one random access.  on = 0 (before anything is ingested) goes back to separate arrays whose
+ * rows lie back to back: for callers that read SCALCE_OUT_QINPUT as one array (sharded runs); lean batches do so by themselves.
+ * Returns SCALCE_ERR_ARG when the batch cannot take the layout asked for. */
+int scalce_batch_set_fused_rows(scalce_batch *b, int on);
 /* output_quality (qualities.cpp:177-204): q' = map[q]-offset (N -> 0) and the order-2 trigram
  * counters ac_freq4 over the input-order stream of this shard. */
 int scalce_batch_quality(scalce_batch *b, void *stream);

@@ -96,9 +96,15 @@ struct UnpackArgs {
   u64 nrec;
   int L, stride, mate, use_names, no_ac;
   u8 *packed;     // nrec * stride, zero padded rows, base 4j..4j+3 in byte j, first base in bits 7-6
-  u8 *q;          // nrec * L
+  u8 *q;          // nrec rows of L symbols, qstride bytes apart (L: back to back)
   u8 *namelen;    // nrec (mate 0 only)
-  u8 *namecell;   // nrec x 16 (mate 0, names on): [length][first 15 characters] -- one gather for the emit stage
+  u8 *namecell;   // nrec cells of 16 bytes, cellstride apart (mate 0, names on): [length][first 15 characters]
+  // One row per read (round 4): q' | name cell | a second copy of the packed bases, qstride = cellstride = the row's size,
+  // namecell = q + round4(L), packed2 = namecell + 16.  The emit stage then finds everything it gathers through the
+  // permutation -- 100 + 16 + 25 bytes of a 100 bp read -- behind ONE random access instead of three (the rows the
+  // tokenizer and the order stage walk stay where they are: 32-byte rows read in sequence).
+  u32 qstride, cellstride;
+  u8 *packed2;    // or null: the copy of the packed words inside the fused row, cellstride apart, ceil(L / 16) words each
   const u8 *qlut;  // 128 bytes: (values[c] - offset) & 255
   int q_affine;    // >= 0: values[c] == c for every c, q' = (c & 127) - q_affine without the table
   DevErr *err;
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
       rec_sq[k] = 0xFFFFu;
       if (a.u.mate == 0) {  // the run ends with an error; until the host sees it, later stages must find a well-formed row
         a.u.namelen[rid] = 0;
-        if (a.u.namecell) *reinterpret_cast<uint4 *>(a.u.namecell + 16 * rid) = make_uint4(0, 0, 0, 0);
+        if (a.u.namecell) { u32x4a z; z.x = z.y = z.z = z.w = 0; *reinterpret_cast<u32x4a *>(a.u.namecell + (u64)a.u.cellstride * rid) = z; }
       }
       continue;
     }
@@ -684,7 +690,8 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
             w[x] = keepb >= 4 ? v : keepb <= 0 ? 0u : (v & ((1u << (8 * keepb)) - 1));
           }
           w[0] = (w[0] & 0xFFFFFF00u) | nlen;
-          *reinterpret_cast<uint4 *>(a.u.namecell + 16 * rid) = make_uint4(w[0], w[1], w[2], w[3]);
+          u32x4a cv; cv.x = w[0]; cv.y = w[1]; cv.z = w[2]; cv.w = w[3];
+          *reinterpret_cast<u32x4a *>(a.u.namecell + (u64)a.u.cellstride * rid) = cv;  // (4-byte aligned inside a fused row)
         }
         if (nlen > 15 && a.u.max_namelen) atomicMax(a.u.max_namelen, nlen);
       }
@@ -701,6 +708,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
     const u32 S = (u32)a.u.stride / 4, units = ntake * S, wfull = (u32)L / 16;
     u32 k = (u32)(((u64)(u32)tid * g.magic_s) >> 32), w = (u32)tid - k * S;
     u32 *dst = reinterpret_cast<u32 *>(a.u.packed + rid0 * (u64)a.u.stride);
+    const u32 w2n = ((u32)L + 15) / 16;  // words of the copy inside the fused row
     for (u32 u = (u32)tid; u < units; u += ING_THREADS) {
       const u32 sb = rec_sb[k];
       if (sb != 0xFFFFu) {
@@ -724,6 +732,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
           }
         }
         dst[u] = acc;
+        if (a.u.packed2 && w < w2n) reinterpret_cast<u32 *>(a.u.packed2 + (rid0 + k) * (u64)a.u.cellstride)[w] = acc;
       }
       k += g.step_ks; w += g.step_rs;
       if (w >= S) { w -= S; k++; }
@@ -737,9 +746,10 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
     const bool al = (L & 3) == 0;
     const u32 aff = (u32)(a.u.q_affine >= 0 ? a.u.q_affine : 0) * 0x01010101u;
     u32 k = (u32)(((u64)(u32)tid * g.magic_w) >> 32), w = (u32)tid - k * W;
-    u8 *qtile = a.u.q + rid0 * (u64)L;
-    u32 qoff = k * (u32)L + 16 * w;                                 // (a tile's q' rows: far below 2^32 bytes)
-    const u32 qstep = g.step_kw * (u32)L + 16 * g.step_rw, qwrap = (u32)L - 16 * W;
+    const u32 QS = a.u.qstride;
+    u8 *qtile = a.u.q + rid0 * (u64)QS;
+    u32 qoff = k * QS + 16 * w;                                     // (a tile's q' rows: far below 2^32 bytes)
+    const u32 qstep = g.step_kw * QS + 16 * g.step_rw, qwrap = QS - 16 * W;
     auto quality = [&](u32 vq) -> u32 {
       if (a.u.q_affine >= 0)  // four subtractions in one word (see unpack_record_at)
         return (((vq & 0x7F7F7F7Fu) | 0x80808080u) - aff) ^ 0x80808080u;
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   if (hi >= 80 && !a.u.no_ac) {  // a symbol the coder's tables have no row for (arithmetic.h:47): which record was it?
     for (u32 k = (u32)tid; k < ntake; k += ING_THREADS) {
       if (rec_sb[k] == 0xFFFFu) continue;
-      const u8 *qsrc = a.u.q + (rid0 + k) * (u64)L;
+      const u8 *qsrc = a.u.q + (rid0 + k) * (u64)a.u.qstride;
       bool bad = false;
       for (int x = 0; x < L; x++) bad |= qsrc[x] >= 80;
       if (bad) { dev_fail(a.u.err, E_SYMBOL, rid0 + k); break; }
@@ -878,10 +888,15 @@ __global__ __launch_bounds__(256) void sym_range_k(const u8 *q, u64 n, u32 *minm
 // range[0] = smallest symbol < 80 that occurs, range[1] = A = span of the occurring symbols (0: none)
 // The two symbols in front of a piece (qualities.cpp:179: prev[] runs across reads): the tail of the q' rows already
 // held when there are any (q_piece points behind them), else what the caller carried in (500 = none).
-__global__ void tri_prev_k(const u8 *q_piece, u64 symbols_before, u32 carried0, u32 carried1, u32 *prev /*[2]*/) {
+// (q0 = the first row of the batch, rows of L symbols qstride bytes apart; the piece begins at symbol symbols_before)
+__device__ __forceinline__ u32 q_symbol(const u8 *q0, u32 L, u32 qstride, u64 t) {
+  const u64 row = t / L;
+  return q0[row * qstride + (t - row * L)];
+}
+__global__ void tri_prev_k(const u8 *q0, u32 L, u32 qstride, u64 symbols_before, u32 carried0, u32 carried1, u32 *prev /*[2]*/) {
   if (threadIdx.x || blockIdx.x) return;
-  if (symbols_before >= 2) { prev[0] = *(q_piece - 2); prev[1] = *(q_piece - 1); }
-  else if (symbols_before == 1) { prev[0] = carried1; prev[1] = *(q_piece - 1); }
+  if (symbols_before >= 2) { prev[0] = q_symbol(q0, L, qstride, symbols_before - 2); prev[1] = q_symbol(q0, L, qstride, symbols_before - 1); }
+  else if (symbols_before == 1) { prev[0] = carried1; prev[1] = q_symbol(q0, L, qstride, 0); }
   else { prev[0] = carried0; prev[1] = carried1; }
 }
 
@@ -906,8 +921,13 @@ __global__ void tri_range_k(const u32 *minmax, const u32 *prev, u32 *range) {
 // fraction of the speed of the others, and with equal shares the whole workgroup -- and the kernel, one workgroup per
 // CU -- waited for them (4.4 -> 14 ms per pass).
 constexpr u32 TRI_TILE = 64 * 1024;
+// q = the piece's first row; rows of L symbols lie qstride bytes apart (qstride == L: the stream is contiguous).  With
+// fused rows (qstride > L, both multiples of 4) a unit of 16 symbols is one 16-byte load at a 4-byte boundary when it lies
+// inside a row and is put together from two rows when it does not; a thread finds (row, column) of its first unit by one
+// division per tile and moves on by additions.
 __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, const u32 *prev, u32 pass,
-                                                             const u32 *range, u64 *freq4, unsigned long long *tile_counter) {
+                                                             const u32 *range, u64 *freq4, unsigned long long *tile_counter,
+                                                             u32 L, u32 qstride) {
   const u32 prev0 = prev[0], prev1 = prev[1];
   // Counters are 16-bit fields, two per word: twice the leading symbols per pass (a 39-symbol alphabet in ONE streaming
   // pass, the full 80 in nine instead of twenty).  LDS has 32-bit atomics only, so a field must never carry into its
@@ -932,11 +952,18 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
     const u64 tbase = tile * TRI_TILE;
     if (tbase >= n) break;
     const u64 tend = tbase + TRI_TILE < n ? tbase + TRI_TILE : n;
+    const bool rows = qstride != L;
+    u64 row = 0;
+    u32 col = 0;
+    if (rows) { const u64 t0 = tbase + (u64)lane * 16; row = t0 / L; col = (u32)(t0 - row * L); }
+    const u32 adv_r = 1024u / L, adv_c = 1024u - adv_r * L;
   for (u64 t = tbase + (u64)lane * 16; t < tend; t += 64 * 16) {
-    u32 a = t >= 2 ? q[t - 2] : (t == 1 ? prev1 : prev0);
-    u32 b = t >= 1 ? q[t - 1] : prev1;
+    u32 a, b;
     u32 w[4];
     int cnt = 16;
+    if (!rows) {
+    a = t >= 2 ? q[t - 2] : (t == 1 ? prev1 : prev0);
+    b = t >= 1 ? q[t - 1] : prev1;
     if (t + 16 <= n) {
       const uint4 v = *reinterpret_cast<const uint4 *>(q + t);
       w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
@@ -944,6 +971,28 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
       cnt = (int)(n - t);
       w[0] = w[1] = w[2] = w[3] = 0;
       for (int k = 0; k < cnt; k++) w[k >> 2] |= (u32)q[t + k] << (8 * (k & 3));
+    }
+    } else {
+      const u8 *rp = q + row * qstride;
+      // the two symbols in front: in this row, or the tail of the row before
+      a = col >= 2 ? rp[col - 2] : (t >= 2 ? (rp - qstride)[L + col - 2] : (t == 1 ? prev1 : prev0));
+      b = col >= 1 ? rp[col - 1] : (t >= 1 ? (rp - qstride)[L - 1] : prev1);
+      if (col + 16 <= L && t + 16 <= n) {
+        typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const u32x4u v = *reinterpret_cast<const u32x4u *>(rp + col);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+      } else {
+        cnt = t + 16 <= n ? 16 : (int)(n - t);
+        w[0] = w[1] = w[2] = w[3] = 0;
+        u32 c = col;
+        const u8 *p = rp;
+        for (int k = 0; k < cnt; k++) {
+          if (c == L) { c = 0; p += qstride; }
+          w[k >> 2] |= (u32)p[c++] << (8 * (k & 3));
+        }
+      }
+      row += adv_r; col += adv_c;
+      if (col >= L) { col -= L; row++; }
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {

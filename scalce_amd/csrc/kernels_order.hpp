@@ -259,14 +259,25 @@ struct EmitArgs {
   u8 *out;
   const u64 *keys;          // sorted phase-1 keys (position k <-> record perm[k]) or null
   u32 key_bucket_shift, key_bucket_mask, key_end_bits;
+  // Fused rows (emit_reads_k<true>): `packed` points at the copy of the packed words inside the row, `stride` is the row's
+  // size and `pwords` the words of that copy; the same workgroup then also takes the name cell (frow + cell_off) into
+  // cells_sorted / outlen and the row's q' (frow, L bytes, L % 4 == 0) into the reordered stream `qs` -- one random access
+  // per record for everything the emit stage gathers.
+  int pwords;
+  const u8 *frow;
+  u32 cell_off, qunits;     // qunits = ceil(L / 16): 16-byte units of a row's q'
+  u64 qmagic;               // ceil(2^32 / qunits)
+  u8 *cells_sorted, *outlen, *qs;
 };
 // The records of a workgroup's 256 positions are contiguous in the output (bucket headers included), 27 bytes each at
 // L = 100 and not aligned to anything: written by their own threads byte by byte they cost 4.6 bytes of HBM writes per
 // byte (PMC WRITE_SIZE).  They are assembled in LDS instead and leave as one coalesced block.
 constexpr int EMIT_STAGE_BYTES = 256 * 64;
+template <bool FUSED>
 __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
   __shared__ __attribute__((aligned(16))) u8 stage[EMIT_STAGE_BYTES];
   __shared__ u64 wg_begin, wg_end;
+  __shared__ u32 s_row[FUSED ? 256 : 1];
   const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = k < a.nrec;
   u64 my_begin = 0, my_end = 0, rec_at = 0;
@@ -285,6 +296,15 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     my_begin = (k == first) ? a.bucket_off[b] : rec_at;
     my_end = rec_at + (u64)recsz;
   }
+  if (FUSED) {
+    s_row[threadIdx.x] = r;
+    if (live && a.cells_sorted) {  // the name cell: 16 bytes at a 4-byte boundary of the row -> position k
+      typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      const u32x4u c = *reinterpret_cast<const u32x4u *>(a.frow + (u64)r * a.stride + a.cell_off);
+      *reinterpret_cast<uint4 *>(a.cells_sorted + 16 * k) = make_uint4(c.x, c.y, c.z, c.w);
+      a.outlen[k] = (u8)(c.x & 0xFFu);
+    }
+  }
   if (threadIdx.x == 0) wg_begin = my_begin;
   if (live && (threadIdx.x == blockDim.x - 1 || k + 1 == a.nrec)) wg_end = my_end;
   __syncthreads();
@@ -302,7 +322,7 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     // words of the packed row: output word j = up to two bit-field fetches (funnel shifts) instead of 16
     // single-base extractions.
     const u32 *roww = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
-    const int nwords = a.stride >> 2;
+    const int nwords = FUSED ? a.pwords : a.stride >> 2;
     auto S = [&](int i) -> u32 { return i < nwords ? __builtin_bswap32(roww[i]) : 0u; };
     auto bits32 = [&](int pos) -> u32 {  // 32 source bits starting at bit `pos` (MSB first)
       const int w = pos >> 5, sh = pos & 31;
@@ -329,6 +349,25 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     }
     dst[j] = (u8)e;  // end marker, reads.cpp:130
     if (a.sz_meta == 2) dst[j + 1] = (u8)(e >> 8);
+  }
+  if (FUSED && a.qs) {
+    // q' of the workgroup's records: units of 16 bytes dealt to the threads in order -- consecutive threads read consecutive
+    // units of a row (which the loads above have just brought in) and write consecutive bytes of the stream
+    const u64 k0 = (u64)blockIdx.x * blockDim.x;
+    const u32 nlive = (u32)(a.nrec - k0 < 256 ? a.nrec - k0 : 256);
+    const u32 units = nlive * a.qunits, L = (u32)a.L;
+    typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    u8 *qdst = a.qs + k0 * (u64)L;
+    for (u32 u = threadIdx.x; u < units; u += 256) {
+      const u32 rec = (u32)(((u64)u * a.qmagic) >> 32), j = u - rec * a.qunits;
+      const u8 *src = a.frow + (u64)s_row[rec] * a.stride + 16 * j;
+      u8 *dst = qdst + rec * L + 16 * j;
+      if (16 * j + 16 <= L) {
+        *reinterpret_cast<u32x4u *>(dst) = *reinterpret_cast<const u32x4u *>(src);
+      } else {
+        for (u32 x = 16 * j; x < L; x += 4) *reinterpret_cast<u32 *>(dst + (x - 16 * j)) = *reinterpret_cast<const u32 *>(src + (x - 16 * j));
+      }
+    }
   }
   if (!staged) return;
   __syncthreads();
@@ -458,6 +497,41 @@ __global__ __launch_bounds__(256) void gather_rows_k(u64 nrec, const u32 *perm, 
       if (cnt == 16) *reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
       else for (int j = 0; j < cnt; j++) out[i0 + j] = (u8)(v[j >> 2] >> (8 * (j & 3)));
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_bytes_k(const u8 *v, u64 n, unsigned long long *out /* zeroed */) {
+  u64 acc = 0;
+  for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += (u64)gridDim.x * blockDim.x * 16) {
+    if (i + 16 <= n && (((u64)(v + i)) & 15) == 0) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(v + i);
+      const u32 x[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc += (x[k] & 0xFF) + ((x[k] >> 8) & 0xFF) + ((x[k] >> 16) & 0xFF) + (x[k] >> 24);
+    } else {
+      for (u64 j = i; j < n && j < i + 16; j++) acc += v[j];
+    }
+  }
+  for (int o = 32; o; o >>= 1) acc += (u64)__shfl_xor((long long)acc, o);
+  if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+// classic arrays of a piece -> fused rows (the rare pieces that went through the indexed ingest kernels): row r = q' | cell | packed words
+__global__ __launch_bounds__(256) void fuse_rows_k(u64 nrec, const u8 *q, u32 L, const u8 *cells /* or null */, const u8 *packed, u32 pstride, u32 pwords,
+                                                  u8 *frow, u32 rs, u32 cell_off) {
+  const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrec) return;
+  u8 *row = frow + r * (u64)rs;
+  for (u32 x = 0; x < L; x++) row[x] = q[r * (u64)L + x];
+  u32 *c = reinterpret_cast<u32 *>(row + cell_off);
+  for (int x = 0; x < 4; x++) c[x] = cells ? reinterpret_cast<const u32 *>(cells + 16 * r)[x] : 0u;
+  for (u32 x = 0; x < pwords; x++) c[4 + x] = reinterpret_cast<const u32 *>(packed + r * (u64)pstride)[x];
+}
+// q' of fused rows as one contiguous array (SCALCE_OUT_QINPUT for callers that want that)
+__global__ __launch_bounds__(256) void compact_q_k(u64 nrec, const u8 *frow, u32 rs, u32 L, u8 *out) {
+  const u64 total = nrec * (u64)L;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+    const u64 r = i / L;
+    out[i] = frow[r * rs + (i - r * L)];
   }
 }
 

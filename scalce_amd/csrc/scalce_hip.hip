@@ -359,6 +359,12 @@ struct scalce_batch {
   // a 50 M-read shard holds 5 GB of which 2.9 are used.  ac_prepare sizes the stride from what the table says coding its own
   // counts costs (+ 8 % + 64 KiB); a block that outgrows it reports E_ACOVERFLOW and the shard is coded again at the full
   // stride when it is collected (entropy_recode_full) -- same bytes, one launch later.
+  // One row per read (single-end runs with names, read lengths the tile ingest takes): q[0] holds rows of `qstride[0]` bytes --
+  // q' | name cell | a copy of the packed words -- and there is no separate cell array; the emit stage gathers a record's q',
+  // cell and bases with ONE random access (emit_reads_k<true>).  Otherwise qstride[m] = L[m]: rows back to back.
+  bool fused = false;
+  u32 qstride[2] = {0, 0}, row_cell_off = 0, row_pwords = 0;
+  DBuf q_compact, fuse_q, fuse_cells;  // SCALCE_OUT_QINPUT of fused rows on request; classic arrays of a piece the indexed kernels took
   u64 ac_stride[2] = {0, 0};
   const u8 *ac_last_sym[2] = {nullptr, nullptr};  // what the last launch coded (for the recode)
   u64 ac_last_nsym[2] = {0, 0};
@@ -423,7 +429,7 @@ static void free_all(scalce_batch *b) {
   DBuf *all[] = {&b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->counts_total, &b->bucket_name_bytes,
                  &b->ac_scan, &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->ac_tab[0], &b->ac_cum[0], &b->ac_blocks[0],
                  &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1], &b->ac_sizes[1], &b->ac_off[1],
-                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1], &b->ac_tab8[0], &b->ac_tab8[1]};
+                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1], &b->ac_tab8[0], &b->ac_tab8[1], &b->q_compact, &b->fuse_q, &b->fuse_cells};
   for (DBuf *d : all)
     if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
   if (b->owns_ws) { b->ws->free_all(); delete b->ws; }
@@ -447,10 +453,10 @@ static int reserve_rows(scalce_batch *b, u64 rows, u64 used, hipStream_t s) {
   int rc;
   for (int m = 0; m < b->nm; m++) {
     if ((rc = ensure_keep(b, b->packed[m], (size_t)b->stride[m] * rows + 64, (size_t)b->stride[m] * used, s))) return rc;
-    if ((rc = ensure_keep(b, b->q[m], (size_t)b->L[m] * rows + 64, (size_t)b->L[m] * used, s))) return rc;
+    if ((rc = ensure_keep(b, b->q[m], (size_t)b->qstride[m] * rows + 64, (size_t)b->qstride[m] * used, s))) return rc;
   }
   if ((rc = ensure_keep(b, b->namelen, rows + 64, used, s))) return rc;
-  if (b->p.use_names && (rc = ensure_keep(b, b->namecell, 16 * (rows + 8), 16 * used, s))) return rc;
+  if (b->p.use_names && !b->fused && (rc = ensure_keep(b, b->namecell, 16 * (rows + 8), 16 * used, s))) return rc;
   if (b->name_in_off.p && (rc = ensure_keep(b, b->name_in_off, sizeof(u64) * (rows + 2), sizeof(u64) * used, s))) return rc;
   if ((rc = ensure_keep(b, b->bucket, sizeof(u32) * (rows + 1), sizeof(u32) * used, s))) return rc;
   if ((rc = ensure_keep(b, b->endv, sizeof(u16) * (rows + 1), sizeof(u16) * used, s))) return rc;
@@ -507,6 +513,15 @@ static int batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_read
     b->stride[m] = ((b->szr[m] + 1 + 15) / 16) * 16;  // one spare zero byte for 16-bit digit windows
   }
   b->sz_meta = b->L[0] > 255 ? 2 : 1;  // reads.cpp:106-108
+  b->qstride[0] = (u32)b->L[0];
+  b->qstride[1] = (u32)b->L[1];
+  if (b->nm == 1 && p->use_names && (b->L[0] & 3) == 0 && b->L[0] >= 16 && b->L[0] <= 160 && !getenv("SCALCE_FUSED_ROWS_OFF") &&
+      !getenv("SCALCE_INGEST_PAIRS")) {  // (the two-threads-per-record comparison kernel writes rows back to back)
+    b->fused = true;
+    b->row_cell_off = (u32)b->L[0];
+    b->row_pwords = (u32)(b->L[0] + 15) / 16;
+    b->qstride[0] = (b->row_cell_off + 16 + 4 * b->row_pwords + 15) / 16 * 16;
+  }
   *out = b;
   HIP_TRY(c, hipMalloc(&b->d_err, sizeof(DevErr)));
   HIP_TRY(c, hipMemset(b->d_err, 0, sizeof(DevErr)));
@@ -688,9 +703,18 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
   a.text = d_text; a.nbytes = nbytes; a.line_end = nullptr; a.nrec = nrec;
   a.L = b->L[mate]; a.stride = b->stride[mate]; a.mate = mate; a.use_names = b->p.use_names; a.no_ac = b->p.no_ac;
   a.packed = b->packed[mate].as<u8>() + b->base * (u64)b->stride[mate];
-  a.q = b->q[mate].as<u8>() + b->base * (u64)b->L[mate];
+  a.q = b->q[mate].as<u8>() + b->base * (u64)b->qstride[mate];
+  a.qstride = b->qstride[mate];
+  a.cellstride = 16;
+  a.packed2 = nullptr;
   a.namelen = b->namelen.as<u8>() + b->base;
-  a.namecell = (mate == 0 && b->p.use_names) ? b->namecell.as<u8>() + 16 * b->base : nullptr;
+  a.namecell = (mate == 0 && b->p.use_names && !b->fused) ? b->namecell.as<u8>() + 16 * b->base : nullptr;
+  const bool fused_rows = b->fused && mate == 0;
+  if (fused_rows) {  // the cell and a copy of the packed words lie behind the row's q'
+    a.namecell = a.q + b->row_cell_off;
+    a.cellstride = a.qstride;
+    a.packed2 = a.namecell + 16;
+  }
   a.qlut = b->d_qlut[mate]; a.err = b->d_err;
   a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
   a.max_namelen = b->d_small + 16;
@@ -761,9 +785,22 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
     { int rc = ensure_line_index(b, mate, s); if (rc) return rc; }
     a.line_end = b->line_end[mate].as<u64>();
     if (mate == 0) HIP_TRY(c, hipMemsetAsync(b->d_small + 16, 0, sizeof(u32), s));
+    u8 *row_q = a.q;
+    if (fused_rows) {  // the indexed kernels write rows back to back: into arrays of the piece's own, fused behind them
+      ENSURE(b, b->fuse_q, (size_t)a.L * nrec + 64);
+      ENSURE(b, b->fuse_cells, 16 * (size_t)(nrec + 8));
+      a.q = b->fuse_q.as<u8>();
+      a.namecell = b->fuse_cells.as<u8>();
+      a.qstride = (u32)a.L;
+      a.cellstride = 16;
+      a.packed2 = nullptr;
+    }
     if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
       LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
     else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
+    if (fused_rows)
+      LAUNCH(fuse_rows_k, cdiv(nrec, 256), 256, 0, s, nrec, b->fuse_q.as<u8>(), (u32)a.L, b->fuse_cells.as<u8>(), a.packed, (u32)a.stride, b->row_pwords,
+             row_q, b->qstride[0], b->row_cell_off);
     LAUNCH(last_record_end_k, 1, 1, 0, s, a.line_end, nrec, d_consumed);
     { int rc = read_u32(b, b->d_small + 16, flags, 1, s); if (rc) return rc; }
   }
@@ -897,8 +934,23 @@ extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint
   return SCALCE_OK;
 }
 
+// back to rows that lie back to back (before anything is ingested): callers that read q' in input order as one array
+// (sharded runs), runs sized for most of HBM (lean)
+static void unfuse(scalce_batch *b) {
+  if (!b->fused || b->N) return;
+  b->fused = false;
+  b->qstride[0] = (u32)b->L[0];
+  if (b->p.use_names && b->row_cap && b->namecell.cap < 16 * (b->row_cap + 8)) ensure(b, b->namecell, 16 * (b->row_cap + 8));
+}
 extern "C" void scalce_batch_set_lean(scalce_batch *b, int lean) {
-  if (b) b->lean = lean != 0;
+  if (!b) return;
+  b->lean = lean != 0;
+  if (b->lean) unfuse(b);
+}
+extern "C" int scalce_batch_set_fused_rows(scalce_batch *b, int on) {
+  if (!b) return SCALCE_ERR_ARG;
+  if (!on) unfuse(b);
+  return (on != 0) == b->fused ? SCALCE_OK : SCALCE_ERR_ARG;
 }
 
 // ---- stage 1: quality statistics -------------------------------------------------------------------
@@ -917,7 +969,7 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     if (b->p.no_ac) continue;  // statistics are skipped under -A (qualities.cpp:185)
     const u64 n = b->NP * (u64)b->L[m], before = b->base * (u64)b->L[m];
     if (!n) continue;
-    const u8 *q = b->q[m].as<u8>() + before;
+    const u8 *q = b->q[m].as<u8>() + b->base * (u64)b->qstride[m];  // the piece's first row
     u32 *minmax = b->d_small + 24;  // smallest / largest symbol of the piece
     HIP_TRY(c, hipMemsetAsync(minmax, 0xFF, sizeof(u32), s));
     HIP_TRY(c, hipMemsetAsync(minmax + 1, 0, sizeof(u32), s));
@@ -926,17 +978,21 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     if (b->mm_valid[m] && b->ws->tile_mm_owner[m] == b) {
       const u32 nt = cdiv(b->text_bytes[m], ING_TILE);
       LAUNCH(tile_minmax_reduce_k, cdiv(nt, 256 * 16) ? cdiv(nt, 256 * 16) : 1, 256, 0, s, b->tile_mm[m].as<u16>(), nt, minmax);
+    } else if (b->qstride[m] != (u32)b->L[m]) {
+      // (fused rows and no tile ranges -- another batch of the workspace has ingested since: the whole alphabet, more passes)
+      static const u32 whole[2] = {0u, 79u};
+      HIP_TRY(c, hipMemcpyAsync(minmax, whole, sizeof whole, hipMemcpyHostToDevice, s));
     } else {
       LAUNCH(sym_range_k, 2048, 256, 0, s, q, n, minmax);
     }
     u32 *prev = b->d_small + 20 + 2 * m;  // the two symbols in front of this piece
-    LAUNCH(tri_prev_k, 1, 1, 0, s, q, before, b->p.qprev[m][0], b->p.qprev[m][1], prev);
+    LAUNCH(tri_prev_k, 1, 1, 0, s, b->q[m].as<u8>(), (u32)b->L[m], b->qstride[m], before, b->p.qprev[m][0], b->p.qprev[m][1], prev);
     u32 *range = b->d_small + 14;  // {lo, A}: span of the symbols that occur
     LAUNCH(tri_range_k, 1, 1, 0, s, minmax, prev, range);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(b->d_small64 + 300);  // one tile counter per pass
     HIP_TRY(c, hipMemsetAsync(tiles, 0, sizeof(u64) * TRI_MAX_PASSES, s));
     for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
-      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, q, n, prev, pass, range, b->freq4[m].as<u64>(), tiles);
+      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, q, n, prev, pass, range, b->freq4[m].as<u64>(), tiles, (u32)b->L[m], b->qstride[m]);
     {  // one count per symbol with two predecessors (the run's first two have them only when the caller passed qprev)
       const bool p0 = b->p.qprev[m][0] < 80, p1 = b->p.qprev[m][1] < 80;
       const u64 carried = p1 ? (p0 ? 2 : 1) : 0;
@@ -1651,6 +1707,50 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
   exclusive_scan<u64>(LoadAs<u64, u64>{counts}, nb1, StoreTo<u64>{b->bucket_first.as<u64>()}, ws, b->d_small64 + 1, s);
   exclusive_scan<u64>(BucketBytes{counts, c->d_bucket_level, b->L[0], b->sz_meta}, nb1, StoreTo<u64>{b->bucket_off.as<u64>()}, ws,
                       b->d_small64 + 2, s);
+  if (b->fused) {
+    // One row per read: emit_reads_k<true> takes a record's bases, its name cell and its q' from ONE row -- one random access
+    // through the permutation instead of three (emit_reads_k + name_cells_sorted_k + gather_rows_k: each paid its own).  It
+    // needs the record layout only (bucket scans above), so it runs first and brings cells and name lengths into output
+    // order on the way; the name layout is scanned behind it.  The size of the name stream does not depend on the order:
+    // it is summed up front, so that ONE read-back sizes every output.
+    u64 *nsum = b->d_small64 + 11;
+    HIP_TRY(c, hipMemsetAsync(nsum, 0, sizeof(u64), s));
+    if (N) LAUNCH(sum_bytes_k, 1024, 256, 0, s, b->namelen.as<u8>(), N, reinterpret_cast<unsigned long long *>(nsum));
+    u64 h[12];
+    { int rc = read_u64(b, b->d_small64, h, 12, s); if (rc) return rc; }
+    b->out_reads_bytes[0] = h[2];
+    b->out_names_bytes = N + h[11];
+    ENSURE(b, b->out_reads[0], h[2] + 64);
+    ENSURE(b, b->out_names, b->out_names_bytes + 64);
+    ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
+    ENSURE(b, b->outlen, N + 64);
+    ENSURE(b, b->cell_sorted, 16 * (N + 4));
+    ENSURE(b, b->qs[0], (size_t)b->L[0] * N + 64);
+    ENSURE(b, b->bucket_name_bytes, sizeof(u64) * (nb1 + 1));
+    b->names_from_sorted_cells = true;
+    if (N) {
+      EmitArgs a;
+      a.nrec = N; a.perm = b->perm; a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>();
+      a.frow = b->q[0].as<u8>(); a.stride = (int)b->qstride[0]; a.cell_off = b->row_cell_off;
+      a.packed = a.frow + b->row_cell_off + 16; a.pwords = (int)b->row_pwords;
+      a.L = b->L[0]; a.sz_meta = b->sz_meta; a.bucket_level = c->d_bucket_level;
+      a.bucket_pattern = c->d_bucket_pattern; a.bucket_first = b->bucket_first.as<u64>(); a.bucket_off = b->bucket_off.as<u64>();
+      a.counts = counts; a.out = b->out_reads[0].as<u8>();
+      a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
+      a.key_end_bits = b->key_end_bits;
+      a.qunits = ((u32)b->L[0] + 15) / 16;
+      a.qmagic = ((1ull << 32) + a.qunits - 1) / a.qunits;
+      a.cells_sorted = b->cell_sorted.as<u8>(); a.outlen = b->outlen.as<u8>(); a.qs = b->qs[0].as<u8>();
+      LAUNCH(emit_reads_k<true>, cdiv(N, 256), 256, 0, s, a);
+    }
+    exclusive_scan<u64>(NameLenSeq{b->outlen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
+    LAUNCH(bucket_name_bytes_k, cdiv(nb1, 256), 256, 0, s, nb1, b->bucket_first.as<u64>(), counts, b->name_off.as<u64>(), b->d_small64 + 3, N,
+           b->bucket_name_bytes.as<u64>());
+    if (N)
+      LAUNCH(emit_names_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->cell_sorted.as<u8>(), b->name_in_off.as<u64>(),
+             b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
+    return SCALCE_OK;
+  }
   if (b->p.use_names) {
     ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
     ENSURE(b, b->outlen, N + 64);
@@ -1682,7 +1782,8 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.counts = counts; a.out = b->out_reads[0].as<u8>();
     a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
     a.key_end_bits = b->key_end_bits;
-    LAUNCH(emit_reads_k, cdiv(N, 256), 256, 0, s, a);
+    a.pwords = 0; a.frow = nullptr; a.cells_sorted = a.outlen = a.qs = nullptr; a.cell_off = a.qunits = 0; a.qmagic = 0;
+    LAUNCH(emit_reads_k<false>, cdiv(N, 256), 256, 0, s, a);
     if (b->p.use_names && b->names_from_sorted_cells)
       LAUNCH(emit_names_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->cell_sorted.as<u8>(), b->name_in_off.as<u64>(),
              b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
@@ -2413,7 +2514,19 @@ extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, c
     case SCALCE_OUT_PERM: *d_ptr = b->perm; *nbytes = sizeof(u32) * b->N; break;
     case SCALCE_OUT_QSTREAM: *d_ptr = b->qs[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
     case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->tok_open ? b->counts.p : b->counts_total.p; *nbytes = sizeof(u64) * nb1; break;
-    case SCALCE_OUT_QINPUT: *d_ptr = b->q[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
+    case SCALCE_OUT_QINPUT:
+      *nbytes = b->N * (u64)b->L[mate];
+      if (b->qstride[mate] == (u32)b->L[mate]) { *d_ptr = b->q[mate].p; break; }
+      {  // fused rows: the q' of every row as one array, put together on request
+        scalce_batch *mb = const_cast<scalce_batch *>(b);
+        if (hipSetDevice(b->ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return SCALCE_ERR_HIP;
+        int rc = ensure(mb, mb->q_compact, (size_t)*nbytes + 64);
+        if (rc) return rc;
+        if (b->N) LAUNCH(compact_q_k, 4096, 256, 0, (hipStream_t) nullptr, b->N, b->q[mate].as<u8>(), b->qstride[mate], (u32)b->L[mate], mb->q_compact.as<u8>());
+        if (hipDeviceSynchronize() != hipSuccess) return SCALCE_ERR_HIP;
+        *d_ptr = mb->q_compact.p;
+      }
+      break;
     case SCALCE_OUT_NAMELEN: *d_ptr = b->namelen.p; *nbytes = b->N; break;
     case SCALCE_OUT_BUCKET_NAME_BYTES: *d_ptr = b->bucket_name_bytes.p; *nbytes = b->bucket_name_bytes.p ? sizeof(u64) * nb1 : 0; break;
     default: return SCALCE_ERR_ARG;

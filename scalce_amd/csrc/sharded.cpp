@@ -265,6 +265,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     int L[2] = {0, 0};
     local([&] {
       SH_RC(ctx, scalce_batch_reset(b));
+      scalce_batch_set_fused_rows(b, 0);  // (q' in input order is read as one array below: rows back to back)
       SH_RC(ctx, scalce_batch_append(b, text[0], nbytes[0], text[1], nbytes[1], SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_TOKENIZE, used, s));
       N0 = scalce_batch_reads(b);
       for (int m = 0; m < nm; m++) {  // read lengths: symbols per row of the q' output
