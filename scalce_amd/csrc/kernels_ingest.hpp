@@ -99,12 +99,12 @@ struct UnpackArgs {
   u8 *q;          // nrec rows of L symbols, qstride bytes apart (L: back to back)
   u8 *namelen;    // nrec (mate 0 only)
   u8 *namecell;   // nrec cells of 16 bytes, cellstride apart (mate 0, names on): [length][first 15 characters]
-  // One row per read (round 4): q' | name cell | a second copy of the packed bases, qstride = cellstride = the row's size,
-  // namecell = q + round4(L), packed2 = namecell + 16.  The emit stage then finds everything it gathers through the
-  // permutation -- 100 + 16 + 25 bytes of a 100 bp read -- behind ONE random access instead of three (the rows the
-  // tokenizer and the order stage walk stay where they are: 32-byte rows read in sequence).
+  // One row per read (round 4): q' | a second copy of the packed bases, qstride = the row's size (128 bytes for a 100 bp
+  // read: ONE aligned line), packed2 = q + L.  The emit stage then finds a record's q' and bases -- 100 + 25 bytes --
+  // behind ONE random line instead of three (the rows the tokenizer and the order stage walk stay where they are: 32-byte
+  // rows read in sequence; the 16-byte name cells keep their own array: with them a row would not fit a line).
   u32 qstride, cellstride;
-  u8 *packed2;    // or null: the copy of the packed words inside the fused row, cellstride apart, ceil(L / 16) words each
+  u8 *packed2;    // or null: the copy of the packed words inside the fused row, qstride apart, ceil(L / 16) words each
   const u8 *qlut;  // 128 bytes: (values[c] - offset) & 255
   int q_affine;    // >= 0: values[c] == c for every c, q' = (c & 127) - q_affine without the table
   DevErr *err;
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
           }
         }
         dst[u] = acc;
-        if (a.u.packed2 && w < w2n) reinterpret_cast<u32 *>(a.u.packed2 + (rid0 + k) * (u64)a.u.cellstride)[w] = acc;
+        if (a.u.packed2 && w < w2n) reinterpret_cast<u32 *>(a.u.packed2 + (rid0 + k) * (u64)a.u.qstride)[w] = acc;
       }
       k += g.step_ks; w += g.step_rs;
       if (w >= S) { w -= S; k++; }
@@ -982,13 +982,13 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
         const u32x4u v = *reinterpret_cast<const u32x4u *>(rp + col);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
       } else {
+        // the unit runs into the next row (L and the columns are multiples of 4: no word does), or the piece ends inside it
         cnt = t + 16 <= n ? 16 : (int)(n - t);
-        w[0] = w[1] = w[2] = w[3] = 0;
-        u32 c = col;
-        const u8 *p = rp;
-        for (int k = 0; k < cnt; k++) {
-          if (c == L) { c = 0; p += qstride; }
-          w[k >> 2] |= (u32)p[c++] << (8 * (k & 3));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 c = col + 4 * (u32)k;
+          const u8 *p = c < L ? rp + c : rp + qstride + (c - L);
+          w[k] = 4 * k < cnt ? *reinterpret_cast<const u32 *>(p) : 0u;
         }
       }
       row += adv_r; col += adv_c;

@@ -37,7 +37,8 @@ struct KeyDigit {
 // form "runs" and only those go through the remaining key digits (phase 2).  On reads without exact
 // duplicates almost nothing is left for phase 2, so the random digit gathers drop from ceil(L/4) passes to
 // PREFIX_DIGITS.
-constexpr int PREFIX_DIGITS = 3;            // (round 4: three digits = 12 key bases; with four the keys were 48 + 16 bits and phase 1 six passes, now five)
+constexpr int PREFIX_DIGITS = 4;            // (three digits -- five passes instead of six -- were tried in round 4: runs of more than 32 records that agree
+                                            //  on 12 key bases are common enough to send every 50 M-read shard through the 22 radix passes of phase 2: +12 ms)
 constexpr int PREFIX_BITS = 8 * PREFIX_DIGITS;
 
 struct RunArgs {
@@ -259,14 +260,14 @@ struct EmitArgs {
   u8 *out;
   const u64 *keys;          // sorted phase-1 keys (position k <-> record perm[k]) or null
   u32 key_bucket_shift, key_bucket_mask, key_end_bits;
-  // Fused rows (emit_reads_k<true>): `packed` points at the copy of the packed words inside the row, `stride` is the row's
-  // size and `pwords` the words of that copy; the same workgroup then also takes the name cell (frow + cell_off) into
-  // cells_sorted / outlen and the row's q' (frow, L bytes, L % 4 == 0) into the reordered stream `qs` -- one random access
-  // per record for everything the emit stage gathers.
+  // Fused rows (emit_reads_k<true>): `stride` is the row's size, the copy of the packed words (`pwords` of them) lies
+  // cell_off bytes into the row (behind its q'); the same workgroup also takes the row's q' (frow, L bytes, L % 4 == 0) into
+  // the reordered stream `qs` -- one random line per record for the bases and the qualities.  (cells_sorted: a name cell
+  // cell_off + 4 * pwords bytes into the row, for layouts that carry one; the default layout does not.)
   int pwords;
   const u8 *frow;
   u32 cell_off, qunits;     // qunits = ceil(L / 16): 16-byte units of a row's q'
-  u64 qmagic;               // ceil(2^32 / qunits)
+  u64 qmagic, rmagic;       // ceil(2^32 / qunits), ceil(2^32 / (stride / 16))
   u8 *cells_sorted, *outlen, *qs;
 };
 // The records of a workgroup's 256 positions are contiguous in the output (bucket headers included), 27 bytes each at
@@ -296,18 +297,44 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     my_begin = (k == first) ? a.bucket_off[b] : rec_at;
     my_end = rec_at + (u64)recsz;
   }
+  // Fused rows: the workgroup's 256 rows come into LDS first, whole -- every thread issues its share of the 16-byte pieces
+  // back to back (consecutive threads take consecutive pieces of a row), so a row costs ONE trip to memory and all of them
+  // are on their way at once.  (Read where they are used -- the packed words by the record's thread, the q' pieces behind a
+  // barrier -- the same bytes took 8.5 ms per 50 M reads: 5.1 for the first touch of a row, 2.2 for its other line, 0.9 for
+  // the cell, tools/emit_ablate.sh.)  Everything below then reads the row from LDS.
+  extern __shared__ uint4 s_rows[];  // [256][stride / 16]
+  const u32 rs16 = FUSED ? (u32)a.stride >> 4 : 0u;
   if (FUSED) {
     s_row[threadIdx.x] = r;
-    if (live && a.cells_sorted) {  // the name cell: 16 bytes at a 4-byte boundary of the row -> position k
-      typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-      const u32x4u c = *reinterpret_cast<const u32x4u *>(a.frow + (u64)r * a.stride + a.cell_off);
-      *reinterpret_cast<uint4 *>(a.cells_sorted + 16 * k) = make_uint4(c.x, c.y, c.z, c.w);
-      a.outlen[k] = (u8)(c.x & 0xFFu);
+    __syncthreads();
+    const u64 k0 = (u64)blockIdx.x * blockDim.x;
+    const u32 nlive = (u32)(a.nrec - k0 < 256 ? a.nrec - k0 : 256);
+    const u32 units = nlive * rs16;
+    constexpr int MAXU = 16;  // rows of up to 256 bytes
+    uint4 v[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; i++) {
+      const u32 u = (u32)i * 256u + threadIdx.x;
+      if (u < units) {
+        const u32 rec = (u32)(((u64)u * a.rmagic) >> 32), j = u - rec * rs16;
+        v[i] = *reinterpret_cast<const uint4 *>(a.frow + (u64)s_row[rec] * a.stride + 16 * j);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; i++) {
+      const u32 u = (u32)i * 256u + threadIdx.x;
+      if (u < units) s_rows[u] = v[i];
     }
   }
   if (threadIdx.x == 0) wg_begin = my_begin;
   if (live && (threadIdx.x == blockDim.x - 1 || k + 1 == a.nrec)) wg_end = my_end;
   __syncthreads();
+  const u32 *lrow = FUSED ? reinterpret_cast<const u32 *>(s_rows + (u32)threadIdx.x * rs16) : nullptr;  // this thread's record's row
+  if (FUSED && live && a.cells_sorted) {  // the name cell -> position k
+    const u32 *c = lrow + (a.cell_off >> 2) + a.pwords;
+    *reinterpret_cast<uint4 *>(a.cells_sorted + 16 * k) = make_uint4(c[0], c[1], c[2], c[3]);
+    a.outlen[k] = (u8)(c[0] & 0xFFu);
+  }
   const bool staged = wg_end - wg_begin <= (u64)EMIT_STAGE_BYTES;  // always, short of reads of more than ~200 bases
   u8 *dst = staged ? stage + (rec_at - wg_begin) : a.out + rec_at;
   if (live) {
@@ -321,7 +348,7 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     // output_read(line, dest, n = e - lv, l = lv): bases [e, L) then [0, e - lv).  Done on 32-bit big-endian
     // words of the packed row: output word j = up to two bit-field fetches (funnel shifts) instead of 16
     // single-base extractions.
-    const u32 *roww = reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
+    const u32 *roww = FUSED ? lrow + (a.cell_off >> 2) : reinterpret_cast<const u32 *>(a.packed + (u64)r * a.stride);
     const int nwords = FUSED ? a.pwords : a.stride >> 2;
     auto S = [&](int i) -> u32 { return i < nwords ? __builtin_bswap32(roww[i]) : 0u; };
     auto bits32 = [&](int pos) -> u32 {  // 32 source bits starting at bit `pos` (MSB first)
@@ -360,12 +387,14 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     u8 *qdst = a.qs + k0 * (u64)L;
     for (u32 u = threadIdx.x; u < units; u += 256) {
       const u32 rec = (u32)(((u64)u * a.qmagic) >> 32), j = u - rec * a.qunits;
-      const u8 *src = a.frow + (u64)s_row[rec] * a.stride + 16 * j;
+      const uint4 sv = s_rows[rec * rs16 + j];
       u8 *dst = qdst + rec * L + 16 * j;
       if (16 * j + 16 <= L) {
-        *reinterpret_cast<u32x4u *>(dst) = *reinterpret_cast<const u32x4u *>(src);
+        u32x4u o; o.x = sv.x; o.y = sv.y; o.z = sv.z; o.w = sv.w;
+        *reinterpret_cast<u32x4u *>(dst) = o;
       } else {
-        for (u32 x = 16 * j; x < L; x += 4) *reinterpret_cast<u32 *>(dst + (x - 16 * j)) = *reinterpret_cast<const u32 *>(src + (x - 16 * j));
+        const u32 w4[4] = {sv.x, sv.y, sv.z, sv.w};
+        for (u32 x = 16 * j; x < L; x += 4) *reinterpret_cast<u32 *>(dst + (x - 16 * j)) = w4[(x - 16 * j) >> 2];
       }
     }
   }
@@ -515,7 +544,7 @@ __global__ __launch_bounds__(256) void sum_bytes_k(const u8 *v, u64 n, unsigned 
   for (int o = 32; o; o >>= 1) acc += (u64)__shfl_xor((long long)acc, o);
   if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
 }
-// classic arrays of a piece -> fused rows (the rare pieces that went through the indexed ingest kernels): row r = q' | cell | packed words
+// classic arrays of a piece -> fused rows (the rare pieces that went through the indexed ingest kernels): row r = q' | packed words [| cell]
 __global__ __launch_bounds__(256) void fuse_rows_k(u64 nrec, const u8 *q, u32 L, const u8 *cells /* or null */, const u8 *packed, u32 pstride, u32 pwords,
                                                   u8 *frow, u32 rs, u32 cell_off) {
   const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -523,8 +552,8 @@ __global__ __launch_bounds__(256) void fuse_rows_k(u64 nrec, const u8 *q, u32 L,
   u8 *row = frow + r * (u64)rs;
   for (u32 x = 0; x < L; x++) row[x] = q[r * (u64)L + x];
   u32 *c = reinterpret_cast<u32 *>(row + cell_off);
-  for (int x = 0; x < 4; x++) c[x] = cells ? reinterpret_cast<const u32 *>(cells + 16 * r)[x] : 0u;
-  for (u32 x = 0; x < pwords; x++) c[4 + x] = reinterpret_cast<const u32 *>(packed + r * (u64)pstride)[x];
+  for (u32 x = 0; x < pwords; x++) c[x] = reinterpret_cast<const u32 *>(packed + r * (u64)pstride)[x];
+  if (cells) for (int x = 0; x < 4; x++) c[pwords + x] = reinterpret_cast<const u32 *>(cells + 16 * r)[x];
 }
 // q' of fused rows as one contiguous array (SCALCE_OUT_QINPUT for callers that want that)
 __global__ __launch_bounds__(256) void compact_q_k(u64 nrec, const u8 *frow, u32 rs, u32 L, u8 *out) {

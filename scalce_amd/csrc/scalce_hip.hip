@@ -359,9 +359,9 @@ struct scalce_batch {
   // a 50 M-read shard holds 5 GB of which 2.9 are used.  ac_prepare sizes the stride from what the table says coding its own
   // counts costs (+ 8 % + 64 KiB); a block that outgrows it reports E_ACOVERFLOW and the shard is coded again at the full
   // stride when it is collected (entropy_recode_full) -- same bytes, one launch later.
-  // One row per read (single-end runs with names, read lengths the tile ingest takes): q[0] holds rows of `qstride[0]` bytes --
-  // q' | name cell | a copy of the packed words -- and there is no separate cell array; the emit stage gathers a record's q',
-  // cell and bases with ONE random access (emit_reads_k<true>).  Otherwise qstride[m] = L[m]: rows back to back.
+  // One row per read (single-end runs, read lengths the tile ingest takes): q[0] holds rows of `qstride[0]` bytes -- q' | a copy
+  // of the packed words: 128 bytes = one aligned line for a 100 bp read -- and the emit stage gathers a record's q' and bases
+  // with ONE random line (emit_reads_k<true>).  Otherwise qstride[m] = L[m]: rows back to back.
   bool fused = false;
   u32 qstride[2] = {0, 0}, row_cell_off = 0, row_pwords = 0;
   DBuf q_compact, fuse_q, fuse_cells;  // SCALCE_OUT_QINPUT of fused rows on request; classic arrays of a piece the indexed kernels took
@@ -456,7 +456,7 @@ static int reserve_rows(scalce_batch *b, u64 rows, u64 used, hipStream_t s) {
     if ((rc = ensure_keep(b, b->q[m], (size_t)b->qstride[m] * rows + 64, (size_t)b->qstride[m] * used, s))) return rc;
   }
   if ((rc = ensure_keep(b, b->namelen, rows + 64, used, s))) return rc;
-  if (b->p.use_names && !b->fused && (rc = ensure_keep(b, b->namecell, 16 * (rows + 8), 16 * used, s))) return rc;
+  if (b->p.use_names && (rc = ensure_keep(b, b->namecell, 16 * (rows + 8), 16 * used, s))) return rc;
   if (b->name_in_off.p && (rc = ensure_keep(b, b->name_in_off, sizeof(u64) * (rows + 2), sizeof(u64) * used, s))) return rc;
   if ((rc = ensure_keep(b, b->bucket, sizeof(u32) * (rows + 1), sizeof(u32) * used, s))) return rc;
   if ((rc = ensure_keep(b, b->endv, sizeof(u16) * (rows + 1), sizeof(u16) * used, s))) return rc;
@@ -515,12 +515,12 @@ static int batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_read
   b->sz_meta = b->L[0] > 255 ? 2 : 1;  // reads.cpp:106-108
   b->qstride[0] = (u32)b->L[0];
   b->qstride[1] = (u32)b->L[1];
-  if (b->nm == 1 && p->use_names && (b->L[0] & 3) == 0 && b->L[0] >= 16 && b->L[0] <= 160 && !getenv("SCALCE_FUSED_ROWS_OFF") &&
+  if (b->nm == 1 && (b->L[0] & 3) == 0 && b->L[0] >= 16 && b->L[0] <= 160 && !getenv("SCALCE_FUSED_ROWS_OFF") &&
       !getenv("SCALCE_INGEST_PAIRS")) {  // (the two-threads-per-record comparison kernel writes rows back to back)
     b->fused = true;
-    b->row_cell_off = (u32)b->L[0];
+    b->row_cell_off = (u32)b->L[0];   // where the packed words begin
     b->row_pwords = (u32)(b->L[0] + 15) / 16;
-    b->qstride[0] = (b->row_cell_off + 16 + 4 * b->row_pwords + 15) / 16 * 16;
+    b->qstride[0] = (b->row_cell_off + 4 * b->row_pwords + 15) / 16 * 16;
   }
   *out = b;
   HIP_TRY(c, hipMalloc(&b->d_err, sizeof(DevErr)));
@@ -708,13 +708,9 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
   a.cellstride = 16;
   a.packed2 = nullptr;
   a.namelen = b->namelen.as<u8>() + b->base;
-  a.namecell = (mate == 0 && b->p.use_names && !b->fused) ? b->namecell.as<u8>() + 16 * b->base : nullptr;
+  a.namecell = (mate == 0 && b->p.use_names) ? b->namecell.as<u8>() + 16 * b->base : nullptr;
   const bool fused_rows = b->fused && mate == 0;
-  if (fused_rows) {  // the cell and a copy of the packed words lie behind the row's q'
-    a.namecell = a.q + b->row_cell_off;
-    a.cellstride = a.qstride;
-    a.packed2 = a.namecell + 16;
-  }
+  if (fused_rows) a.packed2 = a.q + b->row_cell_off;  // a copy of the packed words lies behind the row's q'
   a.qlut = b->d_qlut[mate]; a.err = b->d_err;
   a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
   a.max_namelen = b->d_small + 16;
@@ -786,20 +782,17 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
     a.line_end = b->line_end[mate].as<u64>();
     if (mate == 0) HIP_TRY(c, hipMemsetAsync(b->d_small + 16, 0, sizeof(u32), s));
     u8 *row_q = a.q;
-    if (fused_rows) {  // the indexed kernels write rows back to back: into arrays of the piece's own, fused behind them
+    if (fused_rows) {  // the indexed kernels write rows back to back: into an array of the piece's own, fused behind them
       ENSURE(b, b->fuse_q, (size_t)a.L * nrec + 64);
-      ENSURE(b, b->fuse_cells, 16 * (size_t)(nrec + 8));
       a.q = b->fuse_q.as<u8>();
-      a.namecell = b->fuse_cells.as<u8>();
       a.qstride = (u32)a.L;
-      a.cellstride = 16;
       a.packed2 = nullptr;
     }
     if ((size_t)UNP_RPB * a.L <= (size_t)UNP_Q_CAP)
       LAUNCH(unpack_tiled_k, cdiv(nrec, UNP_RPB), 2 * UNP_RPB, unp_text_cap(a.L) + 32 + unp_q_cap(a.L), s, a);
     else LAUNCH(unpack_k, cdiv(nrec, 256), 256, 0, s, a);
     if (fused_rows)
-      LAUNCH(fuse_rows_k, cdiv(nrec, 256), 256, 0, s, nrec, b->fuse_q.as<u8>(), (u32)a.L, b->fuse_cells.as<u8>(), a.packed, (u32)a.stride, b->row_pwords,
+      LAUNCH(fuse_rows_k, cdiv(nrec, 256), 256, 0, s, nrec, b->fuse_q.as<u8>(), (u32)a.L, (const u8 *)nullptr, a.packed, (u32)a.stride, b->row_pwords,
              row_q, b->qstride[0], b->row_cell_off);
     LAUNCH(last_record_end_k, 1, 1, 0, s, a.line_end, nrec, d_consumed);
     { int rc = read_u32(b, b->d_small + 16, flags, 1, s); if (rc) return rc; }
@@ -940,7 +933,6 @@ static void unfuse(scalce_batch *b) {
   if (!b->fused || b->N) return;
   b->fused = false;
   b->qstride[0] = (u32)b->L[0];
-  if (b->p.use_names && b->row_cap && b->namecell.cap < 16 * (b->row_cap + 8)) ensure(b, b->namecell, 16 * (b->row_cap + 8));
 }
 extern "C" void scalce_batch_set_lean(scalce_batch *b, int lean) {
   if (!b) return;
@@ -1707,50 +1699,6 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
   exclusive_scan<u64>(LoadAs<u64, u64>{counts}, nb1, StoreTo<u64>{b->bucket_first.as<u64>()}, ws, b->d_small64 + 1, s);
   exclusive_scan<u64>(BucketBytes{counts, c->d_bucket_level, b->L[0], b->sz_meta}, nb1, StoreTo<u64>{b->bucket_off.as<u64>()}, ws,
                       b->d_small64 + 2, s);
-  if (b->fused) {
-    // One row per read: emit_reads_k<true> takes a record's bases, its name cell and its q' from ONE row -- one random access
-    // through the permutation instead of three (emit_reads_k + name_cells_sorted_k + gather_rows_k: each paid its own).  It
-    // needs the record layout only (bucket scans above), so it runs first and brings cells and name lengths into output
-    // order on the way; the name layout is scanned behind it.  The size of the name stream does not depend on the order:
-    // it is summed up front, so that ONE read-back sizes every output.
-    u64 *nsum = b->d_small64 + 11;
-    HIP_TRY(c, hipMemsetAsync(nsum, 0, sizeof(u64), s));
-    if (N) LAUNCH(sum_bytes_k, 1024, 256, 0, s, b->namelen.as<u8>(), N, reinterpret_cast<unsigned long long *>(nsum));
-    u64 h[12];
-    { int rc = read_u64(b, b->d_small64, h, 12, s); if (rc) return rc; }
-    b->out_reads_bytes[0] = h[2];
-    b->out_names_bytes = N + h[11];
-    ENSURE(b, b->out_reads[0], h[2] + 64);
-    ENSURE(b, b->out_names, b->out_names_bytes + 64);
-    ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
-    ENSURE(b, b->outlen, N + 64);
-    ENSURE(b, b->cell_sorted, 16 * (N + 4));
-    ENSURE(b, b->qs[0], (size_t)b->L[0] * N + 64);
-    ENSURE(b, b->bucket_name_bytes, sizeof(u64) * (nb1 + 1));
-    b->names_from_sorted_cells = true;
-    if (N) {
-      EmitArgs a;
-      a.nrec = N; a.perm = b->perm; a.bucket = b->bucket.as<u32>(); a.end = b->endv.as<u16>();
-      a.frow = b->q[0].as<u8>(); a.stride = (int)b->qstride[0]; a.cell_off = b->row_cell_off;
-      a.packed = a.frow + b->row_cell_off + 16; a.pwords = (int)b->row_pwords;
-      a.L = b->L[0]; a.sz_meta = b->sz_meta; a.bucket_level = c->d_bucket_level;
-      a.bucket_pattern = c->d_bucket_pattern; a.bucket_first = b->bucket_first.as<u64>(); a.bucket_off = b->bucket_off.as<u64>();
-      a.counts = counts; a.out = b->out_reads[0].as<u8>();
-      a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
-      a.key_end_bits = b->key_end_bits;
-      a.qunits = ((u32)b->L[0] + 15) / 16;
-      a.qmagic = ((1ull << 32) + a.qunits - 1) / a.qunits;
-      a.cells_sorted = b->cell_sorted.as<u8>(); a.outlen = b->outlen.as<u8>(); a.qs = b->qs[0].as<u8>();
-      LAUNCH(emit_reads_k<true>, cdiv(N, 256), 256, 0, s, a);
-    }
-    exclusive_scan<u64>(NameLenSeq{b->outlen.as<u8>()}, N, StoreTo<u64>{b->name_off.as<u64>()}, ws, b->d_small64 + 3, s);
-    LAUNCH(bucket_name_bytes_k, cdiv(nb1, 256), 256, 0, s, nb1, b->bucket_first.as<u64>(), counts, b->name_off.as<u64>(), b->d_small64 + 3, N,
-           b->bucket_name_bytes.as<u64>());
-    if (N)
-      LAUNCH(emit_names_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->cell_sorted.as<u8>(), b->name_in_off.as<u64>(),
-             b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
-    return SCALCE_OK;
-  }
   if (b->p.use_names) {
     ENSURE(b, b->name_off, sizeof(u64) * (N + 2));
     ENSURE(b, b->outlen, N + 64);
@@ -1782,7 +1730,28 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.counts = counts; a.out = b->out_reads[0].as<u8>();
     a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
     a.key_end_bits = b->key_end_bits;
-    a.pwords = 0; a.frow = nullptr; a.cells_sorted = a.outlen = a.qs = nullptr; a.cell_off = a.qunits = 0; a.qmagic = 0;
+    a.pwords = 0; a.frow = nullptr; a.cells_sorted = a.outlen = a.qs = nullptr; a.cell_off = a.qunits = 0; a.qmagic = a.rmagic = 0;
+    if (b->fused) {
+      // One row per read: the workgroup that assembles a record's bases also moves its q' into the reordered stream -- both
+      // lie in ONE row of the ingest stage's making (128 bytes = one aligned line at 100 bp), fetched whole into LDS with every
+      // thread's loads in flight at once.  One random line per record instead of three (packed row + q' row for
+      // gather_rows_k, each paying its own).
+      ENSURE(b, b->qs[0], (size_t)b->L[0] * N + 64);
+      a.frow = b->q[0].as<u8>(); a.stride = (int)b->qstride[0]; a.cell_off = b->row_cell_off; a.pwords = (int)b->row_pwords;
+      a.packed = a.frow + b->row_cell_off;
+      a.qunits = ((u32)b->L[0] + 15) / 16;
+      a.qmagic = ((1ull << 32) + a.qunits - 1) / a.qunits;
+      a.rmagic = ((1ull << 32) + (b->qstride[0] >> 4) - 1) / (b->qstride[0] >> 4);
+      a.qs = b->qs[0].as<u8>();
+      if (const char *e = getenv("SCALCE_EMIT_ABLATE")) {  // timing experiments only: the output is wrong
+        if (strchr(e, 'q')) a.qs = nullptr;
+        if (strchr(e, 'p')) a.pwords = 0;
+      }
+      const size_t rows_lds = 256 * (size_t)b->qstride[0];
+      if (rows_lds > 32 * 1024)
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(emit_reads_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+      LAUNCH(emit_reads_k<true>, cdiv(N, 256), 256, rows_lds, s, a);
+    } else
     LAUNCH(emit_reads_k<false>, cdiv(N, 256), 256, 0, s, a);
     if (b->p.use_names && b->names_from_sorted_cells)
       LAUNCH(emit_names_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->cell_sorted.as<u8>(), b->name_in_off.as<u64>(),
@@ -1792,8 +1761,9 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
              b->names_in.as<u8>(), b->name_off.as<u64>(), b->out_names.as<u8>());
     for (int m = 0; m < b->nm; m++) {
       const u32 w = (u32)b->L[m];
+      if (m == 0 && b->fused) continue;  // (emit_reads_k<true> has done it)
       ENSURE(b, b->qs[m], (size_t)w * N + 64);
-      LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)w, w, b->qs[m].as<u8>());
+      LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)b->qstride[m], w, b->qs[m].as<u8>());
       if (b->lean) {
         // q' in input order is dead once its reordered copy exists.  Mate 1's buffer becomes mate 2's reordered stream (an
         // allocation and a release of tens of GB each cost a good part of a second), the last one is released.
