@@ -2659,7 +2659,20 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
     if (fast) {
       int wpb = nblk <= 512 ? 2 : nblk <= 1024 ? 4 : nblk <= 2048 ? 8 : 16;  // 16 = four chains per SIMD: a chain issues one instruction in five cycles
       if (const char *e = getenv("SCALCE_AC_DECODE_WPB")) wpb = atoi(e);     // (tests: the wide workgroups on a few blocks)
-      if (wpb == 2) LAUNCH(ac_decode_fast_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+      // no context total above 2^29 (as for the encoder's plain step): the kernel that carries (lo, range, code - lo)
+      u64 max_total = 0;
+      for (u32 ctx = 0; ctx < 6400; ctx++) {
+        u64 t = 0;
+        for (u32 sy = 0; sy < AC_D; sy++) t += table_host[(size_t)ctx * AC_D + sy];
+        max_total = std::max(max_total, t);
+      }
+      const bool lean = max_total <= (1ull << 29) && !getenv("SCALCE_AC_DECODE_NO_LEAN");
+      if (lean) {
+        if (wpb == 2) LAUNCH(ac_decode_lean_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+        else if (wpb == 4) LAUNCH(ac_decode_lean_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
+        else if (wpb == 16) LAUNCH(ac_decode_lean_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
+        else LAUNCH(ac_decode_lean_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
+      } else if (wpb == 2) LAUNCH(ac_decode_fast_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
       else if (wpb == 4) LAUNCH(ac_decode_fast_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
       else if (wpb == 16) LAUNCH(ac_decode_fast_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
       else LAUNCH(ac_decode_fast_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
