@@ -305,6 +305,124 @@ __global__ __launch_bounds__(TOK_THREADS) void tie_candidates_k(TieArgs a) {
   a.tie_ncand[t] = k;
 }
 
+// ---- core tables of realistic size: occurrences found from their STARTS, not by walking the automaton (round 4) ----------
+// The walk above costs one dependent transition per base, and with a million cores of 12-32 bases (9.9 M states, 158 MB of
+// rows) four of five of them are read from L2 or HBM: 2.3 ns per read against 0.32 with the 15 600-core table.  But the
+// automaton is not the contract -- what aho_search (reads.cpp:413-429) reports at position i is the LONGEST CORE ENDING
+// THERE, and its result only depends on the occurrences of the longest cores found anywhere in the read, in the order of
+// their end positions.  Every core is at least K = min(shortest core, 12) bases long, so every occurrence starts with a
+// K-mer that is a depth-K node of the trie:
+//   * a bitmap over all 4^K K-mers (2 MB at K = 12: it lives in an XCD's L2) says whether a position can start a core --
+//     one probe per position, independent of every other probe (no chain of dependent loads);
+//   * where it can (6 % of the positions with a million cores), the node is idK + rank(K-mer) -- nodes of one depth are
+//     numbered in lexicographic order -- and the walk goes DOWN the trie from there along the read (a transition is a
+//     trie edge iff its bit in `child` is set), noting every node at which a core ends (outinfo's level == the depth).
+// Occurrences come out by start position; for cores of one length that is the order of their end positions, and only
+// the occurrences of the longest length seen matter at the end: the first of them (bucket, last base), how many, whether
+// two different cores are among them -- exactly what tokenize_k reports.  CANDS: the second pass over the tie reads
+// (tie_candidates_k's contract: distinct cores of the longest length in order of first appearance).
+struct AnchorArgs {
+  const u32 *next;       // 4 x u32 per state (bit 31: the target has an output)
+  const u32 *outinfo;
+  const u64 *bits;       // 4^K bits
+  const u32 *rank;       // per 64-bit word: set bits in front of it
+  const u32 *child;      // bit 4 s + c: transition c of state s is a trie edge
+  u32 K, idK;
+  const u8 *packed;
+  u64 nrec;
+  int L, stride;
+  u32 root_bucket;
+  u32 *tok_bucket, *tok_pos;
+  // CANDS
+  u32 ntie;
+  const u32 *tie_read, *tie_off, *bucket_level;
+  u32 *cand_bucket, *cand_pos, *tie_ncand;
+};
+template <bool CANDS>
+__global__ __launch_bounds__(256) void tokenize_anchor_k(AnchorArgs a) {
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (CANDS ? (u64)a.ntie : a.nrec)) return;
+  const u64 r = CANDS ? (u64)a.tie_read[t] : t;
+  const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
+  const u8 *rowb = reinterpret_cast<const u8 *>(row);
+  const u32 K = a.K, L = (u32)a.L;
+  const u32 kmask = K >= 16 ? 0xFFFFFFFFu : ((1u << (2 * K)) - 1u);
+  u32 best_lv = 0, best_b = a.root_bucket, best_pos = 0, hits = 0, tie = 0;
+  u32 lvmax = 0, off = 0, ncand = 0;
+  if (CANDS) { lvmax = a.bucket_level[a.tok_bucket[r]]; off = a.tie_off[t]; }
+  auto occurrence = [&](u32 lv, u32 b, u32 end) {
+    if (CANDS) {
+      if (lv != lvmax) return;
+      bool seen = false;
+      for (u32 j = 0; j < ncand; j++) seen |= (a.cand_bucket[off + j] == b);
+      if (!seen) { a.cand_bucket[off + ncand] = b; a.cand_pos[off + ncand] = end; ncand++; }
+    } else if (lv > best_lv) {
+      best_lv = lv; best_b = b; best_pos = end; hits = 1; tie = 0;
+    } else if (lv == best_lv) {
+      hits++;
+      if (b != best_b) tie = 1;
+    }
+  };
+  // the K-mer that ends at base i, from the row's bit string (2 bits per base, first base first: words byte-swapped)
+  auto kmer_at = [&](u32 i) -> u32 {
+    const u32 bitpos = 2 * (i + 1 - K), wi = bitpos >> 5, sh = bitpos & 31u;
+    const u64 two = ((u64)__builtin_bswap32(row[wi]) << 32) | __builtin_bswap32(row[wi + 1]);  // (rows are padded by a spare word)
+    return (u32)(two >> (64 - sh - 2 * K)) & kmask;
+  };
+  u32 code = 0;
+  const u32 nw = (L + 15) >> 4;
+  for (u32 w = 0; w < nw; w++) {
+    const u32 word = row[w];  // byte j of the row = bases 4j..4j+3, first base in bits 7-6
+    const u32 cnt = (L - 16 * w) < 16 ? (L - 16 * w) : 16;
+    // sixteen probes of the bitmap, all issued before any is looked at (a probe behind a branch waits for the one before)
+    u32 hitmask = 0;
+    {
+      u64 wd[16];
+      u32 sh[16];
+#pragma unroll
+      for (u32 k = 0; k < 16; k++) {
+        const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
+        code = ((code << 2) | c) & kmask;
+        const bool on = k < cnt && 16 * w + k + 1 >= K;
+        wd[k] = a.bits[on ? code >> 6 : 0u];
+        sh[k] = on ? (code & 63u) : 64u;
+      }
+#pragma unroll
+      for (u32 k = 0; k < 16; k++) hitmask |= (sh[k] < 64u ? (u32)((wd[k] >> sh[k]) & 1ull) : 0u) << k;
+    }
+    while (hitmask) {
+      const u32 k = (u32)__builtin_ctz(hitmask);
+      hitmask &= hitmask - 1;
+      const u32 i = 16 * w + k;             // a K-mer that is a trie node ends here
+      const u32 kc = kmer_at(i);
+      const u64 wdk = a.bits[kc >> 6];
+      // a core may start at p = i + 1 - K: down the trie along the read
+      u32 s = a.idK + a.rank[kc >> 6] + (u32)__popcll(wdk & ((1ull << (kc & 63u)) - 1ull));
+      u32 d = K, pos = i;                   // depth of s, index of its last base
+      bool has_out = true;                  // (the anchor's own output is not known from a transition word: look)
+      for (;;) {
+        if (has_out) {
+          const u32 info = a.outinfo[s];
+          if (info != kNoOutD && (info >> kLevelShiftD) == d) occurrence(d, info & kBucketMaskD, pos);
+        }
+        if (pos + 1 >= L) break;
+        const u32 cn = (rowb[(pos + 1) >> 2] >> (6 - 2 * ((pos + 1) & 3))) & 3u;
+        const u32 e = 4 * s + cn;
+        if (!((a.child[e >> 5] >> (e & 31u)) & 1u)) break;
+        const u32 tr = a.next[e];
+        s = tr & 0x7FFFFFFFu;
+        has_out = (tr >> 31) != 0;
+        d++; pos++;
+      }
+    }
+  }
+  if (CANDS) a.tie_ncand[t] = ncand;
+  else {
+    a.tok_bucket[r] = best_b;
+    a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
+  }
+}
+
 // The second walk in the shape of tokenize_kmer_pipe_k: straight-line code per base, the output word of the state reached
 // looked at a base later.  tie_candidates_k<false, true> walks the same reads with a wait per lookup and 24 waves per CU:
 // 1.25 us per base and wave, 2.9 ms for the 9 M tie reads of a 50 M-read shard.

@@ -33,6 +33,10 @@ struct scalce_ctx {
   u32 id8_first = 0;
   int tok_lds_states = 0;
   u32 *d_simd_load = nullptr;  // per (XCC, SE, SH, CU, SIMD): coder waves resident there (ac_encode_k's role choice)
+  // anchor tables of tokenize_anchor_k (core tables too large for the k-mer tables in LDS), or null
+  u64 *d_anchor_bits = nullptr;
+  u32 *d_anchor_rank = nullptr, *d_child_bits = nullptr;
+  u32 anchor_K = 0, anchor_idK = 0;
 };
 
 static void set_err(scalce_ctx *c, const char *fmt, ...) {
@@ -82,6 +86,10 @@ static void free_tables(scalce_ctx *c) {
   if (c->d_bucket_level) hipFree(c->d_bucket_level);
   if (c->d_kmer) hipFree(c->d_kmer);
   c->d_kmer = nullptr;
+  if (c->d_anchor_bits) hipFree(c->d_anchor_bits);
+  if (c->d_anchor_rank) hipFree(c->d_anchor_rank);
+  if (c->d_child_bits) hipFree(c->d_child_bits);
+  c->d_anchor_bits = nullptr; c->d_anchor_rank = nullptr; c->d_child_bits = nullptr; c->anchor_K = 0;
   c->d_next = nullptr; c->d_outinfo = nullptr; c->d_bucket_pattern = nullptr; c->d_bucket_level = nullptr;
 }
 
@@ -170,6 +178,51 @@ static int upload_tables(scalce_ctx *c) {
       HIP_TRY(c, hipMemcpy(c->d_kmer, tab.data(), sizeof(u32) * KMER_WORDS, hipMemcpyHostToDevice));
       c->id8_first = id8;
       c->kmer_t7_out = t7_out;
+    }
+    // Anchor tables (tokenize_anchor_k): a table whose shallow part does not fit the k-mer tables above -- thousands of
+    // 8-mers are fine, a million cores of 12-32 bases are not -- is searched from the occurrences' starts instead of by
+    // walking the automaton.  K = min(shortest core, 12); SCALCE_TOK_ANCHOR=1 forces it on any table with cores of 6 bases
+    // and more (tests), SCALCE_TOK_NO_ANCHOR=1 keeps the walk.
+    // (the k-mer tables only shortcut transitions out of states of depth <= 7: with 400 000 states and more most of the walk
+    //  is deeper than that, whether the tables could be built or not)
+    const bool want = (getenv("SCALCE_TOK_ANCHOR") != nullptr || ns > 400000u) && !getenv("SCALCE_TOK_NO_ANCHOR");
+    if (want && order.size() == ns && A.min_level >= 6 && A.n_buckets > 0) {
+      const u32 K = (u32)std::min(A.min_level, 12);
+      const size_t nbits = (size_t)1 << (2 * K), nwords = (nbits + 63) / 64;
+      std::vector<u64> bits(nwords, 0);
+      u32 idK = ns;
+      bool lex = true;
+      u32 prev = 0;
+      for (u32 st = 0; st < ns; st++) {
+        if (depth[st] != (int)K) continue;
+        if (idK == ns) idK = st;
+        else if (code[st] <= prev) lex = false;      // (nodes of one depth are numbered in lexicographic order: BFS over ordered children)
+        prev = code[st];
+        bits[code[st] >> 6] |= 1ull << (code[st] & 63u);
+      }
+      // ids of depth K must be one contiguous, sorted range
+      u32 nK = 0;
+      for (u32 st = 0; st < ns; st++) nK += depth[st] == (int)K;
+      for (u32 st = idK; st < idK + nK && lex; st++) if (depth[st] != (int)K) lex = false;
+      if (lex && idK < ns) {
+        std::vector<u32> rank(nwords);
+        u32 run = 0;
+        for (size_t w = 0; w < nwords; w++) { rank[w] = run; run += (u32)__builtin_popcountll(bits[w]); }
+        std::vector<u32> child(((size_t)ns * 4 + 31) / 32, 0);
+        for (u32 st = 0; st < ns; st++)
+          for (u32 ch = 0; ch < 4; ch++) {
+            const u32 t = A.next[(size_t)st * 4 + ch];
+            if (depth[t] == depth[st] + 1) child[((size_t)st * 4 + ch) >> 5] |= 1u << (((size_t)st * 4 + ch) & 31);
+          }
+        HIP_TRY(c, hipMalloc(&c->d_anchor_bits, sizeof(u64) * nwords));
+        HIP_TRY(c, hipMalloc(&c->d_anchor_rank, sizeof(u32) * nwords));
+        HIP_TRY(c, hipMalloc(&c->d_child_bits, sizeof(u32) * child.size()));
+        HIP_TRY(c, hipMemcpy(c->d_anchor_bits, bits.data(), sizeof(u64) * nwords, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_anchor_rank, rank.data(), sizeof(u32) * nwords, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_child_bits, child.data(), sizeof(u32) * child.size(), hipMemcpyHostToDevice));
+        c->anchor_K = K;
+        c->anchor_idK = idK;
+      }
     }
   }
   // stage as many leading (shallow) states as fit in 60 KiB of LDS: 2 workgroups per CU stay resident
@@ -998,6 +1051,15 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
   return SCALCE_OK;
 }
 
+// the tokenizer walks of a core table too large for the k-mer tables in LDS: occurrences from their starts (tokenize_anchor_k)
+static void anchor_args(const scalce_ctx *c, const scalce_batch *b, const u8 *packed, u64 nrec, AnchorArgs &a) {
+  memset(&a, 0, sizeof a);
+  a.next = reinterpret_cast<const u32 *>(c->d_next); a.outinfo = c->d_outinfo;
+  a.bits = c->d_anchor_bits; a.rank = c->d_anchor_rank; a.child = c->d_child_bits; a.K = c->anchor_K; a.idK = c->anchor_idK;
+  a.packed = packed; a.nrec = nrec; a.L = b->L[0]; a.stride = b->stride[0]; a.root_bucket = (u32)c->A.n_buckets;
+  a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
+}
+
 // ---- stage 2: tokenize ------------------------------------------------------------------------------
 extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   if (!b || !b->ingested[0]) return SCALCE_ERR_ARG;
@@ -1043,7 +1105,11 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     const size_t sh = (size_t)a.lds_states * 20;
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    if (c->d_kmer && tok_pipelined()) {
+    if (c->anchor_K) {
+      AnchorArgs g;
+      anchor_args(c, b, packed0, N, g);
+      LAUNCH(tokenize_anchor_k<false>, cdiv(N, 256), 256, 0, s, g);
+    } else if (c->d_kmer && tok_pipelined()) {
       if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
       else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
     }
@@ -1082,7 +1148,13 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     a.tie_ncand = b->tie_ncand.as<u32>();
     a.lds_states = (u32)c->tok_lds_states;
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    if (c->d_kmer && tok_pipelined()) {
+    if (c->anchor_K) {
+      AnchorArgs g;
+      anchor_args(c, b, packed0, N, g);
+      g.ntie = ntie; g.tie_read = a.tie_read; g.tie_off = a.tie_off; g.bucket_level = a.bucket_level;
+      g.cand_bucket = a.cand_bucket; g.cand_pos = a.cand_pos; g.tie_ncand = a.tie_ncand;
+      LAUNCH(tokenize_anchor_k<true>, cdiv(ntie, 256), 256, 0, s, g);
+    } else if (c->d_kmer && tok_pipelined()) {
       if (c->kmer_t7_out) LAUNCH(tie_candidates_pipe_k<true>, cdiv(ntie, TOKP_THREADS), TOKP_THREADS, 0, s, a);
       else LAUNCH(tie_candidates_pipe_k<false>, cdiv(ntie, TOKP_THREADS), TOKP_THREADS, 0, s, a);
     } else if (c->d_kmer) LAUNCH((tie_candidates_k<false, true>), cdiv(ntie, TOK_THREADS), TOK_THREADS, sizeof(u32) * KMER_WORDS, s, a);
@@ -1475,7 +1547,11 @@ extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint6
     a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
     a.kmer = c->d_kmer; a.id8_first = c->id8_first;
     const size_t sh = (size_t)a.lds_states * 20;
-    if (c->d_kmer && tok_pipelined()) {
+    if (c->anchor_K) {
+      AnchorArgs g;
+      anchor_args(c, b, a.packed, N, g);
+      LAUNCH(tokenize_anchor_k<false>, cdiv(N, 256), 256, 0, s, g);
+    } else if (c->d_kmer && tok_pipelined()) {
       if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
       else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
     }
