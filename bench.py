@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--stage-times", action="store_true", help="also print per-stage HIP-event times to stderr")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> archive leg (the `scalce` binary on the same shard written to a file)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the last timed shard (device decode + record digest)")
+    ap.add_argument("--no-table-scale", action="store_true", help="skip the tokenizer leg on a core table of a million cores")
     ap.add_argument("--shared-input", action="store_true",
                     help="every shard in flight reads the SAME text tensor (rounds 1-3; more shards fit).  Default: one distinct text per shard in flight")
     ap.add_argument("--ref-full-shard", action="store_true",
@@ -396,6 +397,13 @@ def main():
         except Exception as ex:  # noqa: BLE001 - a side leg must not take the measured line with it
             e2e = {"error": repr(ex)[:300]}
 
+    table_scale = None
+    if rank == 0 and world == 1 and not args.no_table_scale and not args.no_e2e:
+        try:
+            table_scale = table_scale_leg(dev)
+        except Exception as ex:  # noqa: BLE001
+            table_scale = {"error": repr(ex)[:300]}
+
     # Counter figures come from rocprofv3 summaries of THIS build kept under profiles/ (tools/profile_round.sh <tag>,
     # tools/pmc_sq.sh <tag>; SCALCE_PROFILE_TAG names the tag): HBM bytes from --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes (KB; FETCH_SIZE doubled: gfx950 reports half of a streaming read, MI355X_MICROARCH.md "HBM"), instructions
@@ -403,7 +411,7 @@ def main():
     bpw_env = int(os.environ.get("SCALCE_AC_BLOCKS_PER_WG", "0") or 0)
     nblk_launch = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
     kname = "ac_encode_k" if G == 1 else ("ac_encode_rows_k" if bpw_env in (4, 8) or (bpw_env == 0 and nblk_launch < 900) else "ac_encode_lanes_k")
-    tag = os.environ.get("SCALCE_PROFILE_TAG", "r03_final")
+    tag = os.environ.get("SCALCE_PROFILE_TAG", "r04_final")
     pmc = os.path.join(ROOT, "profiles", f"{tag}_bench50m_pmc_fetch_write.json")
     sqf = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")
     k_traffic, step_traffic, traffic_src, instr_per_symbol, issue_src = None, None, None, None, None
@@ -487,6 +495,7 @@ def main():
             "cpu_baseline": cpu,
             "decode": (dict(decode, cpu_baseline=(cpu or {}).get("decompress")) if decode else None),
             "e2e": e2e,
+            "table_scale": table_scale,
             "note": "value = device-resident steady state with %d shards (independent jobs of the configs[1] size, each with its own "
                     "input text) in flight; value_single_job = one such job alone, input already in HBM; decode = the inverse path on "
                     "the last shard; e2e = the scalce binary, file in, archive out" % D,
@@ -562,6 +571,37 @@ def end_to_end(text, nbytes):
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def table_scale_leg(dev, reads=2_000_000, L=100):
+    """The tokenize stage against a core table of realistic size (the headline's table has 15 600 cores; the
+    reference's loader admits five million, reads.cpp:336): 1 M cores of 12-32 bases (tests/bigtable.py, 9.9 M automaton
+    states), reads with planted cores.  Stage time by HIP events, second run (tokens are checked against the oracle's trie
+    walk by tests/test_gpu_scale.py::test_million_core_table, not here)."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bigtable
+    from scalce_amd import host, synth
+    blob, vals = bigtable.build()
+    ctx = host.Context(dev.index or 0, patterns_bin=blob)
+    bases = bigtable.reads_with_cores(reads, L, vals)
+    quals = np.full((reads, L), ord("I"), dtype=np.uint8)
+    fq = synth.fastq_bytes_fast(bases, quals)
+    t = torch.frombuffer(bytearray(fq), dtype=torch.uint8).to(dev)
+    b = host.Batch(ctx, L, reads + 8, len(fq) + 64)
+    for _ in range(2):
+        b.stage_reset(True)
+        b.front(t.data_ptr(), len(fq))
+        torch.cuda.synchronize()
+    ms = b.stage_ms()["tokenize"][0]
+    st = b.stats()
+    b.close()
+    return {"cores": int(sum(len(v) for _, v in vals)), "core_lengths": "12-32", "automaton_states": int(ctx.n_states), "reads": reads,
+            "tokenize_stage_ms": round(ms, 2), "ns_per_read": round(ms * 1e6 / reads, 3), "ms_per_50M_reads": round(ms * 50e6 / reads, 1),
+            "tie_reads": st["tie_reads"],
+            "what": "scalce_batch_tokenize (both walks + the exact tie-break) on a 1 M-core table; occurrences are found from their starts "
+                    "(tokenize_anchor_k: K-mer bitmap, then down the trie), not by walking the automaton"}
 
 
 def ref_full_shard(text, nbytes):
