@@ -161,9 +161,10 @@ def main():
             D = max(fit, 1)
             print("bench: %.0f GB of HBM free: %d shards in flight, %d per coder launch" % (free_b / 1e9, D, G), file=sys.stderr)
         elif fit < D:
-            if auto_group and not sharded and fit < 14:
-                # fewer than fourteen fit: three shards per launch on three coder streams keep nine of them in the coder and the
-                # rest in front of it (tools/pipe_shapes_r4.sh: 91 ms per shard at 3 / 11 / 3 against 103 at 4 / 11 / 2)
+            if auto_group and not sharded and fit < 12:
+                # fewer than twelve fit: three shards per launch keep nine of them in the coder and the rest in front of it
+                # (tools/pipe_shapes_r4.sh: 91 ms per shard at 3 / 11 / 3 against 103 at 4 / 11 / 2; with twelve, four per
+                # launch on three streams and three per launch on four measure the same, 88.7 / 88.1)
                 G = 3
             print("bench: %.0f GB of HBM free: %d shards in flight instead of %d, %d per coder launch" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D, G), file=sys.stderr)
             D = fit

@@ -267,7 +267,7 @@ struct EmitArgs {
   int pwords;
   const u8 *frow;
   u32 cell_off, qunits;     // qunits = ceil(L / 16): 16-byte units of a row's q'
-  u64 qmagic, rmagic;       // ceil(2^32 / qunits), ceil(2^32 / (stride / 16))
+  u64 qmagic, rmagic, lmagic;  // ceil(2^32 / qunits), ceil(2^32 / (stride / 16)), ceil(2^32 / L)
   u8 *cells_sorted, *outlen, *qs;
 };
 // The records of a workgroup's 256 positions are contiguous in the output (bucket headers included), 27 bytes each at
@@ -378,24 +378,25 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     if (a.sz_meta == 2) dst[j + 1] = (u8)(e >> 8);
   }
   if (FUSED && a.qs) {
-    // q' of the workgroup's records: units of 16 bytes dealt to the threads in order -- consecutive threads read consecutive
-    // units of a row (which the loads above have just brought in) and write consecutive bytes of the stream
+    // q' of the workgroup's records: a contiguous, 16-byte aligned piece of the stream (256 x L bytes, L % 4 == 0).  A
+    // thread produces aligned 16-byte chunks of it, every word from where it lies in the rows in LDS (copied record by
+    // record in units of 16 bytes at 4-byte boundaries -- L = 100 -- the stores straddled sectors: WRITE_SIZE counted the
+    // stream twice).
     const u64 k0 = (u64)blockIdx.x * blockDim.x;
     const u32 nlive = (u32)(a.nrec - k0 < 256 ? a.nrec - k0 : 256);
-    const u32 units = nlive * a.qunits, L = (u32)a.L;
-    typedef u32 u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const u32 L = (u32)a.L, total = nlive * L, rsb = (u32)a.stride;
+    const u8 *lrows = reinterpret_cast<const u8 *>(s_rows);
     u8 *qdst = a.qs + k0 * (u64)L;
-    for (u32 u = threadIdx.x; u < units; u += 256) {
-      const u32 rec = (u32)(((u64)u * a.qmagic) >> 32), j = u - rec * a.qunits;
-      const uint4 sv = s_rows[rec * rs16 + j];
-      u8 *dst = qdst + rec * L + 16 * j;
-      if (16 * j + 16 <= L) {
-        u32x4u o; o.x = sv.x; o.y = sv.y; o.z = sv.z; o.w = sv.w;
-        *reinterpret_cast<u32x4u *>(dst) = o;
-      } else {
-        const u32 w4[4] = {sv.x, sv.y, sv.z, sv.w};
-        for (u32 x = 16 * j; x < L; x += 4) *reinterpret_cast<u32 *>(dst + (x - 16 * j)) = w4[(x - 16 * j) >> 2];
+    for (u32 c = threadIdx.x * 16u; c < total; c += 256u * 16u) {
+      u32 wv[4];
+#pragma unroll
+      for (u32 x = 0; x < 4; x++) {
+        const u32 o = c + 4 * x;
+        const u32 rec = (u32)(((u64)o * a.lmagic) >> 32), col = o - rec * L;   // o / L, o % L
+        wv[x] = o < total ? *reinterpret_cast<const u32 *>(lrows + rec * rsb + col) : 0u;
       }
+      if (c + 16 <= total) *reinterpret_cast<uint4 *>(qdst + c) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      else for (u32 x = 0; c + 4 * x < total; x++) *reinterpret_cast<u32 *>(qdst + c + 4 * x) = wv[x];
     }
   }
   if (!staged) return;

@@ -1806,7 +1806,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     a.counts = counts; a.out = b->out_reads[0].as<u8>();
     a.keys = b->sorted_keys; a.key_bucket_shift = b->key_bucket_shift; a.key_bucket_mask = b->key_bucket_mask;
     a.key_end_bits = b->key_end_bits;
-    a.pwords = 0; a.frow = nullptr; a.cells_sorted = a.outlen = a.qs = nullptr; a.cell_off = a.qunits = 0; a.qmagic = a.rmagic = 0;
+    a.pwords = 0; a.frow = nullptr; a.cells_sorted = a.outlen = a.qs = nullptr; a.cell_off = a.qunits = 0; a.qmagic = a.rmagic = a.lmagic = 0;
     if (b->fused) {
       // One row per read: the workgroup that assembles a record's bases also moves its q' into the reordered stream -- both
       // lie in ONE row of the ingest stage's making (128 bytes = one aligned line at 100 bp), fetched whole into LDS with every
@@ -1818,6 +1818,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
       a.qunits = ((u32)b->L[0] + 15) / 16;
       a.qmagic = ((1ull << 32) + a.qunits - 1) / a.qunits;
       a.rmagic = ((1ull << 32) + (b->qstride[0] >> 4) - 1) / (b->qstride[0] >> 4);
+      a.lmagic = ((1ull << 32) + (u32)b->L[0] - 1) / (u32)b->L[0];
       a.qs = b->qs[0].as<u8>();
       if (const char *e = getenv("SCALCE_EMIT_ABLATE")) {  // timing experiments only: the output is wrong
         if (strchr(e, 'q')) a.qs = nullptr;
