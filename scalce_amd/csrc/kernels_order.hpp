@@ -310,21 +310,20 @@ __global__ __launch_bounds__(256) void emit_reads_k(EmitArgs a) {
     const u64 k0 = (u64)blockIdx.x * blockDim.x;
     const u32 nlive = (u32)(a.nrec - k0 < 256 ? a.nrec - k0 : 256);
     const u32 units = nlive * rs16;
-    constexpr int MAXU = 16;  // rows of up to 256 bytes
-    uint4 v[MAXU];
-#pragma unroll
-    for (int i = 0; i < MAXU; i++) {
-      const u32 u = (u32)i * 256u + threadIdx.x;
+    // straight into LDS (global_load_lds_dwordx4: lane l of a wave's instruction lands at the wave's base + 16 l, which is
+    // unit u's place), no register in between.  (Through a register array -- loads first, LDS stores behind them -- the
+    // compiler put the array in SCRATCH: 272 bytes per thread, 6.4 GB written to HBM and read back per 50 M-read shard;
+    // found by WRITE_SIZE, tools/emit_write_probe.sh.)
+    const u32 wave_base = (threadIdx.x & ~63u);
+    for (u32 i = 0; i * 256u < units; i++) {
+      const u32 u = i * 256u + threadIdx.x;
       if (u < units) {
         const u32 rec = (u32)(((u64)u * a.rmagic) >> 32), j = u - rec * rs16;
-        v[i] = *reinterpret_cast<const uint4 *>(a.frow + (u64)s_row[rec] * a.stride + 16 * j);
+        const u8 *src = a.frow + (u64)s_row[rec] * a.stride + 16 * j;
+        __builtin_amdgcn_global_load_lds((const SCALCE_GLOBAL void *)src, (__attribute__((address_space(3))) void *)(s_rows + i * 256u + wave_base), 16, 0, 0);
       }
     }
-#pragma unroll
-    for (int i = 0; i < MAXU; i++) {
-      const u32 u = (u32)i * 256u + threadIdx.x;
-      if (u < units) s_rows[u] = v[i];
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the rows are in LDS before the barrier below lets anyone read them)
   }
   if (threadIdx.x == 0) wg_begin = my_begin;
   if (live && (threadIdx.x == blockDim.x - 1 || k + 1 == a.nrec)) wg_end = my_end;
