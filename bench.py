@@ -161,11 +161,12 @@ def main():
             D = max(fit, 1)
             print("bench: %.0f GB of HBM free: %d shards in flight, %d per coder launch" % (free_b / 1e9, D, G), file=sys.stderr)
         elif fit < D:
-            if auto_group and not sharded and fit < 12:
-                # fewer than twelve fit: three shards per launch keep nine of them in the coder and the rest in front of it
-                # (tools/pipe_shapes_r4.sh: 91 ms per shard at 3 / 11 / 3 against 103 at 4 / 11 / 2; with twelve, four per
-                # launch on three streams and three per launch on four measure the same, 88.7 / 88.1)
-                G = 3
+            if auto_group and not sharded:
+                # A coder launch takes ~0.6 s whatever it holds: what counts is that every group of slots has a stream of its
+                # own.  With twelve slots, six shards per launch on two streams, four on three and three on four measure the
+                # same at 20 steps (86.5 / 86.4 / 86.6 ms per shard, tools/pipe_shapes_r4.sh): six it is -- the fewest, largest
+                # launches of the dominant kernel.  Fewer than twelve: three per launch (91 ms at 3 / 11 / 3 against 103 at 4 / 11 / 2).
+                G = 6 if fit >= 12 else 3
             print("bench: %.0f GB of HBM free: %d shards in flight instead of %d, %d per coder launch" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D, G), file=sys.stderr)
             D = fit
     if G > 1 and not (sharded and args.inflight is None):
@@ -221,8 +222,8 @@ def main():
     DF = D // F
     # as many coder streams as groups fit the slots (every launch takes ~0.6 s whatever it holds: with a stream per group in
     # rotation no group waits for another's launch to end; 3 / 4 / 12 measured 88.1 ms per shard against 90.0 at 3 / 3 / 12)
-    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(6, DF // G)) if (G > 1 and DF >= 3 * G and not sharded) else
-                                         "3" if (G > 1 and DF >= 3 * G) else "2" if (G > 1 and DF >= 2 * G + 2 and not sharded) else "1"))
+    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(6, DF // G)) if (G > 1 and DF >= 2 * G and not sharded) else
+                                         "3" if (G > 1 and DF >= 3 * G) else "1"))
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
                            coder_streams=n_coder_streams)
              for f in range(F)]
@@ -267,7 +268,7 @@ def main():
                     state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
                                                         stream=pipe.front.cuda_stream, result=state.get(slot))
             mark(f"shard {j}: front done")
-            pipe.submit(slot, tag=j, flush=j + 1 == k)
+            pipe.submit(slot, tag=j, flush=j + 1 == k, remaining=k - j - 1)
         pipe.drain()
 
     torch.cuda.synchronize()  # the synthetic shard was generated on the default stream

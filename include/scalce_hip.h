@@ -216,7 +216,8 @@ int scalce_batch_entropy_begin_group(scalce_batch **batches, int n, void *prep_s
 /* The same for the LAST launch of a run (last == 1: nothing will be queued behind it): picks the coder kernel by how soon
  * the launch is done instead of by how few CUs it holds beside the next shards' front stages.  last == 2: a launch of one
  * or two shards at the START of a run, with more shards on their way: the kernel that holds the fewest CUs whatever the
- * size of the launch.  Same bytes. */
+ * size of the launch.  last == 3: one of the last launches of a run, a front stage or two still to come: a kernel between
+ * the two (eight blocks per chain wave for up to 1024 blocks).  Same bytes. */
 int scalce_batch_entropy_begin_group_last(scalce_batch **batches, int n, void *prep_stream, void *stream, int last);
 /* Sharded runs: code a caller-assembled range of the run-wide reordered stream (it must start on a 10 MiB
  * block boundary) against the run-wide table; result in SCALCE_OUT_QUAL of `mate`. */

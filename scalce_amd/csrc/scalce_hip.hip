@@ -2372,8 +2372,10 @@ extern "C" int scalce_batch_entropy_begin_group_last(scalce_batch **bs, int n, v
   // sixth of the SIMD time per block, and the front stages of the next shards keep the chip
   // last == 2: a small launch at the START of a run (more shards are on their way: the CUs belong to their front stages):
   // one block per lane whatever the size
-  int bpw = (total < 900 && last != 2) ? 4 : 64;
-  if (last == 1 && total >= 900 && total <= 2048) bpw = 8;
+  // last == 3: one of the last launches of a run, with a front stage or two still to come: eight blocks per chain wave (60 CUs
+  // per 50 M-read shard for ~0.4 s) -- sooner done than one block per lane, and not the whole chip
+  int bpw = (total < 900 && last != 2 && last != 3) ? 4 : 64;
+  if ((last == 1 && total >= 900 && total <= 2048) || (last == 3 && total <= 1024)) bpw = 8;
   if (ac_blocks_per_wg() != 1) bpw = ac_blocks_per_wg();
 
   int rc = ac_launch(jobs.data(), (int)jobs.size(), bpw, s, ps);

@@ -40,6 +40,8 @@ class ShardPipeline:
         # fraction of a CU per 64 blocks for ~0.5 s whatever the size of the launch, so several launches run side by side
         self.coders = [torch.cuda.Stream() for _ in range(max(1, int(coder_streams)))]
         self.coder = self.coders[0]
+        self.tail_streams = [torch.cuda.Stream() for _ in range(3)]  # the halves of a run's last group: never behind a running launch
+        self._tail_launches = 0
         self._launches = 0
         self.on_retire = on_retire
         self.sharded = sharded          # shards arrive prepared (scalce_sharded_compress with SCALCE_SHARD_PREPARE_ONLY / _CODER_ASYNC)
@@ -53,6 +55,9 @@ class ShardPipeline:
         # sooner, the front stages of the next shards run beside one more launch: 89.1 against 88.1 ms per shard at 20 steps
         self.ramp = not sharded and bool(os.environ.get("SCALCE_BENCH_RAMP"))
         self._run_launches = 0          # launches since the pipeline was last drained
+        # the last group of a run in halves (submit): measured (round 4) and left off -- 88.4 against 86.4 ms per shard at 20 steps
+        # (what the smaller, faster launches gain at the end their CUs take from the last front stages)
+        self.tail = bool(os.environ.get("SCALCE_BENCH_TAIL"))
 
     # -- slots ---------------------------------------------------------------------------------------------
     def acquire(self):
@@ -78,8 +83,12 @@ class ShardPipeline:
         self._tag[slot] = None
 
     # -- coder launches ------------------------------------------------------------------------------------
-    def submit(self, slot, tag=None, flush=False):
-        """The front stages of `slot` are enqueued on `self.front`: launch the coder now or with the next shards."""
+    def submit(self, slot, tag=None, flush=False, remaining=None):
+        """The front stages of `slot` are enqueued on `self.front`: launch the coder now or with the next shards.
+        remaining: shards of the run still to come behind this one (None: unknown).  The END of a run is what the last
+        launch takes after the last front stage -- ~0.6 s of an idle chip with one block per lane; with SCALCE_BENCH_TAIL=1 the
+        last group goes out in halves (with 6 pending + to come: 3, then 2, then 1), the smaller ones with kernels that are
+        sooner done (measured: no gain, off by default)."""
         self._tag[slot] = tag
         if self.G == 1:
             b = self.batches[slot]
@@ -97,19 +106,29 @@ class ShardPipeline:
         # the first launches of a run are smaller (1, 2, .. shards): a launch takes ~0.6 s whatever it holds, and nothing is
         # coded -- no slot comes back -- until the first one has gone out
         target = min(self.G, self._run_launches + 1) if self.ramp else self.G
+        tail = remaining is not None and self.tail and not self.sharded and remaining + len(self._pending) <= self.G
+        if tail and not flush and remaining > 0:
+            if len(self._pending) >= remaining:     # as many waiting as still to come: out they go
+                self.flush(mode=3 if remaining <= 2 else 2)
+            return
         if len(self._pending) >= target or flush:
             self.flush(last=flush, small=len(self._pending) < self.G and not flush)
 
-    def flush(self, last=False, small=False):
+    def flush(self, last=False, small=False, mode=None):
         """last: the caller has no further shards (the end of a run): the launch is picked for its own latency.
-        small: a launch of fewer than `group` shards with more on their way: the kernel that holds the fewest CUs."""
+        small: a launch of fewer than `group` shards with more on their way: the kernel that holds the fewest CUs.
+        mode: scalce_batch_entropy_begin_group_last's `last` argument given directly (tail launches)."""
         if not self._pending:
             return
-        coder = self.coders[self._launches % len(self.coders)]
-        self._launches += 1
+        if mode is not None or (last and self._tail_launches):
+            coder = self.tail_streams[self._tail_launches % len(self.tail_streams)]
+            self._tail_launches += 1
+        else:
+            coder = self.coders[self._launches % len(self.coders)]
+            self._launches += 1
         self._run_launches += 1
         host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, coder.cuda_stream,
-                                 last=0 if self.sharded else (1 if last else 2 if small else 0))
+                                 last=0 if self.sharded else (mode if mode is not None else 1 if last else 2 if small else 0))
         ev = self.torch.cuda.Event()
         ev.record(coder)
         for sl in self._pending:
@@ -123,3 +142,4 @@ class ShardPipeline:
         for slot in range(self.D):
             self.retire(slot)
         self._run_launches = 0
+        self._tail_launches = 0
