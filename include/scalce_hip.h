@@ -151,6 +151,10 @@ void scalce_batch_set_lean(scalce_batch *b, int lean);
  * rows lie back to back: for callers that read SCALCE_OUT_QINPUT as one array (sharded runs); lean batches do so by themselves.
  * Returns SCALCE_ERR_ARG when the batch cannot take the layout asked for. */
 int scalce_batch_set_fused_rows(scalce_batch *b, int on);
+/* edge[0..1] = the first two, edge[2..3] = the last two q' symbols of the rows held (input order), *nsym = how many there are,
+ * *read_len (may be NULL) = symbols per row: what a rank of a sharded run tells its neighbours (qualities.cpp:179-198: prev[]
+ * runs across reads, so two trigrams straddle every rank boundary).  Runs on `stream` and synchronises it. */
+int scalce_batch_qinput_edges(scalce_batch *b, int mate, uint8_t edge[4], uint64_t *nsym, int32_t *read_len, void *stream);
 /* output_quality (qualities.cpp:177-204): q' = map[q]-offset (N -> 0) and the order-2 trigram
  * counters ac_freq4 over the input-order stream of this shard. */
 int scalce_batch_quality(scalce_batch *b, void *stream);
@@ -340,6 +344,9 @@ int scalce_comm_rank(const scalce_comm *c);
 int scalce_comm_barrier(scalce_comm *c, void *stream);
 int scalce_comm_all_gather(scalce_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
 int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, uint64_t count, void *stream);
+/* One message between two ranks (what a chain of ranks hands on: the counts of the tie-break, rank r to rank r + 1). */
+int scalce_comm_send(scalce_comm *c, const void *d_buf, uint64_t bytes, int peer, void *stream);
+int scalce_comm_recv(scalce_comm *c, void *d_buf, uint64_t bytes, int peer, void *stream);
 int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, const uint64_t *send_bytes, void *d_recv,
                              const uint64_t *recv_bytes, void *stream);
 

@@ -77,7 +77,9 @@ struct ShmHeader {
   uint64_t ready;      // set by rank 0 once the barrier is initialised
   uint64_t slot_bytes;
   uint64_t sizes[64][64];  // all_to_all_v: sizes[src][dst]
+  uint64_t box_state[64];  // point-to-point mailbox of every receiver: 0 = empty, else bytes + 1 of the message in it
 };
+constexpr size_t SHM_BOX_BYTES = 16u << 20;  // one message of up to 16 MiB per receiver (behind the slots)
 
 }  // namespace
 
@@ -152,7 +154,7 @@ extern "C" int scalce_comm_create_shm(int device, int world, int rank, const cha
   c->shm_name = name;
   c->slot_bytes = slot_bytes ? slot_bytes : (64ull << 20);
   *out = c;
-  c->map_bytes = sizeof(ShmHeader) + (size_t)world * c->slot_bytes;
+  c->map_bytes = sizeof(ShmHeader) + (size_t)world * c->slot_bytes + (size_t)world * SHM_BOX_BYTES;
   int fd = -1;
   if (rank == 0) {
     shm_unlink(name);
@@ -179,6 +181,7 @@ extern "C" int scalce_comm_create_shm(int device, int world, int rank, const cha
     pthread_barrier_init(&c->hdr->barrier, &a, (unsigned)world);
     pthread_barrierattr_destroy(&a);
     c->hdr->slot_bytes = c->slot_bytes;
+    for (int r = 0; r < 64; r++) c->hdr->box_state[r] = 0;
     __atomic_store_n(&c->hdr->ready, 1ull, __ATOMIC_RELEASE);
   } else {
     for (int tries = 0; tries < 30000 && !__atomic_load_n(&c->hdr->ready, __ATOMIC_ACQUIRE); tries++) usleep(1000);
@@ -256,6 +259,49 @@ extern "C" int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, u
   pthread_barrier_wait(&c->hdr->barrier);
   CM_HIP(c, cm_copy(c, d_buf, acc, bytes, hipMemcpyHostToDevice, s));
   CM_HIP(c, cm_sync(c, s));
+  return SCALCE_OK;
+}
+
+// Point to point: one message from this rank to `peer` / from `peer` to this rank (what a chain of ranks hands on: the
+// counts of the tie-break, sharded.cpp).  Over RCCL a plain ncclSend / ncclRecv on the stream; over the rehearsal transport a
+// mailbox per receiver in the shared segment (the sender waits for it to be empty, the receiver for it to be full).
+extern "C" int scalce_comm_send(scalce_comm *c, const void *d_buf, uint64_t bytes, int peer, void *stream) {
+  if (!c || !d_buf || !bytes || peer < 0 || peer >= c->world || peer == c->rank) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->shm) {
+    if (!c->nccl) return SCALCE_ERR_ARG;
+    CM_NCCL(c, g_rccl.Send(d_buf, bytes, ncclUint8, peer, c->nccl, s));
+    return SCALCE_OK;
+  }
+  if (bytes > SHM_BOX_BYTES) { c->err = "shm transport: point-to-point message larger than a mailbox"; return SCALCE_ERR_CAPACITY; }
+  uint8_t *box = c->slots + (size_t)c->world * c->slot_bytes + (size_t)peer * SHM_BOX_BYTES;
+  for (long tries = 0; __atomic_load_n(&c->hdr->box_state[peer], __ATOMIC_ACQUIRE) != 0; tries++) {
+    if (tries > 600000) { c->err = "shm transport: the receiver never emptied its mailbox"; return SCALCE_ERR_HIP; }
+    usleep(100);
+  }
+  CM_HIP(c, cm_copy(c, box, d_buf, bytes, hipMemcpyDeviceToHost, s));
+  CM_HIP(c, cm_sync(c, s));
+  __atomic_store_n(&c->hdr->box_state[peer], bytes + 1, __ATOMIC_RELEASE);
+  return SCALCE_OK;
+}
+extern "C" int scalce_comm_recv(scalce_comm *c, void *d_buf, uint64_t bytes, int peer, void *stream) {
+  if (!c || !d_buf || !bytes || peer < 0 || peer >= c->world || peer == c->rank) return SCALCE_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (!c->shm) {
+    if (!c->nccl) return SCALCE_ERR_ARG;
+    CM_NCCL(c, g_rccl.Recv(d_buf, bytes, ncclUint8, peer, c->nccl, s));
+    return SCALCE_OK;
+  }
+  uint8_t *box = c->slots + (size_t)c->world * c->slot_bytes + (size_t)c->rank * SHM_BOX_BYTES;
+  uint64_t st = 0;
+  for (long tries = 0; (st = __atomic_load_n(&c->hdr->box_state[c->rank], __ATOMIC_ACQUIRE)) == 0; tries++) {
+    if (tries > 600000) { c->err = "shm transport: no message arrived"; return SCALCE_ERR_HIP; }
+    usleep(100);
+  }
+  if (st - 1 != bytes) { c->err = "shm transport: a message of another size than expected"; return SCALCE_ERR_ARG; }
+  CM_HIP(c, cm_copy(c, d_buf, box, bytes, hipMemcpyHostToDevice, s));
+  CM_HIP(c, cm_sync(c, s));
+  __atomic_store_n(&c->hdr->box_state[c->rank], 0ull, __ATOMIC_RELEASE);
   return SCALCE_OK;
 }
 

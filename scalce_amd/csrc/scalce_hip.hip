@@ -2490,6 +2490,34 @@ extern "C" int scalce_batch_params(const scalce_batch *b, scalce_params *out) {
   return SCALCE_OK;
 }
 
+// the first two and the last two q' symbols of the rows held (input order), and how many symbols there are: what a rank of a
+// sharded run tells its neighbours (the trigrams that straddle a rank boundary) -- without asking for SCALCE_OUT_QINPUT as
+// one array, which fused rows would have to be copied together for
+extern "C" int scalce_batch_qinput_edges(scalce_batch *b, int mate, uint8_t edge[4], uint64_t *nsym, int32_t *read_len, void *stream) {
+  if (!b || mate < 0 || mate >= b->nm || !edge || !nsym) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const u64 L = (u64)b->L[mate], n = b->N * L, QS = b->qstride[mate];
+  *nsym = n;
+  if (read_len) *read_len = b->L[mate];
+  edge[0] = edge[1] = edge[2] = edge[3] = 0;
+  const u8 *q = b->q[mate].as<u8>();
+  auto at = [&](u64 t) { return q + (t / L) * QS + (t % L); };
+  // (on the caller's stream, behind the ingest: a device-wide wait would sit behind every coder that is running)
+  if (n >= 2) {
+    HIP_TRY(c, hipMemcpyAsync(&edge[0], at(0), 1, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&edge[1], at(1), 1, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&edge[2], at(n - 2), 1, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&edge[3], at(n - 1), 1, hipMemcpyDeviceToHost, s));
+  } else if (n == 1) {
+    HIP_TRY(c, hipMemcpyAsync(&edge[0], at(0), 1, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(c, hipStreamSynchronize(s));
+  if (n == 1) edge[3] = edge[0];
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_set_frame_on_demand(scalce_batch *b, int on) {
   if (!b) return SCALCE_ERR_ARG;
   b->frame_on_demand = on != 0;

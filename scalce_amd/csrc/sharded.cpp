@@ -31,6 +31,10 @@ namespace {
 typedef uint64_t u64;
 constexpr u64 AC_BLOCK = 10ull * 1024 * 1024;
 
+__global__ void add_counts_into_k(uint32_t nb1, const u64 *mine, u64 *acc) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb1) acc[b] += mine[b];
+}
 // prior[b] = reads of bucket b held by the ranks before `rank`; gathered = [world][stride] u64
 __global__ void prior_from_gathered_k(uint32_t nb1, const u64 *gathered, uint32_t stride, int rank, u64 *prior) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,12 +269,14 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     int L[2] = {0, 0};
     local([&] {
       SH_RC(ctx, scalce_batch_reset(b));
-      scalce_batch_set_fused_rows(b, 0);  // (q' in input order is read as one array below: rows back to back)
       SH_RC(ctx, scalce_batch_append(b, text[0], nbytes[0], text[1], nbytes[1], SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_TOKENIZE, used, s));
       N0 = scalce_batch_reads(b);
-      for (int m = 0; m < nm; m++) {  // read lengths: symbols per row of the q' output
-        SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QINPUT, m, &dp, &nb));
-        L[m] = N0 ? (int)(nb / N0) : 0;
+      for (int m = 0; m < nm; m++) {  // read lengths: symbols per row
+        uint8_t e4[4];
+        uint64_t ns = 0;
+        int32_t rl = 0;
+        SH_RC(ctx, scalce_batch_qinput_edges(b, m, e4, &ns, &rl, s));
+        L[m] = N0 ? rl : 0;
       }
     });
     if (local_err.rc) N0 = 0;
@@ -305,14 +311,9 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     // the first two and last two q' symbols of the own piece: trigrams that straddle a rank boundary (step 4)
     uint8_t edge[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int m = 0; m < nm; m++) {
-      SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QINPUT, m, &dp, &nb));
-      if (nb >= 2) {
-        SH_HIP(hipMemcpy(edge[m], dp, 2, hipMemcpyDeviceToHost));
-        SH_HIP(hipMemcpy(edge[m] + 2, static_cast<const uint8_t *>(dp) + nb - 2, 2, hipMemcpyDeviceToHost));
-      } else if (nb == 1) {
-        SH_HIP(hipMemcpy(edge[m], dp, 1, hipMemcpyDeviceToHost));
-        edge[m][3] = edge[m][0];
-      }
+      uint64_t ns = 0;
+      SH_RC(ctx, scalce_batch_qinput_edges(b, m, edge[m], &ns, nullptr, s));
+      nb = ns;
     }
     // ---- 2. spill chunks of the run-wide -B rule: a chain of carries, then everybody learns every cut
     std::vector<u64> cuts_global;  // run-wide rows in front of which a chunk begins
@@ -452,11 +453,46 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
       }
     }
     mark("quality model");
-    // ---- 5. tie-break across ranks: rounds of (all-gather counts -> prior, a few local sweeps) until nobody moves
+    // ---- 5. tie-break across ranks.  bin_size is cumulative over the run (reads.cpp:246): a rank's tie reads are decided
+    // against the FINAL counts of every rank in front of it.  Rounds 1-3 iterated: all-gather of everybody's counts, a few
+    // global sweeps, until no rank moved (~13 rounds, 27 ms per 50 M-read shard).  Round 4: the ranks form a chain.  Rank r
+    // waits for the counts of ranks 0 .. r-1 from rank r-1 (one message: [status][buckets + 1 counts]), settles its own tie
+    // reads against them window by window (scalce_batch_tokenize_settle: the tie-break of a batch on its own, exact given its
+    // prior), adds its counts and hands the sum to rank r+1.  A rank only spends its own settle; what the chain adds is a
+    // start-up skew of one settle per rank in front -- with several shards in flight the ranks work on different shards.
+    // SCALCE_SHARD_TIE_ROUNDS=1 keeps the rounds (comparisons).
     {
       local([&] { SH_RC(ctx, scalce_batch_tokenize_begin(b, s)); });
       if (W > 1) agree("tokenizer"); else if (local_err.rc) throw local_err;
       const uint32_t stride = nb1 + 1;
+      static const bool rounds_mode = getenv("SCALCE_SHARD_TIE_ROUNDS") != nullptr;
+      if (!rounds_mode) {
+        u64 *d_msg = mem.alloc<u64>(stride);       // [0] status of the ranks in front (0 = fine), [1 ..] their counts per bucket
+        u64 upstream = 0;
+        if (rank > 0) {
+          SH_CM(comm, scalce_comm_recv(comm, d_msg, (size_t)stride * 8, rank - 1, s));
+          SH_HIP(hipMemcpyAsync(&upstream, d_msg, 8, hipMemcpyDeviceToHost, s));
+          SH_HIP(hipStreamSynchronize(s));
+        } else {
+          SH_HIP(hipMemsetAsync(d_msg, 0, (size_t)stride * 8, s));
+        }
+        if (!upstream)
+          local([&] { SH_RC(ctx, scalce_batch_tokenize_settle(b, rank > 0 ? reinterpret_cast<const uint64_t *>(d_msg + 1) : nullptr, s)); });
+        else
+          local([&] { SH_RC(ctx, scalce_batch_tokenize_settle(b, nullptr, s)); });  // (a rank in front failed: the run ends at the next agree())
+        res->rounds = 1;
+        res->sweeps = 0;
+        if (rank + 1 < W) {
+          u64 status = upstream ? upstream : (local_err.rc ? 2 + (u64)local_err.rc : 0);
+          if (!local_err.rc) {
+            SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dp, &nb));
+            hipLaunchKernelGGL(add_counts_into_k, dim3((nb1 + 255) / 256), dim3(256), 0, s, nb1, static_cast<const u64 *>(dp), d_msg + 1);
+          }
+          SH_HIP(hipMemcpyAsync(d_msg, &status, 8, hipMemcpyHostToDevice, s));
+          SH_HIP(hipStreamSynchronize(s));  // `status` is a stack variable
+          SH_CM(comm, scalce_comm_send(comm, d_msg, (size_t)stride * 8, rank + 1, s));
+        }
+      } else {
       u64 *d_mine = mem.alloc<u64>(stride), *d_all = mem.alloc<u64>((size_t)W * stride), *d_prior = mem.alloc<u64>(nb1);
       u64 moved = 1;
       std::vector<u64> flags(W);
@@ -489,6 +525,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         if (res->rounds > total_reads + 8) throw Fail{"tie resolution did not converge", SCALCE_ERR_HIP};
       }
       local([&] { SH_RC(ctx, scalce_batch_tokenize_end(b, s)); });  // (its status travels with the order stage's, below)
+      }
     }
     mark("tie-break");
     // ---- 6. order (the run's cuts inside this rank's rows are its chunks) and emit

@@ -35,6 +35,17 @@ def main():
                                            recv_counts.ctypes.data_as(C.POINTER(C.c_uint64)), None))
     want = np.concatenate([np.full(int(recv_counts[s]), s * 16 + rank, dtype=np.uint8) for s in range(world)])
     assert (recv == want).all()
+    # point to point, as a chain: rank r receives a running sum from r - 1, adds its own, hands it on (the tie-break's counts)
+    L.scalce_comm_send.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    L.scalce_comm_recv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    for rep in range(3):
+        acc = np.zeros(777, dtype=np.uint64)
+        if rank > 0:
+            comm._check(L.scalce_comm_recv(comm.h, acc.ctypes.data, acc.nbytes, rank - 1, None))
+        assert (acc == (rep + 1) * rank * (rank + 1) // 2).all()
+        acc += (rep + 1) * (rank + 1)
+        if rank + 1 < world:
+            comm._check(L.scalce_comm_send(comm.h, acc.ctypes.data, acc.nbytes, rank + 1, None))
     comm.barrier()
     comm.close()
     print("rank", rank, "ok")
