@@ -103,6 +103,7 @@ struct AcEncArgs {
   u32 chain_prio;      // s_setprio of the chain waves (ac_encode_rows_k)
   u32 helper_prio;     // s_setprio of the helper waves (ac_encode_rows_k)
   u32 lanes_used;      // ac_encode_lanes_k: blocks per workgroup (0 = 64)
+  u32 pairing;         // ac_encode_lanes_k with two sets: which roles share a SIMD (experiments)
   u32 test_poison;     // test hook: every test_poison-th super-round pretends a step hit the full-range exit (0 = off)
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]

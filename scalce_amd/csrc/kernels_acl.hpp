@@ -28,9 +28,12 @@
 //           Rounds that are not plain for a lane -- the first (two raw symbols), a block's tail, a symbol that is the
 //           last of its context, a range that renormalises to the full 2^32 -- are redone for those lanes by the
 //           general step under the exec mask
-//   sink    lane b adds block b's (B, Q) records of the previous round into its accumulator; the word that may still
-//           take a carry goes to a staging ring in LDS in every step
-//   writer  moves the words that are final from the ring to the block's output, 16 bytes per lane and store
+//   sink    lane b adds block b's (B, Q) records of the previous round into its accumulator and reports, per step, the word
+//           that may still take a carry and its index (two steps per 16-byte record: round 4 -- in round 3 this wave stored
+//           the word into the staging ring itself, an LDS instruction and two of address arithmetic per step of the wave
+//           that sets the pace of a round)
+//   writer  puts the reported words into its staging ring, in step order, and moves those that are final from the ring to
+//           the block's output, a 128-byte line per lane and visit
 // One LDS-only barrier per round.  Contexts depend on symbols only, never on coder state, which is why the gather
 // wave can run ahead.  Measured costs behind this split: tools/ubench_lds.hip (a DS instruction costs a wave 17-35 cycles
 // whatever its width, a branch on a VALU result ~30, a VALU instruction 4), DESIGN.md section 5.
@@ -94,19 +97,20 @@ __device__ __forceinline__ void acl_step_plain(u32 &lo, u32 &M, const uint4 g, u
 //   * the notes -- word indices, in a log that grows down from the end of the block's own output buffer -- are applied by
 //     finish(): additions commute.  (Resolved on the spot, a loop of loads and stores in the step sequence, the compiler
 //     put s_waitcnt vmcnt(0) in front of every store of the following steps.)
-constexpr int ACL_RING = 128;  // staging ring, words per lane: the writer takes whole 128-byte lines (32 words), the sink is at most three rounds (48 words) ahead of it
+// staging ring of the writer wave, words per lane: it takes whole 128-byte lines (32 words) out and puts at most 16 words
+// per round in front of them: 31 + 16 + 16 + 2 <= WORDS.
+template <int LW, int SETS> struct AclRing { static constexpr int WORDS = 64; };
+template <int LW>
 struct AclSink {
   SCALCE_GLOBAL u32 *dst;
-  u32 (*ring)[64];  // [slot][lane]: word k of the block lives in slot (k + 1) & (ACL_RING - 1) -- lane l always hits bank l
-  int lane;
   u32 wcap;      // words the block may write
   u32 w2, w1, w0;
   u32 Qb;        // stream position of the next B's top bit
   u32 ncar;      // smallest w2 seen right after a step of this round added its carry: 0 = a carry may have left w2 (step())
   u32 nlog;      // notes in the log
   bool over;
-  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 (*r)[64], int l, u32 cap_words, u32 s0, u32 s1) {
-    dst = d; ring = r; lane = l; wcap = cap_words;
+  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 cap_words, u32 s0, u32 s1) {
+    dst = d; wcap = cap_words;
     w2 = 0; w1 = (s0 << 24) | (s1 << 16); w0 = 0;  // the two raw symbols (arithmetic.cpp:110-120): 16 bits of X
     Qb = 16; ncar = ~0u; nlog = 0; over = false;    // (w2 = the empty word in front of the block: ring slot 0, never taken out)
   }
@@ -119,8 +123,10 @@ struct AclSink {
     if ((Qb >> 5) + 2 * ACL_STEPS + 2 + nlog >= wcap) over = true;
     return !over;
   }
-  // the step: X += B at bit Qb, then on to Qa
-  __device__ __forceinline__ void step(u32 B, u32 Qa) {
+  // the step: X += B at bit Qb, then on to Qa.  Reports the word that may still take a carry as it stands now (val) and
+  // the index wq of the word behind it: word wq - 1 of the block is `val` until a later step says otherwise -- the writer
+  // wave puts it into the staging ring (slot wq & (ring words - 1)); it is final once a step completes word wq.
+  __device__ __forceinline__ void step(u32 B, u32 Qa, u32 &val, u32 &wq) {
     const u32 pos = Qb & 31u;
     const u32 b_hi = B >> pos;
     const u32 b_lo = __builtin_amdgcn_alignbit(B, 0u, pos);  // low word of {B, 0} >> pos: B << (32 - pos), 0 for pos = 0
@@ -132,8 +138,8 @@ struct AclSink {
     // another reason -- the empty word in front of the block, a genuine all-zero word -- only costs that redo.)
     w2 += c1;
     ncar = w2 < ncar ? w2 : ncar;
-    const u32 wq = Qb >> 5;
-    ring[__builtin_amdgcn_ubfe(Qb, 5, 7)][lane] = w2;  // slot wq & (ACL_RING - 1); final if this step completes w1, overwritten otherwise
+    wq = Qb >> 5;
+    val = w2;
     const bool f = (Qa >> 5) != wq;
     w2 = f ? w1 : w2;
     w1 = f ? w0 : w1;
@@ -154,8 +160,7 @@ struct AclSink {
       dst[wcap - 1u - nlog] = wq - 2u;  // (wq >= 2: a carry out of w2 needs 32 ones there, the empty word in front of the block has none)
       nlog++;
     }
-    ring[wq & (ACL_RING - 1)][lane] = w2;
-    if ((Qa >> 5) != wq) { w2 = w1; w1 = w0; w0 = 0u; }
+    if ((Qa >> 5) != wq) { w2 = w1; w1 = w0; w0 = 0u; }  // (the words are those step() reported: only the note is new)
     Qb = Qa;
   }
   static __device__ __forceinline__ void carry_back(SCALCE_GLOBAL u32 *dst, u32 wcap, int k) {
@@ -202,13 +207,15 @@ struct AclSink {
   }
 };
 
-constexpr int ACL_SLOTS = 5;   // operand ring: the gather wave runs four rounds ahead of the chain
+// LW = lanes (blocks) of a set of four waves, SLOTS = operand ring: the gather wave runs SLOTS - 1 rounds ahead of the chain
+template <int LW, int SLOTS, int RINGW>
 struct AclShared {
-  uint4 ops[ACL_SLOTS][ACL_STEPS][64];  // gather -> chain: operands of a round (slot = round % ACL_SLOTS), written by LDS-direct loads
-  uint2 rec[2][ACL_STEPS][64];          // chain -> sink: (B, Q) of a round
-  u32 stage[ACL_RING][64];              // sink -> writer: coded words on their way out
-  u32 pub[2][64];                       // sink -> writer: words below this index are final
-  u32 final_lo[64];
+  uint4 ops[SLOTS][ACL_STEPS][LW];      // gather -> chain: operands of a round (slot = round % SLOTS), written by LDS-direct loads
+  uint4 rec[2][ACL_STEPS / 2][LW];      // chain -> sink: (B, Q) of two steps of a round per entry
+  uint4 fifo[2][ACL_STEPS / 2][LW];     // sink -> writer: (val, wq) of two steps per entry (AclSink::step)
+  u32 stage[RINGW][LW];                 // writer: coded words on their way out -- word k of the block in slot (k + 1) & (WORDS - 1)
+  u32 pub[2][LW];                       // sink -> writer: words below this index are final
+  u32 final_lo[LW];
 };
 
 // VMEM of the gather wave is issued and awaited by hand.  Its loads are consumed two to four rounds after they were
@@ -230,25 +237,46 @@ __device__ __forceinline__ void acl_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <bool EXCLUSIVE>
-__global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
-  __shared__ AclShared sh;
+// SETS = 1: one set of four waves per workgroup, a wave per SIMD (round 3).  SETS = 2 (round 4): TWO sets in a workgroup of
+// eight waves over 2 x LW blocks, two waves per SIMD -- a chain or sink wave spends half of a step waiting for its DS
+// instructions, slots that a light wave (gather, writer) of the OTHER set takes: wave w of a workgroup
+// goes to SIMD w % 4, so
+//     SIMD 0: chain A + gather B    SIMD 1: chain B + gather A    SIMD 2: sink A + writer B    SIMD 3: sink B + writer A
+// A CU then codes 2 x LW blocks at (nearly) the pace of LW.  Each wave claims 256 registers: two per SIMD, nothing else.
+// LDS holds both sets (LW = 48, SLOTS = 3: 2 x 73 KB).  One barrier per round for all eight waves.
+template <bool EXCLUSIVE, int SETS, int LW, int SLOTS>
+__global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
+  static_assert(SLOTS >= 3 && SLOTS <= 9 && LW <= 64 && (SETS == 1 || SETS == 2), "");
+  __shared__ AclShared<LW, SLOTS, AclRing<LW, SETS>::WORDS> shs[SETS];
   const int lane = lane_id();
-  const int role = wave_id();  // 0 chain, 1 gather, 2 sink, 3 writer: the four SIMDs of the CU
+  const int w = wave_id();
+  // SETS == 1: 0 chain, 1 gather, 2 sink, 3 writer: the four SIMDs of the CU.  SETS == 2: see above.
+  // (a.pairing, experiments: 1 = chain + writer / sink + gather, 2 = chain + sink / gather + writer on a SIMD)
+  const u32 rtab = a.pairing == 1 ? 0x11332200u : a.pairing == 2 ? 0x33221100u : 0x33112200u;  // role of wave w: nibble w
+  const u32 stab = a.pairing == 1 ? 0x01011010u : a.pairing == 2 ? 0x01011010u : 0x01011010u;  // set of wave w
+  const int role = SETS == 1 ? w : (int)((rtab >> (4 * w)) & 15u);
+  const int set = SETS == 1 ? 0 : (int)((stab >> (4 * w)) & 15u);
+  AclShared<LW, SLOTS, AclRing<LW, SETS>::WORDS> &sh = shs[set];
   // Workgroups are dealt to the 8 XCDs in turn (b and b + 8 share one: MI355X_MICROARCH.md, Workgroup dispatch), and
   // every XCD has an L2 of its own.  A launch holds the blocks of several streams back to back, each stream with its own
-  // 4 MB table: the workgroups of an XCD take CONSECUTIVE groups of 64 blocks, so that an L2 serves one or two tables
+  // 4 MB table: the workgroups of an XCD take CONSECUTIVE groups of blocks, so that an L2 serves one or two tables
   // instead of all of them (with three tables per L2 the gather wave, not the chain, set the pace of a launch).  Speed
   // only: any placement gives the same bytes.
   const u32 nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7u, xcd = blockIdx.x & 7u;
   const u32 wg = (xcd < xr ? xcd * (xq + 1u) : xr * (xq + 1u) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  const u32 bpw = a.lanes_used ? a.lanes_used : 64u;  // blocks per workgroup (lanes in use)
-  const u32 blk = wg * bpw + (u32)lane;
+  const u32 bpw = a.lanes_used && a.lanes_used < (u32)LW ? a.lanes_used : (u32)LW;  // blocks per set (lanes in use)
+  const u32 blk = (wg * SETS + (u32)set) * bpw + (u32)lane;
   const bool have = blk < a.nblocks && (u32)lane < bpw;
   const SCALCE_GLOBAL AcBlockDesc *dp = (const SCALCE_GLOBAL AcBlockDesc *)a.desc + (have ? blk : 0u);
   const u32 n = have ? dp->n : 0u;
   const u32 nr = (n + ACL_STEPS - 1) / ACL_STEPS;  // rounds of this lane's block
   u32 nr_wg = nr;                                    // rounds of the workgroup = those of its longest block
+  if (SETS == 2) {                                   // (the other set's blocks as well: one barrier serves both)
+    const u32 oblk = (wg * SETS + (u32)(set ^ 1)) * bpw + (u32)lane;
+    const u32 on = oblk < a.nblocks && (u32)lane < bpw ? ((const SCALCE_GLOBAL AcBlockDesc *)a.desc + oblk)->n : 0u;
+    const u32 onr = (on + ACL_STEPS - 1) / ACL_STEPS;
+    nr_wg = onr > nr_wg ? onr : nr_wg;
+  }
 #pragma unroll
   for (int d = 32; d; d >>= 1) { const u32 o = __shfl_xor(nr_wg, d, 64); nr_wg = o > nr_wg ? o : nr_wg; }
   nr_wg = __builtin_amdgcn_readfirstlane(nr_wg);
@@ -257,13 +285,26 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
   // (every one of the four waves is on the round's critical path, the one-instruction-per-four-cycles kind), and their
   // memory traffic queues in front of the gather wave's table rows in the CU's own memory pipeline.  EXCLUSIVE makes each
   // coder wave claim its SIMD's whole register file (256 VGPRs + 256 AGPRs: an empty asm statement that names the last
-  // of each), so that the dispatcher places nothing else on the CU; otherwise all four only run at raised priority.
-  if (EXCLUSIVE) asm volatile("" ::: "v255", "a255");
-  __builtin_amdgcn_s_setprio(3);
-  if (a.prof && lane == 0) atomicOr((unsigned int *)&a.prof[blockIdx.x * 5 + 2], (simd_key() & 3u) << (4 * role));  // profiling: which SIMD each role runs on
+  // of each; half of it with two sets), so that the dispatcher places nothing else on the CU; otherwise all only run at
+  // raised priority.
+  if (EXCLUSIVE) {
+    if (SETS == 1) asm volatile("" ::: "v255", "a255");
+    else asm volatile("" ::: "v255");
+  }
+  if (SETS == 2 && (role & 1)) {  // the light waves take what the chain / sink on their SIMD leaves
+    if (a.helper_prio == 0) __builtin_amdgcn_s_setprio(0);
+    else if (a.helper_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.helper_prio == 3) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(2);
+  } else __builtin_amdgcn_s_setprio(3);
+  u64 *const prof = a.prof ? a.prof + (size_t)(blockIdx.x * SETS + set) * 5 : nullptr;
+  if (prof && lane == 0) atomicOr((unsigned int *)&prof[2], (simd_key() & 3u) << (4 * role));  // profiling: which SIMD each role runs on
+  // lanes beyond LW (SETS == 2) hold no block and must not touch the arrays, whose rows are LW wide
+  const bool inrow = LW == 64 || lane < LW;
 
   if (role == 1) {
-    // ================= gather: table rows straight into LDS, three rounds ahead =================
+    // ================= gather: table rows straight into LDS, SLOTS - 1 rounds ahead =================
+    constexpr int AHEAD = SLOTS - 1;
     const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
     const SCALCE_GLOBAL u64 *tab = (const SCALCE_GLOBAL u64 *)dp->tab;  // compact: [6400][81] bounds (ac_table_k)
     // 16 symbols of round k.  The block's symbols are 16-byte aligned (blocks start at multiples of 10 MiB of a 16-byte
@@ -274,9 +315,9 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
       return sp + off;
     };
     u32 p0 = 0, p1 = 0;  // the two symbols in front of the next round to be addressed
-    // 16 LDS-direct loads: bounds c and c + 1 of context (p0, p1) in the lane's table -> ops[k % ACL_SLOTS][j][lane]
+    // 16 LDS-direct loads: bounds c and c + 1 of context (p0, p1) in the lane's table -> ops[k % SLOTS][j][lane]
     auto request = [&](const u32x4 sy, u32 k) {
-      uint4 *slot = &sh.ops[k % ACL_SLOTS][0][0];
+      uint4 *slot = &sh.ops[k % SLOTS][0][0];
 #pragma unroll
       for (int j = 0; j < ACL_STEPS; j++) {
         const u32 word = j < 4 ? sy.x : j < 8 ? sy.y : j < 12 ? sy.z : sy.w;
@@ -284,7 +325,7 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
         const u32 D1 = AC_D - 1;
         c = c < D1 ? c : D1;  // symbols >= AC_D raised E_SYMBOL at ingest; stay inside the table regardless
         const u32 idx = (p0 * AC_D + p1) * (AC_D + 1) + c;
-        __builtin_amdgcn_global_load_lds((const SCALCE_GLOBAL void *)(tab + idx), (__attribute__((address_space(3))) void *)(slot + j * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const SCALCE_GLOBAL void *)(tab + idx), (__attribute__((address_space(3))) void *)(slot + j * LW), 16, 0, 0);
         p0 = p1;
         p1 = c;
       }
@@ -294,204 +335,255 @@ __global__ __launch_bounds__(256) void ac_encode_lanes_k(AcEncArgs a) {
     // did -- touches every 128-byte line of the block eight times, 0.75 us apart, and beside another shard's front stages
     // the line has left the L2 in between: the stream was fetched from HBM several times over and a launch took 1.7 x
     // as long beside the ingest stage as alone.
-    // VMEM in issue order: prologue [A B] wait [R0 R1 R2 R3], then per iteration i [R(i+4)] and, twice in 16 iterations, a
-    // chunk of 8 loads behind it; R = 16 instructions.  The hardware counts at most 63 outstanding vector memory
-    // instructions per wave: three requests in flight behind the one awaited is as deep as it goes, and everything older
-    // than those 48 instructions -- the chunks, requested 8 rounds ahead -- has landed by then.
+    // VMEM in issue order: prologue [A B] wait [R0 .. R(AHEAD-1)], then per iteration i [R(i+AHEAD)] and, twice in 16
+    // iterations, a chunk of 8 loads behind it; R = 16 instructions.  The hardware counts at most 63 outstanding vector
+    // memory instructions per wave: three requests in flight behind the one awaited is as deep as it goes, and everything
+    // older than those -- the chunks, requested 8 rounds ahead -- has landed by then.
     u32x4 ca[8], cb[8];
     auto load_chunk = [&](u32x4 (&c)[8], u32 first) {
 #pragma unroll
       for (int q = 0; q < 8; q++) c[q] = acl_load16(sym_addr(first + q));
     };
-    load_chunk(ca, 0);
-    load_chunk(cb, 8);
-#pragma unroll
-    for (int q = 0; q < 8; q++) { acl_wait_vm<0>(ca[q]); acl_wait_vm<0>(cb[q]); }
-    request(ca[0], 0);
-    request(ca[1], 1);
-    request(ca[2], 2);
-    request(ca[3], 3);
-    acl_wait_vm<3 * 16>();  // round 0 is in LDS
-    asm volatile("s_barrier" ::: "memory");
     u64 gprof_wait = 0;
-    // iteration i: request round i + 4; round i + 1 is in LDS when at most the three requests behind it are outstanding
-    auto iteration = [&](u32 i, const u32x4 &sy) {
-      request(sy, i + 4);
-    };
-    auto close = [&]() {
-      acl_wait_vm<3 * 16>();
-      if (a.prof) {
-        const u64 w0 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_barrier" ::: "memory");
-        gprof_wait += __builtin_amdgcn_s_memtime() - w0;
-      } else {
-        asm volatile("s_barrier" ::: "memory");
-      }
-    };
-    for (u32 i0 = 0; i0 < nr_wg; i0 += 16) {
+    if (inrow) {
+      load_chunk(ca, 0);
+      load_chunk(cb, 8);
 #pragma unroll
-      for (int j = 0; j < 16; j++) {
-        if (i0 + j < nr_wg) {
-          // round i0 + j + 4: symbols 4..7 of chunk A, then chunk B, then 0..3 of the next chunk A (requested at j = 4)
-          iteration(i0 + j, j < 4 ? ca[j + 4] : j < 12 ? cb[j - 4] : ca[j - 12]);
-          if (j == 4) load_chunk(ca, i0 + 16);
-          if (j == 12) load_chunk(cb, i0 + 24);
-          close();
+      for (int q = 0; q < 8; q++) { acl_wait_vm<0>(ca[q]); acl_wait_vm<0>(cb[q]); }
+#pragma unroll
+      for (int q = 0; q < AHEAD; q++) request(ca[q], q);
+      acl_wait_vm<(AHEAD - 1) * 16>();  // round 0 is in LDS
+      asm volatile("s_barrier" ::: "memory");
+      // iteration i: request round i + AHEAD; round i + 1 is in LDS when at most the AHEAD - 1 requests behind it are outstanding
+      auto close = [&]() {
+        acl_wait_vm<(AHEAD - 1) * 16>();
+        if (prof) {
+          const u64 w0 = __builtin_amdgcn_s_memtime();
+          asm volatile("s_barrier" ::: "memory");
+          gprof_wait += __builtin_amdgcn_s_memtime() - w0;
+        } else {
+          asm volatile("s_barrier" ::: "memory");
+        }
+      };
+      for (u32 i0 = 0; i0 < nr_wg; i0 += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if (i0 + j < nr_wg) {
+            // round i0 + j + AHEAD: its symbols are element (j + AHEAD) % 16 of the chunk pair; chunk A is free for the rounds
+            // 16 .. 23 behind i0 once round i0 + 7 has been requested (j = 8 - AHEAD), chunk B eight iterations later
+            const int e = (j + AHEAD) & 15;
+            request(e < 8 ? ca[e] : cb[e - 8], i0 + j + AHEAD);
+            if (j == 8 - AHEAD) load_chunk(ca, i0 + 16);
+            if (j == 16 - AHEAD) load_chunk(cb, i0 + 24);
+            close();
+          }
         }
       }
+      acl_wait_vm<0>();  // nothing of this wave may land in LDS after the workgroup has gone
+      asm volatile("s_barrier" ::: "memory");  // (the sink's last round)
+      asm volatile("s_barrier" ::: "memory");  // (the writer's last words)
     }
-    acl_wait_vm<0>();  // nothing of this wave may land in LDS after the workgroup has gone
-    asm volatile("s_barrier" ::: "memory");  // (the sink's last round)
-    asm volatile("s_barrier" ::: "memory");  // (the writer's last words)
-    if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 3] = gprof_wait;
+    if (prof && lane == 0) prof[3] = gprof_wait;
   } else if (role == 0) {
-    // ================= chain: 64 coder states =================
+    // ================= chain: one coder state per lane =================
     u32 ones, zero;
     asm("v_mov_b32 %0, -1" : "=v"(ones));
     asm("v_mov_b32 %0, 0" : "=v"(zero));
     u32 lo = 0, M = 0;  // M = 0 stands for 2^32
     u32 Q = 16;         // stream position of the next B's top bit: the two raw symbols, then every bit dropped
     u64 prof_wait = 0;
-    const u64 prof_t0 = a.prof ? __builtin_amdgcn_s_memtime() : 0;
-    __syncthreads();  // round 0's operands are in LDS
-    for (u32 r = 0; r < nr_wg; r++) {
-      const int slot = r % ACL_SLOTS;
-      const u32 lo0 = lo, M0 = M, Q0 = Q;
-      // all 16 operand reads are issued before the first step (read at the point of use, every step waited for a full
-      // LDS round trip)
-      uint4 g[ACL_STEPS];
+    const u64 prof_t0 = prof ? __builtin_amdgcn_s_memtime() : 0;
+    if (inrow) {
+      __syncthreads();  // round 0's operands are in LDS
+      for (u32 r = 0; r < nr_wg; r++) {
+        const int slot = r % SLOTS;
+        const u32 lo0 = lo, M0 = M, Q0 = Q;
+        // all 16 operand reads are issued before the first step (read at the point of use, every step waited for a full
+        // LDS round trip)
+        uint4 g[ACL_STEPS];
 #pragma unroll
-      for (int j = 0; j < ACL_STEPS; j++) g[j] = sh.ops[slot][j][lane];
-      u32 topw = 0;  // g(c_hi) = 2^64 - 1 marks the last symbol of a context (ac_table_k); no regular high word reaches that
+        for (int j = 0; j < ACL_STEPS; j++) g[j] = sh.ops[slot][j][lane];
+        u32 topw = 0;  // g(c_hi) = 2^64 - 1 marks the last symbol of a context (ac_table_k); no regular high word reaches that
+        u32 Bp = 0, Qp = 0;  // (the even step of a pair: two steps leave in one 16-byte record)
 #pragma unroll
-      for (int j = 0; j < ACL_STEPS; j++) {
-        u32 B, t;
-        acl_step_plain(lo, M, g[j], ones, zero, B, t);
-        Q += t;
-        sh.rec[r & 1][j][lane] = make_uint2(B, Q);
-        topw = g[j].w > topw ? g[j].w : topw;
-      }
-      const bool live = r < nr;
-      const bool poisoned = a.test_poison && r % a.test_poison == 0;
-      const bool complete = r > 0 && r * ACL_STEPS + ACL_STEPS <= n;  // not the round of the raw symbols, not a tail
-      const bool fast_ok = complete && topw != 0xFFFFFFFFu && M0 != 0u && M != 0u && !poisoned;
-      const bool fix = live && !fast_ok;  // this lane's records of the round are rewritten by general steps (a lane whose
-                                          // block has ended computes garbage nobody reads: the sink skips it)
-      if (__builtin_expect(__any(fix), 0)) {
-        if (fix) {
-          u32 glo = lo0 & 0x7FFFFFFFu, ghi = glo + M0 - 1u, gq = Q0;
-          const u32 jstart = r == 0 ? 2u : 0u;
-          const u32 left = n - r * ACL_STEPS;
-          const u32 jend = left < (u32)ACL_STEPS ? left : (u32)ACL_STEPS;
+        for (int j = 0; j < ACL_STEPS; j++) {
+          u32 B, t;
+          acl_step_plain(lo, M, g[j], ones, zero, B, t);
+          Q += t;
+          if (j & 1) sh.rec[r & 1][j >> 1][lane] = make_uint4(Bp, Qp, B, Q);
+          else { Bp = B; Qp = Q; }
+          topw = g[j].w > topw ? g[j].w : topw;
+        }
+        const bool live = r < nr;
+        const bool poisoned = a.test_poison && r % a.test_poison == 0;
+        const bool complete = r > 0 && r * ACL_STEPS + ACL_STEPS <= n;  // not the round of the raw symbols, not a tail
+        const bool fast_ok = complete && topw != 0xFFFFFFFFu && M0 != 0u && M != 0u && !poisoned;
+        const bool fix = live && !fast_ok;  // this lane's records of the round are rewritten by general steps (a lane whose
+                                            // block has ended computes garbage nobody reads: the sink skips it)
+        if (__builtin_expect(__any(fix), 0)) {
+          if (fix) {
+            u32 glo = lo0 & 0x7FFFFFFFu, ghi = glo + M0 - 1u, gq = Q0;
+            const u32 jstart = r == 0 ? 2u : 0u;
+            const u32 left = n - r * ACL_STEPS;
+            const u32 jend = left < (u32)ACL_STEPS ? left : (u32)ACL_STEPS;
+            u32 Bp = 0, Qp = 0;
 #pragma unroll 1
-          for (u32 j = 0; j < (u32)ACL_STEPS; j++) {
-            const uint4 gj = sh.ops[slot][j][lane];
-            u32 B = 0, t = 0;
-            if (j >= jstart && j < jend) acl_step_general(glo, ghi, gj, B, t);
-            gq += t;
-            sh.rec[r & 1][j][lane] = make_uint2(B, gq);
+            for (u32 j = 0; j < (u32)ACL_STEPS; j++) {
+              const uint4 gj = sh.ops[slot][j][lane];
+              u32 B = 0, t = 0;
+              if (j >= jstart && j < jend) acl_step_general(glo, ghi, gj, B, t);
+              gq += t;
+              if (j & 1u) sh.rec[r & 1][j >> 1][lane] = make_uint4(Bp, Qp, B, gq);
+              else { Bp = B; Qp = gq; }
+            }
+            lo = glo;
+            M = ghi - glo + 1u;
+            Q = gq;
           }
-          lo = glo;
-          M = ghi - glo + 1u;
-          Q = gq;
+        }
+        if (r + 1 == nr) sh.final_lo[lane] = lo & 0x7FFFFFFFu;
+        if (prof) {
+          const u64 w0 = __builtin_amdgcn_s_memtime();
+          __syncthreads();
+          prof_wait += __builtin_amdgcn_s_memtime() - w0;
+        } else {
+          __syncthreads();
         }
       }
-      if (r + 1 == nr) sh.final_lo[lane] = lo & 0x7FFFFFFFu;
-      if (a.prof) {
-        const u64 w0 = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        prof_wait += __builtin_amdgcn_s_memtime() - w0;
-      } else {
-        __syncthreads();
-      }
+      __syncthreads();  // (the sink's last round)
+      __syncthreads();  // (the writer's last words)
     }
-    __syncthreads();  // (the sink's last round)
-    __syncthreads();  // (the writer's last words)
-    if (a.prof && lane == 0) {
-      a.prof[blockIdx.x * 5 + 0] = prof_wait;
-      a.prof[blockIdx.x * 5 + 1] = __builtin_amdgcn_s_memtime() - prof_t0;
+    if (prof && lane == 0) {
+      prof[0] = prof_wait;
+      prof[1] = __builtin_amdgcn_s_memtime() - prof_t0;
     }
   } else if (role == 2) {
-    // ================= sink: 64 bit accumulators, one round behind the chain =================
-    AclSink sk;
-    {
-      const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
-      const u32 s0 = n ? (u32)sp[0] : 0u, s1 = n > 1 ? (u32)sp[1] : 0u;
-      sk.init((SCALCE_GLOBAL u32 *)dp->dst, sh.stage, lane, dp->cap / 4, s0, s1);
-    }
-    sh.pub[0][lane] = 0;
-    sh.pub[1][lane] = 0;
-    barrier_lds_only();
+    // ================= sink: one bit accumulator per lane, one round behind the chain =================
     u64 sprof_wait = 0;
-    auto take = [&](u32 r) {  // the records of round r
-      if (r < nr && sk.room()) {  // (per lane: a block that has ended has no records)
-        uint2 v[ACL_STEPS];
+    if (inrow) {
+      AclSink<LW> sk;
+      {
+        const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
+        const u32 s0 = n ? (u32)sp[0] : 0u, s1 = n > 1 ? (u32)sp[1] : 0u;
+        sk.init((SCALCE_GLOBAL u32 *)dp->dst, dp->cap / 4, s0, s1);
+      }
+      sh.pub[0][lane] = 0;
+      sh.pub[1][lane] = 0;
+      barrier_lds_only();
+      auto take = [&](u32 r) {  // the records of round r
+        if (r < nr && sk.room()) {  // (per lane: a block that has ended has no records)
+          uint4 v[ACL_STEPS / 2];
 #pragma unroll
-        for (int j = 0; j < ACL_STEPS; j++) v[j] = sh.rec[r & 1][j][lane];
-        const u32 s2 = sk.w2, s1 = sk.w1, s0 = sk.w0, sq = sk.Qb;
-        sk.ncar = ~0u;
+          for (int j = 0; j < ACL_STEPS / 2; j++) v[j] = sh.rec[r & 1][j][lane];
+          const u32 s2 = sk.w2, s1 = sk.w1, s0 = sk.w0, sq = sk.Qb;
+          sk.ncar = ~0u;
+          // two steps, one record for the writer wave: the ring stores (an LDS instruction and its address per step) are its
+          // work, not this wave's -- the sink sets the pace of a round
 #pragma unroll
-        for (int j = 0; j < ACL_STEPS; j++) sk.step(v[j].x, v[j].y);
-        if (__builtin_expect(__any(sk.ncar == 0u), 0)) {
-          if (sk.ncar == 0u) {
-            sk.w2 = s2; sk.w1 = s1; sk.w0 = s0; sk.Qb = sq;
+          for (int j = 0; j < ACL_STEPS / 2; j++) {
+            uint4 o;
+            sk.step(v[j].x, v[j].y, o.x, o.y);
+            sk.step(v[j].z, v[j].w, o.z, o.w);
+            sh.fifo[r & 1][j][lane] = o;
+          }
+          if (__builtin_expect(__any(sk.ncar == 0u), 0)) {
+            if (sk.ncar == 0u) {
+              sk.w2 = s2; sk.w1 = s1; sk.w0 = s0; sk.Qb = sq;
 #pragma unroll 1
-            for (int j = 0; j < ACL_STEPS; j++) sk.careful(sh.rec[r & 1][j][lane].x, sh.rec[r & 1][j][lane].y);
+              for (int j = 0; j < ACL_STEPS / 2; j++) {
+                const uint4 x = sh.rec[r & 1][j][lane];
+                sk.careful(x.x, x.y);
+                sk.careful(x.z, x.w);
+              }
+            }
           }
         }
+      };
+      for (u32 i = 0; i < nr_wg; i++) {  // iteration i: round i - 1
+        if (i > 0) take(i - 1);
+        sh.pub[i & 1][lane] = sk.final_words();
+        if (prof) {
+          const u64 w0 = __builtin_amdgcn_s_memtime();
+          barrier_lds_only();
+          sprof_wait += __builtin_amdgcn_s_memtime() - w0;
+        } else {
+          barrier_lds_only();
+        }
       }
-    };
-    for (u32 i = 0; i < nr_wg; i++) {  // iteration i: round i - 1
-      if (i > 0) take(i - 1);
-      sh.pub[i & 1][lane] = sk.final_words();
-      if (a.prof) {
-        const u64 w0 = __builtin_amdgcn_s_memtime();
-        barrier_lds_only();
-        sprof_wait += __builtin_amdgcn_s_memtime() - w0;
-      } else {
-        barrier_lds_only();
+      take(nr_wg - 1);
+      sh.pub[nr_wg & 1][lane] = sk.final_words();
+      barrier_lds_only();   // the writer takes out every final word ...
+      barrier_lds_only();   // ... and they are in memory (its fence): the notes go on top
+      if (have && n) {
+        const u32 bytes = sk.finish(sh.final_lo[lane]);
+        *(SCALCE_GLOBAL u32 *)dp->out_size = sk.over ? 0u : bytes;  // (a block that ran out of room: nothing frames bytes it does not hold)
+        if (sk.over) dev_fail(dp->err, E_ACOVERFLOW, dp->index, bytes);
       }
     }
-    if (a.prof && lane == 0) a.prof[blockIdx.x * 5 + 4] = sprof_wait;
-    take(nr_wg - 1);
-    sh.pub[nr_wg & 1][lane] = sk.final_words();
-    barrier_lds_only();   // the writer takes out every final word ...
-    barrier_lds_only();   // ... and they are in memory (its fence): the notes go on top
-    if (have && n) {
-      const u32 bytes = sk.finish(sh.final_lo[lane]);
-      *(SCALCE_GLOBAL u32 *)dp->out_size = sk.over ? 0u : bytes;  // (a block that ran out of room: nothing frames bytes it does not hold)
-      if (sk.over) dev_fail(dp->err, E_ACOVERFLOW, dp->index, bytes);
-    }
+    if (prof && lane == 0) prof[4] = sprof_wait;
   } else {
     // ================= writer: final words out of the staging ring =================
+    constexpr u32 RING = AclRing<LW, SETS>::WORDS;
     SCALCE_GLOBAL u32 *dst = (SCALCE_GLOBAL u32 *)dp->dst;
     const u32 wcap = dp->cap / 4;
     u32 wo = 0;  // words of this lane's block in global memory (multiple of 32 until the end)
-    auto word = [&](u32 k) -> u32 { return __builtin_bswap32(sh.stage[(k + 1u) & (ACL_RING - 1)][lane]); };
-    // Whole 128-byte lines: 32 words per lane in eight 16-byte stores back to back.  (Sixteen bytes per lane and visit left
-    // every line of the output half written in the L2 for several rounds -- where another shard's front stages stream
-    // through the same L2 it went to memory in pieces.)
+    auto word = [&](u32 k) -> u32 { return __builtin_bswap32(sh.stage[(k + 1u) & (RING - 1)][lane]); };
+    // Whole 128-byte lines, the lines of TWO blocks per visit: threads 0..31 store the 32 words of one block's line, threads
+    // 32..63 those of another's -- one coalesced 128-byte store each, and a visit per pair of lines that ARE ready.  (Round 3:
+    // every lane stored its own line in eight 16-byte pieces, all lanes masked but the ready ones -- 64 scattered pieces per
+    // instruction, and the visit cost the same ~1900 cycles for one ready lane as for forty; with some lane ready in nearly
+    // every round it was half of this wave's time.)
     auto drain = [&](u32 lim) {
-      while (__any(lim >= wo + 32u)) {
-        if (lim >= wo + 32u) {
+      u64 ready = __ballot(inrow && lim >= wo + 32u);
+      while (ready) {
+        const u32 la = (u32)__builtin_ctzll(ready);
+        ready &= ready - 1;
+        const u32 lb = ready ? (u32)__builtin_ctzll(ready) : la;  // (one line left: the upper threads stand by)
+        const bool two = ready != 0;
+        ready &= ready - 1;
+        const u32 t = (u32)lane & 31u;
+        const bool up = lane >= 32;
+        const u32 src = up ? lb : la;
+        const u32 wo_a = (u32)__builtin_amdgcn_readlane(wo, la), wo_b = (u32)__builtin_amdgcn_readlane(wo, lb);
+        const u32 cap_a = (u32)__builtin_amdgcn_readlane(wcap, la), cap_b = (u32)__builtin_amdgcn_readlane(wcap, lb);
+        // (the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends into the high word)
+        const u64 da = (u64)(uintptr_t)dst;
+        const u32 dlo = (u32)da, dhi = (u32)(da >> 32);
+        const u64 dst_a = ((u64)(u32)__builtin_amdgcn_readlane(dhi, la) << 32) | (u64)(u32)__builtin_amdgcn_readlane(dlo, la);
+        const u64 dst_b = ((u64)(u32)__builtin_amdgcn_readlane(dhi, lb) << 32) | (u64)(u32)__builtin_amdgcn_readlane(dlo, lb);
+        const u32 k = (up ? wo_b : wo_a) + t;
+        const u32 v = __builtin_bswap32(sh.stage[(k + 1u) & (RING - 1)][src]);
+        SCALCE_GLOBAL u32 *d = (SCALCE_GLOBAL u32 *)(uintptr_t)(up ? dst_b : dst_a);
+        if ((!up || two) && k < (up ? cap_b : cap_a)) d[k] = v;
+        if ((u32)lane == la || (two && (u32)lane == lb)) wo += 32;
+      }
+    };
+    // the words the sink's steps of round r reported (AclSink::step), into the ring in step order: a later report of the
+    // same word replaces an earlier one.  Only for a round the lane's block has -- what lies in the records otherwise is an
+    // older round's, and putting that back would undo newer words that are not out yet.
+    auto apply = [&](u32 r) {
+      if (inrow && r < nr) {
+        uint4 e[ACL_STEPS / 2];
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            u32x4 o;
-            o.x = word(wo + 4 * q); o.y = word(wo + 4 * q + 1); o.z = word(wo + 4 * q + 2); o.w = word(wo + 4 * q + 3);
-            if (wo + 4 * q + 4u <= wcap) *(SCALCE_GLOBAL u32x4 *)(dst + wo + 4 * q) = o;
-          }
-          wo += 32;
+        for (int j = 0; j < ACL_STEPS / 2; j++) e[j] = sh.fifo[r & 1][j][lane];
+#pragma unroll
+        for (int j = 0; j < ACL_STEPS / 2; j++) {
+          sh.stage[e[j].y & (RING - 1)][lane] = e[j].x;
+          sh.stage[e[j].w & (RING - 1)][lane] = e[j].z;
         }
       }
     };
     barrier_lds_only();
-    for (u32 i = 0; i < nr_wg; i++) {  // iteration i: what the sink published in iteration i - 1
-      if (i > 0) drain(sh.pub[(i - 1) & 1][lane]);
+    for (u32 i = 0; i < nr_wg; i++) {  // iteration i: the records of round i - 2 (the sink took it in iteration i - 1), then what it published there
+      if (i > 1) apply(i - 2);
+      if (i > 0) drain(inrow ? sh.pub[(i - 1) & 1][lane] : 0u);
       barrier_lds_only();
     }
-    barrier_lds_only();  // the sink's last round is in the ring
+    barrier_lds_only();  // the sink's last round is in the records
     {
-      const u32 lim = sh.pub[nr_wg & 1][lane];
+      if (nr_wg > 1) apply(nr_wg - 2);
+      apply(nr_wg - 1);
+      const u32 lim = inrow ? sh.pub[nr_wg & 1][lane] : 0u;
       drain(lim);
       for (; wo < lim; wo++)
         if (wo < wcap) dst[wo] = word(wo);

@@ -948,7 +948,7 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
   for (;;) {
     u64 tile = 0;
     if (lane == 0) tile = atomicAdd(tile_counter + pass, 1ull);
-    tile = ((u64)__builtin_amdgcn_readfirstlane((u32)(tile >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)tile);
+    tile = ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(tile >> 32)) << 32) | (u64)(u32)__builtin_amdgcn_readfirstlane((u32)tile);
     const u64 tbase = tile * TRI_TILE;
     if (tbase >= n) break;
     const u64 tend = tbase + TRI_TILE < n ? tbase + TRI_TILE : n;

@@ -1950,6 +1950,12 @@ static u32 ac_lanes_used() {
   return (u32)(v < 1 || v > 64 ? 48 : v);
 }
 
+// Sets of four waves per workgroup of ac_encode_lanes_k: 2 = eight waves over 2 x lanes_used blocks on one CU.
+static int ac_lane_sets() {
+  const char *e = getenv("SCALCE_AC_SETS");
+  return e && atoi(e) == 1 ? 1 : 2;
+}
+
 // ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 / 8 = ac_encode_rows_k,
 // 64 = ac_encode_lanes_k (one block per lane).
 // `ps` = the stream the tables were prepared on: the block descriptors are uploaded there (never behind a coder that
@@ -2056,12 +2062,22 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
-    const u32 nwg = cdiv(total, blocks_per_wg == 64 ? ac_lanes_used() : (u32)blocks_per_wg);
-    if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * nwg)); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * nwg)); }
+    const u32 nwg = cdiv(total, blocks_per_wg == 64 ? std::min<u32>(ac_lanes_used(), ac_lane_sets() == 2 ? 48u : 64u) : (u32)blocks_per_wg);  // (sets of four waves)
+    if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * (nwg + 2))); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * (nwg + 2))); }
     if (blocks_per_wg == 64) {
       a.lanes_used = ac_lanes_used();
-      if (getenv("SCALCE_AC_LANES_SHARED")) LAUNCH(ac_encode_lanes_k<false>, cdiv(total, a.lanes_used), 256, 0, s, a);
-      else LAUNCH(ac_encode_lanes_k<true>, cdiv(total, a.lanes_used), 256, 0, s, a);
+      const int sets = ac_lane_sets();
+      a.helper_prio = getenv("SCALCE_AC_LIGHT_PRIO") ? (u32)atoi(getenv("SCALCE_AC_LIGHT_PRIO")) : 2u;
+      a.pairing = getenv("SCALCE_AC_PAIRING") ? (u32)atoi(getenv("SCALCE_AC_PAIRING")) : 0u;
+      if (sets == 2) {  // two sets of four waves per workgroup (kernels_acl.hpp): rows of 48, 40 or 32 lanes
+        if (a.lanes_used > 48) a.lanes_used = 48;
+        const u32 g = cdiv(total, 2 * a.lanes_used);
+        if (a.lanes_used > 40) LAUNCH((ac_encode_lanes_k<true, 2, 48, 3>), g, 512, 0, s, a);
+        else if (a.lanes_used > 32) LAUNCH((ac_encode_lanes_k<true, 2, 40, 4>), g, 512, 0, s, a);
+        else LAUNCH((ac_encode_lanes_k<true, 2, 32, 5>), g, 512, 0, s, a);
+      } else if (getenv("SCALCE_AC_LANES_SHARED")) LAUNCH((ac_encode_lanes_k<false, 1, 64, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);
+      else if (a.lanes_used <= 48) LAUNCH((ac_encode_lanes_k<true, 1, 48, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);  // (rows of 48: LDS for a longer staging ring)
+      else LAUNCH((ac_encode_lanes_k<true, 1, 64, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);
     } else if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
       else LAUNCH((ac_encode_rows_k<false, 8>), cdiv(total, 8), 320, 0, s, a);
