@@ -1692,6 +1692,158 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_lean_k(AcDecCachedArgs a) 
   if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
 }
 
+// ---- decoder, the loop written for the scalar unit (round 4): ac_decode_lean_k in ~45 instructions per symbol --------
+// ac_decode_lean_k's loop is ~80 instructions as the compiler emits it (230 ns per symbol: a lone wavefront issues one
+// instruction in four to five cycles, and the chain of a block is nothing but issue slots): a dozen s_cselect / s_cmp to
+// materialise conditions, renorm_count on the vector unit and back (v_mov, v_bfe, s_nop, v_readfirstlane), two scalar
+// multiplications for the address of the next row, v_cmp + v_cndmask for the output lane, eleven register moves where the
+// two paths of the loop meet.  Here:
+//   * ONE exit test per symbol: s_ff1 of the ballot returns -1 for "no lane" -- j <= 0 covers a code value below or above the
+//     compact row, and the full range too (M = 0 makes every U zero, so no lane answers);
+//   * the LDS offset of the next row is a sum of two per-lane constants read with v_readlane: lane l of a compact row IS
+//     symbol smin - 1 + l, cW[l] = its rank * W * S1 * 8 (as the first symbol of a context), cS[l] = its rank * S1 * 8 (as
+//     the second); a symbol outside the cache carries 2^30, so one comparison says "not in LDS";
+//   * the renormalisation count entirely on the scalar unit (flbit, shift, and, add, flbit), and code - lo moves through
+//     ONE 64-bit shift together with the next bits of the stream ({v - B : window} << t), which also covers t = 0;
+//   * the decoded symbol goes to its output lane with v_writelane;
+//   * the plain path is an inner loop of its own, the generic step (the reference's own registers, as in ac_decode_lean_k)
+//     sits outside it: nothing is copied where they meet.
+// Same arguments, launch shapes and conditions as ac_decode_lean_k (no context total above 2^29, symbol 79 outside the span).
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a) {
+  __shared__ uint2 cache[AC_DEC_CACHE_ENTRIES + 64];
+  const u32 W = a.W, S1 = a.S1;
+  for (u32 i = threadIdx.x; i < W * W * S1; i += blockDim.x) {
+    const u32 slot = i / S1, j = i % S1;
+    const u32 ctx = (u32)a.hot[slot / W] * AC_D + a.hot[slot % W];
+    cache[i] = a.rows[(u64)ctx * S1 + j];
+  }
+  for (u32 i = W * W * S1 + threadIdx.x; i < W * W * S1 + 64; i += blockDim.x) cache[i] = make_uint2(0, 0);
+  __syncthreads();
+  const u32 blk = blockIdx.x * WPB + wave_id();
+  if (blk >= a.nblk) return;
+  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
+  const u32 n = __builtin_amdgcn_readfirstlane((u32)((a.d.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.d.nsym - boff) : (u64)AC_BLOCK_SYMS));
+  const u8 *in = a.d.in + a.d.blk_off[blk];
+  const u32 insz = a.d.blk_size[blk];
+  u8 *out = a.d.out + boff;
+  const int lane = lane_id();
+  u32 p0 = insz > 0 ? in[0] : 0, p1 = insz > 1 ? in[1] : 0;
+  if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
+  if (p0 >= AC_D) p0 = AC_D - 1;
+  if (p1 >= AC_D) p1 = AC_D - 1;
+  p0 = __builtin_amdgcn_readfirstlane(p0);
+  p1 = __builtin_amdgcn_readfirstlane(p1);
+  constexpr u32 FAR = 1u << 30;  // "this symbol's rows are not in LDS"
+  const u32 smin1 = a.smin - 1u;
+  const u32 my_sym = smin1 + (u32)lane;  // (lane 0: the bound below the span, never decoded)
+  const u32 my_rank = (lane >= 1 && (u32)lane < S1 && my_sym < AC_D) ? (u32)a.rank[my_sym] : 0xFFu;
+  const u32 cS = my_rank < W ? my_rank * S1 * 8u : FAR;
+  const u32 cW = my_rank < W ? my_rank * W * S1 * 8u : FAR;
+  const u64 span = S1 >= 64 ? ~0ull : ((1ull << S1) - 1);
+  const u32 lane8 = (u32)lane * 8u;
+  auto off_of = [&](u32 sy, u32 scale) -> u32 {  // sy wave-uniform; only for the two raw symbols and after the generic step
+    const u32 r = sy < AC_D ? (u32)a.rank[sy] : 0xFFu;
+    return r < W ? r * scale : FAR;
+  };
+  typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+  const u32 cache_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) u32x2 *)cache;
+  const SCALCE_GLOBAL u32x2 *rows_g = (const SCALCE_GLOBAL u32x2 *)a.rows;
+  // the row of context (c0, c1): from LDS at offset `off` when off < FAR, else from the row table (padded by 64 entries)
+  auto fetch = [&](u32 c0, u32 c1, u32 off) -> uint2 {
+    if (__builtin_expect(off < FAR, 1)) {
+      const u32x2 x = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(cache_lds + off + lane8);
+      return make_uint2(x.x, x.y);
+    }
+    const u32x2 x = rows_g[(u64)(c0 * AC_D + c1) * S1 + lane];
+    return make_uint2(x.x, x.y);
+  };
+  AcBitReader br;
+  br.start(in, insz, 2, lane);
+  // State as in ac_decode_lean_k: lo, M = hi - lo + 1 (0 stands for 2^32), v = code - lo.
+  u32 lo = 0, M = 0, v = br.get(32, lane);
+  u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
+  u32 qW = off_of(p1, W * S1 * 8u);  // what the last symbol adds to the offset of the NEXT context's row
+  uint2 e = fetch(p0, p1, off_of(p0, W * S1 * 8u) + off_of(p1, S1 * 8u));  // (a sum with FAR in it is >= FAR)
+  u32 i = 2;
+  while (i < n) {
+    // ---- the plain path, symbol after symbol ----
+    bool rare = false;
+    while (i < n) {
+      // U[l] = floor(M * g[l] / 2^64): what symbol l's upper bound adds to lo
+      const u32 U = (u32)(((u64)M * e.y + __umulhi(M, e.x)) >> 32);
+      const u64 m = __ballot(v < U) & span;
+      int j;
+      asm("s_ff1_i32_b64 %0, %1" : "=s"(j) : "s"(m));  // first symbol whose upper bound lies above the code value; -1: none
+      if (__builtin_expect(j <= 0, 0)) { rare = true; break; }
+      const u32 A = (u32)__builtin_amdgcn_readlane(U, j);
+      const u32 B = (u32)__builtin_amdgcn_readlane(U, j - 1);
+      const u32 off = qW + (u32)__builtin_amdgcn_readlane(cS, j);
+      qW = (u32)__builtin_amdgcn_readlane(cW, j);
+      const u32 sidx = smin1 + (u32)j;
+      const uint2 e_next = fetch(p1, sidx, off);  // the next context is known: ask for its row before anything else
+      p0 = p1;
+      p1 = sidx;
+      const u32 nlo = lo + B, D = A - 1u - B;
+      const u32 c = (u32)__builtin_clz(D);                       // D >= 1: every symbol keeps two values or more
+      const u32 t = (u32)__builtin_clz((nlo & (0x7FFFFFFFu >> c)) + D);   // renorm_count, on the scalar unit
+      M = (D + 1u) << t;
+      lo = nlo << t;
+      // {v - B : the next 32 bits of the stream} << t: the high word is the new v (t = 0 .. 32 bits come in)
+      v = (u32)(((((u64)(v - B)) << 32) | (u64)(u32)(br.win >> 32)) << t >> 32);
+      br.win <<= t;
+      br.wb -= t;
+      if (__builtin_expect(br.wb <= 32, 0)) br.refill(lane);
+      asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(outacc) : "s"(sidx), "s"(i & 63u) : "m0");
+      if (__builtin_expect((i & 63u) == 63u, 0)) out[(i & ~63u) + lane] = (u8)outacc;
+      e = e_next;
+      i++;
+    }
+    if (!rare) break;
+    // ---- below or above the symbols the compact rows hold, the last symbol of a context, the full range: the full row,
+    // on the reference's own registers (lo without the stray bit, hi, code), exactly as ac_decode_lean_k ----
+    {
+      if (M == 0u) lo = 0u;
+      else if ((u32)(lo + M - 1u) < lo) lo ^= 0x80000000u;
+      u32 hi = lo + M - 1u, code = lo + v;
+      const u32 R = hi - lo, vv = code - lo;
+      bool is_last = false;
+      u32 A, B, sidx;
+      const uint4 *row = a.d.tab + (u64)(p0 * AC_D + p1) * AC_D;
+      const uint4 f0 = row[lane];
+      const uint4 f1 = lane < 16 ? row[64 + lane] : make_uint4(0, 0, 0, 0);
+      const bool last0 = f0.w == 0xFFFFFFFFu, last1 = f1.w == 0xFFFFFFFFu;
+      const u32 U0 = mulfrac(R, f0.z, f0.w), U1 = mulfrac(R, f1.z, f1.w);
+      const u64 m0 = __ballot(last0 || vv < U0);
+      const u64 m1 = __ballot(lane < 16 && (last1 || vv < U1));
+      if (m0) {
+        sidx = (u32)__ffsll((long long)m0) - 1;
+        A = (u32)__builtin_amdgcn_readlane(U0, sidx);
+        is_last = __builtin_amdgcn_readlane((u32)last0, sidx) != 0;
+        B = sidx ? (u32)__builtin_amdgcn_readlane(U0, sidx - 1) : 0u;
+      } else {
+        const u32 t = m1 ? (u32)__ffsll((long long)m1) - 1 : 15u;  // corrupt stream: last symbol
+        sidx = 64 + t;
+        A = (u32)__builtin_amdgcn_readlane(U1, t);
+        is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
+        B = t ? (u32)__builtin_amdgcn_readlane(U1, t - 1) : (u32)__builtin_amdgcn_readlane(U0, 63);
+      }
+      p0 = p1;
+      p1 = sidx;
+      qW = off_of(p1, W * S1 * 8u);
+      e = fetch(p0, p1, off_of(p0, W * S1 * 8u) + off_of(p1, S1 * 8u));
+      ac_dec_renorm(lo, hi, code, lo + B, is_last ? hi : lo + A - 1, br, lane);
+      M = hi - lo + 1u;
+      v = code - lo;
+      outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
+      if ((i & 63) == 63) out[(i & ~63u) + lane] = (u8)outacc;
+      i++;
+    }
+  }
+  const u32 done = n & ~63u;
+  if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
+}
+
 // ---- self-test: closed-form step vs the reference's literal loop, on random and crafted states ------
 __device__ __forceinline__ u32 mix32(u32 x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;

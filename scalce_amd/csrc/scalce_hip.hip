@@ -1946,14 +1946,17 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool f
 // trade (ms per shard at 32 / 40 / 48 / 56 / 64 blocks: 107.0 / 106.6 / 102.4 / 108.0 / 115.5).
 static u32 ac_lanes_used() {
   const char *e = getenv("SCALCE_AC_LANES_USED");
-  const int v = e ? atoi(e) : 48;
-  return (u32)(v < 1 || v > 64 ? 48 : v);
+  const int v = e ? atoi(e) : 40;  // (round 4, with the ring stores in the writer wave: 79.9 / 80.0 / 81.1 / 81.7 / 82.2 / 85.6 ms per shard at 32 / 36 / 40 / 44 / 48 / 56)
+  return (u32)(v < 1 || v > 64 ? 40 : v);
 }
 
-// Sets of four waves per workgroup of ac_encode_lanes_k: 2 = eight waves over 2 x lanes_used blocks on one CU.
+// Sets of four waves per workgroup of ac_encode_lanes_k: 2 = eight waves over 2 x lanes_used blocks on one CU -- two thirds of
+// the CU-seconds of a launch and 35 % more latency (730 against 541 ms for three shards alone).  With twelve shards in
+// flight the pipeline is bound by the latency of a launch (slots / latency), so one set is the default:
+// 111 against 87 ms per shard at the driver's 20 steps (tools/sets_bench_r4.sh).
 static int ac_lane_sets() {
   const char *e = getenv("SCALCE_AC_SETS");
-  return e && atoi(e) == 1 ? 1 : 2;
+  return e && atoi(e) == 2 ? 2 : 1;
 }
 
 // ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 / 8 = ac_encode_rows_k,
@@ -2790,7 +2793,12 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
         max_total = std::max(max_total, t);
       }
       const bool lean = max_total <= (1ull << 29) && !getenv("SCALCE_AC_DECODE_NO_LEAN");
-      if (lean) {
+      if (lean && !getenv("SCALCE_AC_DECODE_NO_TIGHT")) {  // the same step with its loop written for the scalar unit
+        if (wpb == 2) LAUNCH(ac_decode_tight_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+        else if (wpb == 4) LAUNCH(ac_decode_tight_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
+        else if (wpb == 16) LAUNCH(ac_decode_tight_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
+        else LAUNCH(ac_decode_tight_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
+      } else if (lean) {
         if (wpb == 2) LAUNCH(ac_decode_lean_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
         else if (wpb == 4) LAUNCH(ac_decode_lean_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
         else if (wpb == 16) LAUNCH(ac_decode_lean_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);

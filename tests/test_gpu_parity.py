@@ -764,6 +764,50 @@ def test_coder_long_underflow_runs_and_carries(blocks_per_wave, ctx, monkeypatch
 
 
 @pytest.mark.gpu
+def test_lanes_coder_shapes_write_the_same_bytes(ctx, monkeypatch):
+    """ac_encode_lanes_k in every shape of its workgroup -- one set of four waves over rows of 48 or 64 lanes, two sets over
+    rows of 48, 40 and 32 (eight waves, two per SIMD; kernels_acl.hpp) -- and with every seventh round forced through the
+    redo path: 130 blocks (more than one workgroup in every shape, a last workgroup that is partly empty, a last block that
+    is short), crafted carries at the start of two of them.  All shapes against the first, and the first block of the
+    stream -- which holds the crafted symbols -- against the oracle's bytes."""
+    import hashlib
+    import torch
+    from gpu_util import craft_straddle
+    monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", "64")
+    rng = np.random.default_rng(11)
+    row = np.ones(80, dtype=np.uint32)
+    row[8:40] = 1000
+    cum = np.concatenate([[0], np.cumsum(row)])
+    BLK = 10 * 1024 * 1024
+    nsym = 129 * BLK + 77_777
+    g = torch.Generator(device="cuda:0"); g.manual_seed(3)
+    d_sym = torch.randint(8, 40, (nsym + 64,), dtype=torch.uint8, device="cuda:0", generator=g)
+    part, maxpend = craft_straddle(40_000, cum, int(cum[-1]), rng)
+    assert maxpend > 64
+    for start in (0, 97 * BLK):
+        d_sym[start:start + len(part)] = torch.from_numpy(part).to("cuda:0")
+    table = np.tile(row, 6400)
+    d_tab = torch.from_numpy(table.view(np.int32)).to("cuda:0")
+    first = d_sym[:BLK].cpu().numpy()
+    want0 = O.AcStat(table).encode_stream(first)
+    ref = None
+    for sets, lanes, poison in (("1", "48", "0"), ("1", "64", "0"), ("2", "48", "0"), ("2", "40", "0"), ("2", "32", "7"), ("1", "40", "7")):
+        monkeypatch.setenv("SCALCE_AC_SETS", sets)
+        monkeypatch.setenv("SCALCE_AC_LANES_USED", lanes)
+        monkeypatch.setenv("SCALCE_AC_TEST_POISON", poison)
+        b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
+        b.entropy_stream(0, d_tab.data_ptr(), d_sym.data_ptr(), nsym)
+        b.finish()
+        enc = b.output(host.OUT_QUAL, 0)
+        if ref is None:
+            assert (enc[:len(want0)] == want0).all(), "the first block differs from the oracle's"
+            ref = (len(enc), hashlib.sha256(enc.tobytes()).hexdigest())
+        else:
+            assert (len(enc), hashlib.sha256(enc.tobytes()).hexdigest()) == ref, f"sets {sets}, rows of {lanes} lanes: other bytes"
+        b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nsym", [1, 2, 3, 15, 16, 17, 33, 10 * 1024 * 1024, 10 * 1024 * 1024 + 1, 10 * 1024 * 1024 + 2])
 def test_lanes_coder_block_edges(nsym, ctx, monkeypatch):
     """One block per lane: blocks of 1, 2 and 3 symbols (nothing but the raw symbols and the flush), a round that is

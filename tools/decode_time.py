@@ -22,8 +22,11 @@ out = torch.zeros(nsym, dtype=torch.uint8, device=dev)
 qp, qn = b.output_ptr(host.OUT_QSTREAM, 0)
 want = torch.empty(nsym, dtype=torch.uint8, device=dev)
 ctx.copy_d2d(want.data_ptr(), qp, qn, 0)
-for name, env in (("compact rows + LDS cache", None), ("plain kernel", "1")):
-    if env: os.environ["SCALCE_AC_DECODE_PLAIN"] = env
+variants = (("tight loop (round 4)", {}), ("lean (compiler's loop)", {"SCALCE_AC_DECODE_NO_TIGHT": "1"}), ("plain kernel", {"SCALCE_AC_DECODE_PLAIN": "1"}))
+if len(sys.argv) > 2:
+    variants = variants[:int(sys.argv[2])]
+for name, env in variants:
+    os.environ.update(env)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ctx.ac_decode(table, p, nb, nsym, out.data_ptr())
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
