@@ -1709,6 +1709,9 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_lean_k(AcDecCachedArgs a) 
 //   * the plain path is an inner loop of its own, the generic step (the reference's own registers, as in ac_decode_lean_k)
 //     sits outside it: nothing is copied where they meet.
 // Same arguments, launch shapes and conditions as ac_decode_lean_k (no context total above 2^29, symbol 79 outside the span).
+#ifndef AC_DEC_TIGHT_CXX
+#define AC_DEC_TIGHT_CXX 0  // 1: the plain path as the compiler schedules it (comparison; 178 ns per symbol)
+#endif
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a) {
   __shared__ uint2 cache[AC_DEC_CACHE_ENTRIES + 64];
@@ -1720,7 +1723,7 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
   }
   for (u32 i = W * W * S1 + threadIdx.x; i < W * W * S1 + 64; i += blockDim.x) cache[i] = make_uint2(0, 0);
   __syncthreads();
-  const u32 blk = blockIdx.x * WPB + wave_id();
+  const u32 blk = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + wave_id());  // (uniform to the compiler as well: pointers and sizes in SGPRs)
   if (blk >= a.nblk) return;
   const u64 boff = (u64)blk * AC_BLOCK_SYMS;
   const u32 n = __builtin_amdgcn_readfirstlane((u32)((a.d.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.d.nsym - boff) : (u64)AC_BLOCK_SYMS));
@@ -1768,14 +1771,138 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
   u32 i = 2;
   while (i < n) {
     // ---- the plain path, symbol after symbol ----
-    bool rare = false;
-    while (i < n) {
+    u32 rare = 0;
+    if (!AC_DEC_TIGHT_CXX) {
+      // The loop by hand: 46 instructions per symbol (the compiler's version of the same statements, below: 59 -- where its
+      // paths meet it copies the state from register to register and turns conditions into masks and back).  Fixed
+      // registers, so that the halves of a 64-bit pair can be named: s40 i, s41 lo, s42 M, s57 v (the high half of the pair
+      // that takes in the stream's bits), s44 qW, s45 p1, s60 p0, s46 / s47 / s[48:49] the bit reader's wb / wi / window,
+      // s61 the loop's bound, v[106:107] the row entry of this lane.  Leaves the loop: at i = n (reason 0), in front of a
+      // symbol the plain step cannot take (reason 1, nothing of the state touched), behind the symbol whose refill used up
+      // the reader's 64-word window (the bound is pulled in to i + 1: reason 0 with wi = 64).
+      // (every scalar through v_readfirstlane: to the compiler some of them depend on the lane -- they never do)
+      auto rfl = [](u32 x) -> u32 { return (u32)__builtin_amdgcn_readfirstlane(x); };
+      auto rfl64 = [&](u64 x) -> u64 { return ((u64)rfl((u32)(x >> 32)) << 32) | (u64)rfl((u32)x); };
+      u32 win_lo = rfl((u32)br.win), win_hi = rfl((u32)(br.win >> 32));
+      u32 zi = rfl(i), zlo = rfl(lo), zM = rfl(M), zv = rfl(v), zqW = rfl(qW), zp1 = rfl(p1), zp0 = rfl(p0), zwb = rfl(br.wb), zwi = rfl(br.wi);
+      const u64 zout = rfl64((u64)(uintptr_t)out), zrows = rfl64((u64)(uintptr_t)rows_g), zspan = rfl64(span);
+      const u32 zn = rfl(n), zsmin1 = rfl(smin1), zS1 = rfl(S1);
+      asm volatile(
+          "s_mov_b32 s40, %[i]\n\ts_mov_b32 s41, %[lo]\n\ts_mov_b32 s42, %[M]\n\ts_mov_b32 s57, %[v]\n\ts_mov_b32 s44, %[qW]\n\t"
+          "s_mov_b32 s45, %[p1]\n\ts_mov_b32 s60, %[p0]\n\ts_mov_b32 s46, %[wb]\n\ts_mov_b32 s47, %[wi]\n\t"
+          "s_mov_b32 s48, %[wlo]\n\ts_mov_b32 s49, %[whi]\n\ts_mov_b32 s61, %[n]\n\t"
+          "v_mov_b32 v106, %[ex]\n\tv_mov_b32 v107, %[ey]\n\tv_mov_b32 v101, 0\n\ts_mov_b32 %[rare], 0\n\ts_mov_b32 s68, m0\n"
+          "Ltop_%=:\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_mul_hi_u32 v100, s42, v106\n\t"
+          "v_mad_u64_u32 v[102:103], s[64:65], s42, v107, v[100:101]\n\t"
+          "v_cmp_lt_u32_e32 vcc, s57, v103\n\t"
+          "s_and_b64 s[62:63], vcc, %[span]\n\t"
+          "s_ff1_i32_b64 s50, s[62:63]\n\t"
+          "s_cmp_lt_i32 s50, 1\n\t"
+          "s_cbranch_scc1 Lgeneric_%=\n\t"
+          "s_add_i32 s59, s50, -1\n\t"
+          "v_readlane_b32 s51, v103, s50\n\t"
+          "v_readlane_b32 s52, v103, s59\n\t"
+          "v_readlane_b32 s53, %[cS], s50\n\t"
+          "s_add_u32 s53, s53, s44\n\t"
+          "v_readlane_b32 s44, %[cW], s50\n\t"
+          "s_add_i32 s54, s50, %[smin1]\n\t"
+          "s_cmp_ge_u32 s53, 0x40000000\n\t"
+          "s_cbranch_scc1 Lfar_%=\n\t"
+          "v_add_u32_e32 v104, s53, %[ldsb]\n\t"
+          "ds_read_b64 v[106:107], v104\n"
+          "Lhave_%=:\n\t"
+          "s_mov_b32 s60, s45\n\t"
+          "s_mov_b32 s45, s54\n\t"
+          "s_add_u32 s41, s41, s52\n\t"
+          "s_not_b32 s59, s52\n\t"
+          "s_add_u32 s55, s51, s59\n\t"
+          "s_flbit_i32_b32 s59, s55\n\t"
+          "s_lshr_b32 s59, 0x7fffffff, s59\n\t"
+          "s_and_b32 s59, s59, s41\n\t"
+          "s_add_u32 s59, s59, s55\n\t"
+          "s_flbit_i32_b32 s58, s59\n\t"
+          "s_add_u32 s42, s55, 1\n\t"
+          "s_lshl_b32 s42, s42, s58\n\t"
+          "s_lshl_b32 s41, s41, s58\n\t"
+          "s_sub_u32 s57, s57, s52\n\t"
+          "s_mov_b32 s56, s49\n\t"
+          "s_lshl_b64 s[56:57], s[56:57], s58\n\t"
+          "s_lshl_b64 s[48:49], s[48:49], s58\n\t"
+          "s_sub_u32 s46, s46, s58\n\t"
+          "s_cmp_le_u32 s46, 32\n\t"
+          "s_cbranch_scc1 Lrefill_%=\n"
+          "Lrefilled_%=:\n\t"
+          "s_and_b32 m0, s40, 63\n\t"
+          "v_writelane_b32 %[outacc], s54, m0\n\t"
+          "s_cmp_eq_u32 m0, 63\n\t"
+          "s_cbranch_scc1 Lstore_%=\n"
+          "Lstored_%=:\n\t"
+          "s_add_u32 s40, s40, 1\n\t"
+          "s_cmp_lt_u32 s40, s61\n\t"
+          "s_cbranch_scc1 Ltop_%=\n\t"
+          "s_branch Lout_%=\n"
+          "Lrefill_%=:\n\t"                       // wb <= 32: the next word of the window behind the bits held
+          "v_readlane_b32 s66, %[wcur], s47\n\t"
+          "s_mov_b32 s67, 0\n\t"
+          "s_sub_u32 s59, 32, s46\n\t"
+          "s_lshl_b64 s[66:67], s[66:67], s59\n\t"
+          "s_or_b64 s[48:49], s[48:49], s[66:67]\n\t"
+          "s_add_u32 s46, s46, 32\n\t"
+          "s_add_u32 s47, s47, 1\n\t"
+          "s_cmp_eq_u32 s47, 64\n\t"
+          "s_cbranch_scc0 Lrefilled_%=\n\t"
+          "s_add_u32 s61, s40, 1\n\t"            // the window is used up: this symbol is the last of the run
+          "s_branch Lrefilled_%=\n"
+          "Lstore_%=:\n\t"                        // 64 symbols, one per lane
+          "s_and_b32 s59, s40, 0xffffffc0\n\t"
+          "v_or_b32_e32 v104, s59, %[lane]\n\t"
+          "global_store_byte v104, %[outacc], %[out]\n\t"
+          "s_branch Lstored_%=\n"
+          "Lfar_%=:\n\t"                          // the next context's row is not in LDS: from the row table
+          "s_mul_i32 s59, s45, 0x50\n\t"
+          "s_add_u32 s59, s59, s54\n\t"
+          "s_mul_i32 s59, s59, %[S1]\n\t"
+          "v_add_u32_e32 v104, s59, %[lane]\n\t"
+          "v_lshlrev_b32_e32 v104, 3, v104\n\t"
+          "global_load_dwordx2 v[106:107], v104, %[rows]\n\t"
+          "s_waitcnt vmcnt(0)\n\t"
+          "s_branch Lhave_%=\n"
+          "Lgeneric_%=:\n\t"
+          "s_mov_b32 %[rare], 1\n"
+          "Lout_%=:\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "s_mov_b32 m0, s68\n\t"
+          "s_mov_b32 %[i], s40\n\ts_mov_b32 %[lo], s41\n\ts_mov_b32 %[M], s42\n\ts_mov_b32 %[v], s57\n\ts_mov_b32 %[qW], s44\n\t"
+          "s_mov_b32 %[p1], s45\n\ts_mov_b32 %[p0], s60\n\ts_mov_b32 %[wb], s46\n\ts_mov_b32 %[wi], s47\n\t"
+          "s_mov_b32 %[wlo], s48\n\ts_mov_b32 %[whi], s49\n\t"
+          "v_mov_b32 %[ex], v106\n\tv_mov_b32 %[ey], v107\n"
+          : [i] "+s"(zi), [lo] "+s"(zlo), [M] "+s"(zM), [v] "+s"(zv), [qW] "+s"(zqW), [p1] "+s"(zp1), [p0] "+s"(zp0), [wb] "+s"(zwb),
+            [wi] "+s"(zwi), [wlo] "+s"(win_lo), [whi] "+s"(win_hi), [ex] "+v"(e.x), [ey] "+v"(e.y), [outacc] "+v"(outacc),
+            [rare] "=&s"(rare)
+          : [n] "s"(zn), [span] "s"(zspan), [smin1] "s"(zsmin1), [S1] "s"(zS1), [out] "s"(zout), [rows] "s"(zrows), [cS] "v"(cS),
+            [cW] "v"(cW), [ldsb] "v"(cache_lds + lane8), [wcur] "v"(br.wcur), [lane] "v"((u32)lane)
+          : "memory", "vcc", "scc", "s68", "s40", "s41", "s42", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+            "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "v100", "v101", "v102",
+            "v103", "v104", "v106", "v107");
+      i = zi; lo = zlo; M = zM; v = zv; qW = zqW; p1 = zp1; p0 = zp0; br.wb = zwb; br.wi = zwi;
+      br.win = ((u64)win_hi << 32) | win_lo;
+      if (br.wi == 64) {  // (AcBitReader::refill's other half: the next 64 words of the block)
+        br.wi = 0;
+        br.base += 256;
+        br.wcur = br.wnext;
+        br.wnext = br.load_window(br.base + 256, lane);
+      }
+      if (!rare) continue;
+    }
+    while (AC_DEC_TIGHT_CXX && i < n) {
       // U[l] = floor(M * g[l] / 2^64): what symbol l's upper bound adds to lo
       const u32 U = (u32)(((u64)M * e.y + __umulhi(M, e.x)) >> 32);
       const u64 m = __ballot(v < U) & span;
       int j;
       asm("s_ff1_i32_b64 %0, %1" : "=s"(j) : "s"(m));  // first symbol whose upper bound lies above the code value; -1: none
-      if (__builtin_expect(j <= 0, 0)) { rare = true; break; }
+      if (__builtin_expect(j <= 0, 0)) { rare = 1; break; }
       const u32 A = (u32)__builtin_amdgcn_readlane(U, j);
       const u32 B = (u32)__builtin_amdgcn_readlane(U, j - 1);
       const u32 off = qW + (u32)__builtin_amdgcn_readlane(cS, j);
@@ -1789,12 +1916,12 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
       const u32 t = (u32)__builtin_clz((nlo & (0x7FFFFFFFu >> c)) + D);   // renorm_count, on the scalar unit
       M = (D + 1u) << t;
       lo = nlo << t;
-      // {v - B : the next 32 bits of the stream} << t: the high word is the new v (t = 0 .. 32 bits come in)
+      // {v - B : the next 32 bits of the stream} << t: the high word is the new v (t = 0 .. 31 bits come in)
       v = (u32)(((((u64)(v - B)) << 32) | (u64)(u32)(br.win >> 32)) << t >> 32);
       br.win <<= t;
       br.wb -= t;
       if (__builtin_expect(br.wb <= 32, 0)) br.refill(lane);
-      asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(outacc) : "s"(sidx), "s"(i & 63u) : "m0");
+      asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(outacc) : "s"(sidx), "s"(i & 63u));  // (M0 holds nothing in this kernel)
       if (__builtin_expect((i & 63u) == 63u, 0)) out[(i & ~63u) + lane] = (u8)outacc;
       e = e_next;
       i++;
