@@ -26,8 +26,8 @@ extern "C" {
 #define SCALCE_ERR_HIP 2       /* HIP runtime failure (message in scalce_last_error) */
 #define SCALCE_ERR_FORMAT 3    /* malformed input: the cases where the reference prints (ERROR) and exits */
 #define SCALCE_ERR_CAPACITY 4  /* batch larger than the capacity it was created with */
-#define SCALCE_ERR_UNCUT 5     /* scalce_sharded_compress: -B does not cut the run anywhere, so no rank boundary can sit on a chunk
-                                  boundary; every rank returns it together -- run the input on one GPU instead */
+#define SCALCE_ERR_UNCUT 5     /* (rounds 1-3: scalce_sharded_compress refused a run that -B does not cut anywhere.  Since round 4 such
+                                  a run -- one spill chunk -- goes to rank 0 as a whole and the code is no longer returned.) */
 
 #define SCALCE_AC_DEPTH 80                  /* arithmetic.h:47 */
 #define SCALCE_AC_BLOCK (10 * 1024 * 1024)  /* arithmetic.cpp:48 */

@@ -13,7 +13,8 @@
 //   coder blocks    arithmetic.cpp:318-363 cut every 10 MiB of the RUN-WIDE reordered stream: one all-to-all of q' bytes
 //                                         into contiguous block ranges (~ L bytes per read, 7/8 of it leaves the rank)
 // With rank boundaries ON chunk boundaries, "inside a bucket: rank 0's records, rank 1's, ..." is exactly the merge order
-// of compress.cpp:104-159, so the archive equals the one-GPU archive and the reference's at -T 1 with the same -B.
+// of compress.cpp:104-159, so the archive equals the one-GPU archive and the reference's at -T 1 with the same -B.  A run
+// that -B does not cut at all is one chunk: its rows all go to rank 0 (scalce_shard_plan_boundaries).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -127,12 +128,18 @@ template <typename T> std::vector<T> gather_host(scalce_comm *comm, const T *min
 // Host-only plan math, exported so that it can be checked without a GPU -------------------------------------------------
 // Rank boundaries g[0..world] (run-wide row of every rank's first record, g[world] = rows of the run) move to the nearest
 // cut of the run-wide -B rule; gn[] = the moved boundaries (non-decreasing; ranks may end up without records when chunks are
-// larger than a rank's share).  Returns SCALCE_ERR_CAPACITY when the run has no cut to move to.
+// larger than a rank's share).  A run without any cut is ONE chunk -- less than -B bytes of records, what the reference keeps
+// in memory as one bucket set (compress.cpp:708-715) and sorts bucket by bucket as a whole (reads.cpp:547-634): all its rows
+// go to rank 0, whose order and emit stages then ARE the merge of every bucket across the ranks (round 4; rounds 1-3 refused
+// such a run with SCALCE_ERR_UNCUT).  The other ranks keep their share of the quality statistics and of the coder's blocks.
 extern "C" int scalce_shard_plan_boundaries(int world, const uint64_t *g, const uint64_t *cuts_sorted, uint64_t ncuts, uint64_t *gn) {
   if (world < 1 || !g || !gn || (ncuts && !cuts_sorted)) return SCALCE_ERR_ARG;
   for (int r = 0; r <= world; r++) gn[r] = g[r];
+  if (!ncuts) {
+    for (int r = 1; r < world; r++) gn[r] = g[world];
+    return SCALCE_OK;
+  }
   for (int r = 1; r < world; r++) {
-    if (!ncuts) return SCALCE_ERR_CAPACITY;
     const uint64_t *end = cuts_sorted + ncuts, *it = std::lower_bound(cuts_sorted, end, g[r]);
     uint64_t best = it == end ? cuts_sorted[ncuts - 1] : *it;
     if (it != cuts_sorted) { const uint64_t lo = *(it - 1); if (best < g[r] || g[r] - lo <= best - g[r]) best = lo; }
@@ -351,8 +358,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     {
       const int prc = scalce_shard_plan_boundaries(W, g.data(), cuts_global.data(), cuts_global.size(), gn.data());
       // (every rank computes the same plan from the same cuts: they all leave here together)
-      if (prc) throw Fail{"a sharded run needs a -B that cuts the run: no spill chunk ends inside it, so the records of a bucket "
-                          "would have to be merged across ranks", SCALCE_ERR_UNCUT};
+      if (prc) throw Fail{"internal: rank boundaries could not be planned", SCALCE_ERR_ARG};
     }
     auto clampu = [](u64 x, u64 a, u64 b) { return x < a ? a : (x > b ? b : x); };
     res->first_read = gn[rank];

@@ -256,16 +256,16 @@ def test_cli_long_reads_two_byte_end_marker(tmp_path):
     assert open(tmp_path / "back_1.fastq", "rb").read() == open(tmp_path / "oback_1.fastq", "rb").read()
 
 
-def test_cli_gpus_run_that_B_does_not_cut_goes_to_one_gpu(tmp_path, monkeypatch):
-    """A run shorter than one spill chunk has no chunk boundary for a rank boundary to sit on (compress.cpp:708-715): the
-    ranks find that out together, nothing is written, and the same command goes on with one GPU -- a warning, never an
-    (ERROR) -- to the archive the oracle writes."""
+def test_cli_gpus_run_that_B_does_not_cut_is_one_chunk_on_rank_0(tmp_path, monkeypatch):
+    """A run shorter than one spill chunk has no chunk boundary for a rank boundary to sit on (compress.cpp:708-715): it is
+    ONE chunk, all its rows go to rank 0 (whose order stage then is the merge of every bucket across the ranks), the other
+    ranks keep their share of the statistics and of the coder's blocks -- no fallback, no (ERROR), the oracle's archive."""
     monkeypatch.setenv("SCALCE_COMM", "shm")
     n, L = 20000, 100
     b1, q1 = synth.reads_and_quals(n, L, seed=91, n_frac=0.003, dup_frac=0.1)
     open(tmp_path / "in_1.fq", "wb").write(synth.fastq_bytes_fast(b1, q1))
     r = run_cli("-c", "no", "--gpus", 2, "-o", tmp_path / "hip", tmp_path / "in_1.fq", "--patterns-bin", PBIN)   # default -B 4G
-    assert "compressing on one GPU" in r.stderr and "(ERROR)" not in r.stderr, r.stderr[-600:]
+    assert "compressing on one GPU" not in r.stderr and "(ERROR)" not in r.stderr, r.stderr[-600:]
     O.orc_cli("compress", PBIN, tmp_path / "in_1.fq", tmp_path / "orc")
     for ext in "nrq":
         assert open(tmp_path / f"orc_1.scalce{ext}", "rb").read() == open(tmp_path / f"hip_1.scalce{ext}", "rb").read(), ext

@@ -83,7 +83,7 @@ def split_records(text, cuts):
     return [text[ends[i]:ends[i + 1]] for i in range(len(ends) - 1)]
 
 
-@pytest.mark.parametrize("case", ["se100_w2", "pe150_lossy_w3", "ties36_w4", "tiny_rank_w3", "empty_rank_w3", "rccl_w1"])
+@pytest.mark.parametrize("case", ["se100_w2", "pe150_lossy_w3", "ties36_w4", "tiny_rank_w3", "empty_rank_w3", "rccl_w1", "uncut_w3", "uncut_pe_w2"])
 def test_sharded_archive_equals_one_batch(case, tmp_path, patterns_blob):
     from gpu_util import device_bytes
     paired, L, n, world, B, ptxt, lossy, rccl = False, 100, 60000, 2, 1_500_000, None, 0, False
@@ -98,6 +98,10 @@ def test_sharded_archive_equals_one_batch(case, tmp_path, patterns_blob):
         world, n, B = 3, 50000, 1_000_000
     elif case == "rccl_w1":
         world, n, rccl = 1, 30000, True
+    elif case == "uncut_w3":      # -B larger than the run: ONE chunk, every bucket merged across the ranks (all rows to rank 0)
+        world, n, B = 3, 45000, 1 << 30
+    elif case == "uncut_pe_w2":
+        paired, L, n, world, B = True, 150, 20000, 2, 1 << 30
     bases, quals = synth.reads_and_quals(n, L, seed=131, dup_frac=0.15, n_frac=0.003)
     texts = [synth.fastq_bytes_fast(bases, quals, prefix="p." if paired else "s.", suffix="/1" if paired else "")]
     if paired:

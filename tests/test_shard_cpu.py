@@ -93,7 +93,8 @@ def test_boundaries_move_to_the_nearest_cut():
     assert plan([0, 100, 200], [60, 140]) == (0, [0, 60, 200])                 # a tie goes to the earlier cut
     assert plan([0, 10, 20, 30], [20]) == (0, [0, 20, 20, 30])                 # rank 1 ends up without records
     assert plan([0, 100], []) == (0, [0, 100])                                 # one rank: nothing to move
-    assert plan([0, 100, 200], [])[0] != 0                                     # two ranks and no cut: refused
+    assert plan([0, 100, 200], []) == (0, [0, 200, 200])                       # no cut at all: one chunk, all of it to rank 0
+    assert plan([0, 10, 20, 30, 40], []) == (0, [0, 40, 40, 40, 40])
     assert plan([0, 10, 20, 30, 40], [35]) == (0, [0, 35, 35, 35, 40])         # one cut for three boundaries: two ranks end up empty
 
 
