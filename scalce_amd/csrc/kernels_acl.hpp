@@ -211,7 +211,7 @@ struct AclSink {
 template <int LW, int SLOTS, int RINGW>
 struct AclShared {
   uint4 ops[SLOTS][ACL_STEPS][LW];      // gather -> chain: operands of a round (slot = round % SLOTS), written by LDS-direct loads
-  uint4 rec[2][ACL_STEPS / 2][LW];      // chain -> sink: (B, Q) of two steps of a round per entry
+  uint4 rec[2][ACL_STEPS / 2][LW];      // chain -> sink: (Q, B) of two steps of a round per entry
   uint4 fifo[2][ACL_STEPS / 2][LW];     // sink -> writer: (val, wq) of two steps per entry (AclSink::step)
   u32 stage[RINGW][LW];                 // writer: coded words on their way out -- word k of the block in slot (k + 1) & (WORDS - 1)
   u32 pub[2][LW];                       // sink -> writer: words below this index are final
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
           u32 B, t;
           acl_step_plain(lo, M, g[j], ones, zero, B, t);
           Q += t;
-          if (j & 1) sh.rec[r & 1][j >> 1][lane] = make_uint4(Bp, Qp, B, Q);
+          if (j & 1) sh.rec[r & 1][j >> 1][lane] = make_uint4(Qp, Bp, Q, B);  // (Q, B): B is the HIGH word of its product's register pair -- an odd register, as .y and .w are; the other order cost two v_mov per step
           else { Bp = B; Qp = Q; }
           topw = g[j].w > topw ? g[j].w : topw;
         }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
               u32 B = 0, t = 0;
               if (j >= jstart && j < jend) acl_step_general(glo, ghi, gj, B, t);
               gq += t;
-              if (j & 1u) sh.rec[r & 1][j >> 1][lane] = make_uint4(Bp, Qp, B, gq);
+              if (j & 1u) sh.rec[r & 1][j >> 1][lane] = make_uint4(Qp, Bp, gq, B);
               else { Bp = B; Qp = gq; }
             }
             lo = glo;
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
 #pragma unroll
           for (int j = 0; j < ACL_STEPS / 2; j++) {
             uint4 o;
-            sk.step(v[j].x, v[j].y, o.x, o.y);
-            sk.step(v[j].z, v[j].w, o.z, o.w);
+            sk.step(v[j].y, v[j].x, o.x, o.y);
+            sk.step(v[j].w, v[j].z, o.z, o.w);
             sh.fifo[r & 1][j][lane] = o;
           }
           if (__builtin_expect(__any(sk.ncar == 0u), 0)) {
@@ -492,8 +492,8 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
 #pragma unroll 1
               for (int j = 0; j < ACL_STEPS / 2; j++) {
                 const uint4 x = sh.rec[r & 1][j][lane];
-                sk.careful(x.x, x.y);
-                sk.careful(x.z, x.w);
+                sk.careful(x.y, x.x);
+                sk.careful(x.w, x.z);
               }
             }
           }
