@@ -1773,7 +1773,7 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
     // ---- the plain path, symbol after symbol ----
     u32 rare = 0;
     if (!AC_DEC_TIGHT_CXX) {
-      // The loop by hand: 46 instructions per symbol (the compiler's version of the same statements, below: 59 -- where its
+      // The loop by hand: 46 instructions per symbol, the next row's LDS read issued as early as the recurrence allows (the compiler's version of the same statements, below: 59 -- where its
       // paths meet it copies the state from register to register and turns conditions into masks and back).  Fixed
       // registers, so that the halves of a 64-bit pair can be named: s40 i, s41 lo, s42 M, s57 v (the high half of the pair
       // that takes in the stream's bits), s44 qW, s45 p1, s60 p0, s46 / s47 / s[48:49] the bit reader's wb / wi / window,
@@ -1799,43 +1799,50 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
           "v_cmp_lt_u32_e32 vcc, s57, v103\n\t"
           "s_and_b64 s[62:63], vcc, %[span]\n\t"
           "s_ff1_i32_b64 s50, s[62:63]\n\t"
-          "s_cmp_lt_i32 s50, 1\n\t"
-          "s_cbranch_scc1 Lgeneric_%=\n\t"
-          "s_add_i32 s59, s50, -1\n\t"
-          "v_readlane_b32 s51, v103, s50\n\t"
-          "v_readlane_b32 s52, v103, s59\n\t"
+          // the next row is asked for before anything else is looked at -- the recurrence of a block is row -> U -> j -> row.
+          // With j = -1 or 0 (the generic step's business) or a context outside the cache the address is nonsense: LDS
+          // answers a read beyond its end with zeros, and both ways out fetch the row again before anybody reads it.
           "v_readlane_b32 s53, %[cS], s50\n\t"
           "s_add_u32 s53, s53, s44\n\t"
-          "v_readlane_b32 s44, %[cW], s50\n\t"
-          "s_add_i32 s54, s50, %[smin1]\n\t"
-          "s_cmp_ge_u32 s53, 0x40000000\n\t"
-          "s_cbranch_scc1 Lfar_%=\n\t"
           "v_add_u32_e32 v104, s53, %[ldsb]\n\t"
-          "ds_read_b64 v[106:107], v104\n"
-          "Lhave_%=:\n\t"
-          "s_mov_b32 s60, s45\n\t"
-          "s_mov_b32 s45, s54\n\t"
-          "s_add_u32 s41, s41, s52\n\t"
+          "ds_read_b64 v[106:107], v104\n\t"
+          "s_cmp_lt_i32 s50, 1\n\t"
+          "s_cbranch_scc1 Lgeneric_%=\n\t"
+          // From here on the chain that sets the pace of a block -- A, B -> D -> count t -> new M and v -> next U -- and, one
+          // for one between its links, what does not depend on it (a lone wavefront issues an instruction that needs its
+          // predecessor's result every 8 cycles, one that does not every 5: gpurun_out/ubench_issue2.log).  An s_cmp and its
+          // s_cbranch stay together: every scalar ALU instruction in between would overwrite SCC.
+          "s_add_i32 s59, s50, -1\n\t"
+          "v_readlane_b32 s51, v103, s50\n\t"           // A
+          "v_readlane_b32 s52, v103, s59\n\t"           // B
+          "v_readlane_b32 s44, %[cW], s50\n\t"          //   qW of the next symbol
           "s_not_b32 s59, s52\n\t"
-          "s_add_u32 s55, s51, s59\n\t"
-          "s_flbit_i32_b32 s59, s55\n\t"
+          "s_add_i32 s54, s50, %[smin1]\n\t"            //   the symbol
+          "s_add_u32 s55, s51, s59\n\t"                 // D = A - 1 - B
+          "s_add_u32 s41, s41, s52\n\t"                 //   nlo = lo + B
+          "s_cmp_ge_u32 s53, 0x40000000\n\t"
+          "s_cbranch_scc1 Lfar_%=\n"
+          "Lhave_%=:\n\t"
+          "s_flbit_i32_b32 s59, s55\n\t"                // c
+          "s_and_b32 m0, s40, 63\n\t"                   //   the output lane
           "s_lshr_b32 s59, 0x7fffffff, s59\n\t"
+          "v_writelane_b32 %[outacc], s54, m0\n\t"
           "s_and_b32 s59, s59, s41\n\t"
+          "s_mov_b32 s60, s45\n\t"                      //   p0 = p1
           "s_add_u32 s59, s59, s55\n\t"
-          "s_flbit_i32_b32 s58, s59\n\t"
+          "s_mov_b32 s45, s54\n\t"                      //   p1 = the symbol
+          "s_flbit_i32_b32 s58, s59\n\t"                // t
+          "s_sub_u32 s57, s57, s52\n\t"                 //   v - B
           "s_add_u32 s42, s55, 1\n\t"
-          "s_lshl_b32 s42, s42, s58\n\t"
+          "s_mov_b32 s56, s49\n\t"                      //   the stream's next 32 bits below it
+          "s_lshl_b32 s42, s42, s58\n\t"                // M = (D + 1) << t
+          "s_lshl_b64 s[56:57], s[56:57], s58\n\t"      // v
           "s_lshl_b32 s41, s41, s58\n\t"
-          "s_sub_u32 s57, s57, s52\n\t"
-          "s_mov_b32 s56, s49\n\t"
-          "s_lshl_b64 s[56:57], s[56:57], s58\n\t"
           "s_lshl_b64 s[48:49], s[48:49], s58\n\t"
           "s_sub_u32 s46, s46, s58\n\t"
           "s_cmp_le_u32 s46, 32\n\t"
           "s_cbranch_scc1 Lrefill_%=\n"
           "Lrefilled_%=:\n\t"
-          "s_and_b32 m0, s40, 63\n\t"
-          "v_writelane_b32 %[outacc], s54, m0\n\t"
           "s_cmp_eq_u32 m0, 63\n\t"
           "s_cbranch_scc1 Lstore_%=\n"
           "Lstored_%=:\n\t"
@@ -1856,16 +1863,17 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
           "s_add_u32 s61, s40, 1\n\t"            // the window is used up: this symbol is the last of the run
           "s_branch Lrefilled_%=\n"
           "Lstore_%=:\n\t"                        // 64 symbols, one per lane
-          "s_and_b32 s59, s40, 0xffffffc0\n\t"
-          "v_or_b32_e32 v104, s59, %[lane]\n\t"
+          "s_and_b32 s63, s40, 0xffffffc0\n\t"
+          "v_or_b32_e32 v104, s63, %[lane]\n\t"
           "global_store_byte v104, %[outacc], %[out]\n\t"
           "s_branch Lstored_%=\n"
           "Lfar_%=:\n\t"                          // the next context's row is not in LDS: from the row table
-          "s_mul_i32 s59, s45, 0x50\n\t"
-          "s_add_u32 s59, s59, s54\n\t"
-          "s_mul_i32 s59, s59, %[S1]\n\t"
-          "v_add_u32_e32 v104, s59, %[lane]\n\t"
+          "s_mul_i32 s63, s45, 0x50\n\t"
+          "s_add_u32 s63, s63, s54\n\t"
+          "s_mul_i32 s63, s63, %[S1]\n\t"
+          "v_add_u32_e32 v104, s63, %[lane]\n\t"
           "v_lshlrev_b32_e32 v104, 3, v104\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"                 // (the read that went beyond LDS has answered: nothing else writes the pair)
           "global_load_dwordx2 v[106:107], v104, %[rows]\n\t"
           "s_waitcnt vmcnt(0)\n\t"
           "s_branch Lhave_%=\n"
