@@ -1773,25 +1773,28 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
     // ---- the plain path, symbol after symbol ----
     u32 rare = 0;
     if (!AC_DEC_TIGHT_CXX) {
-      // The loop by hand: 46 instructions per symbol, the next row's LDS read issued as early as the recurrence allows (the compiler's version of the same statements, below: 59 -- where its
+      // The loop by hand: 42 instructions per symbol (the compiler's version of the same statements, below: 59 -- where its
       // paths meet it copies the state from register to register and turns conditions into masks and back).  Fixed
-      // registers, so that the halves of a 64-bit pair can be named: s40 i, s41 lo, s42 M, s57 v (the high half of the pair
-      // that takes in the stream's bits), s44 qW, s45 p1, s60 p0, s46 / s47 / s[48:49] the bit reader's wb / wi / window,
-      // s61 the loop's bound, v[106:107] the row entry of this lane.  Leaves the loop: at i = n (reason 0), in front of a
-      // symbol the plain step cannot take (reason 1, nothing of the state touched), behind the symbol whose refill used up
-      // the reader's 64-word window (the bound is pulled in to i + 1: reason 0 with wi = 64).
+      // registers, so that the halves of a 64-bit pair can be named: s41 lo, s42 M, s57 v (the high half of the pair that
+      // takes in the stream's bits), s44 qW, s46 / s47 / s[48:49] the bit reader's wb / wi / window, v[106:107] the row
+      // entry of this lane; i = s40 + m0 (s40 a multiple of 64, m0 the output lane), s61 = i - bound counts up to 0 (the
+      // carry of its increment ends the loop).  The two symbols in front are not carried along: they are in the output
+      // lanes (outacc) for the rare paths that need them.  Leaves the loop: at i = n (reason 0), in front of a symbol the
+      // plain step cannot take (reason 1, nothing of the state touched), behind the symbol whose refill used up the
+      // reader's 64-word window (s61 is set to -1: reason 0 with wi = 64).
       // (every scalar through v_readfirstlane: to the compiler some of them depend on the lane -- they never do)
       auto rfl = [](u32 x) -> u32 { return (u32)__builtin_amdgcn_readfirstlane(x); };
       auto rfl64 = [&](u64 x) -> u64 { return ((u64)rfl((u32)(x >> 32)) << 32) | (u64)rfl((u32)x); };
       u32 win_lo = rfl((u32)br.win), win_hi = rfl((u32)(br.win >> 32));
-      u32 zi = rfl(i), zlo = rfl(lo), zM = rfl(M), zv = rfl(v), zqW = rfl(qW), zp1 = rfl(p1), zp0 = rfl(p0), zwb = rfl(br.wb), zwi = rfl(br.wi);
+      u32 zi = rfl(i), zlo = rfl(lo), zM = rfl(M), zv = rfl(v), zqW = rfl(qW), zwb = rfl(br.wb), zwi = rfl(br.wi);
       const u64 zout = rfl64((u64)(uintptr_t)out), zrows = rfl64((u64)(uintptr_t)rows_g), zspan = rfl64(span);
-      const u32 zn = rfl(n), zsmin1 = rfl(smin1), zS1 = rfl(S1);
+      const u32 zneg = rfl(i - n), zsmin1 = rfl(smin1), zS1 = rfl(S1);   // i - n: negative, i < n here
       asm volatile(
-          "s_mov_b32 s40, %[i]\n\ts_mov_b32 s41, %[lo]\n\ts_mov_b32 s42, %[M]\n\ts_mov_b32 s57, %[v]\n\ts_mov_b32 s44, %[qW]\n\t"
-          "s_mov_b32 s45, %[p1]\n\ts_mov_b32 s60, %[p0]\n\ts_mov_b32 s46, %[wb]\n\ts_mov_b32 s47, %[wi]\n\t"
-          "s_mov_b32 s48, %[wlo]\n\ts_mov_b32 s49, %[whi]\n\ts_mov_b32 s61, %[n]\n\t"
-          "v_mov_b32 v106, %[ex]\n\tv_mov_b32 v107, %[ey]\n\tv_mov_b32 v101, 0\n\ts_mov_b32 %[rare], 0\n\ts_mov_b32 s68, m0\n"
+          "s_mov_b32 s68, m0\n\t"
+          "s_and_b32 m0, %[i], 63\n\ts_andn2_b32 s40, %[i], 63\n\ts_mov_b32 s61, %[neg]\n\t"
+          "s_mov_b32 s41, %[lo]\n\ts_mov_b32 s42, %[M]\n\ts_mov_b32 s57, %[v]\n\ts_mov_b32 s44, %[qW]\n\t"
+          "s_mov_b32 s46, %[wb]\n\ts_mov_b32 s47, %[wi]\n\ts_mov_b32 s48, %[wlo]\n\ts_mov_b32 s49, %[whi]\n\t"
+          "v_mov_b32 v106, %[ex]\n\tv_mov_b32 v107, %[ey]\n\tv_mov_b32 v101, 0\n\ts_mov_b32 %[rare], 0\n"
           "Ltop_%=:\n\t"
           "s_waitcnt lgkmcnt(0)\n\t"
           "v_mul_hi_u32 v100, s42, v106\n\t"
@@ -1808,33 +1811,28 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
           "ds_read_b64 v[106:107], v104\n\t"
           "s_cmp_lt_i32 s50, 1\n\t"
           "s_cbranch_scc1 Lgeneric_%=\n\t"
-          // From here on the chain that sets the pace of a block -- A, B -> D -> count t -> new M and v -> next U -- and, one
-          // for one between its links, what does not depend on it (a lone wavefront issues an instruction that needs its
-          // predecessor's result every 8 cycles, one that does not every 5: gpurun_out/ubench_issue2.log).  An s_cmp and its
-          // s_cbranch stay together: every scalar ALU instruction in between would overwrite SCC.
+          // From here on the chain that sets the pace of a block -- A, B -> D -> count t -> new M and v -> next U -- with what
+          // does not depend on it between its links.  An s_cmp and its s_cbranch stay together: every scalar ALU instruction
+          // in between would overwrite SCC.
           "s_add_i32 s59, s50, -1\n\t"
           "v_readlane_b32 s51, v103, s50\n\t"           // A
           "v_readlane_b32 s52, v103, s59\n\t"           // B
           "v_readlane_b32 s44, %[cW], s50\n\t"          //   qW of the next symbol
-          "s_not_b32 s59, s52\n\t"
+          "s_sub_u32 s42, s51, s52\n\t"                 // A - B = D + 1: what the new M is made of
           "s_add_i32 s54, s50, %[smin1]\n\t"            //   the symbol
-          "s_add_u32 s55, s51, s59\n\t"                 // D = A - 1 - B
+          "s_add_u32 s55, s42, -1\n\t"                  // D
           "s_add_u32 s41, s41, s52\n\t"                 //   nlo = lo + B
           "s_cmp_ge_u32 s53, 0x40000000\n\t"
           "s_cbranch_scc1 Lfar_%=\n"
           "Lhave_%=:\n\t"
           "s_flbit_i32_b32 s59, s55\n\t"                // c
-          "s_and_b32 m0, s40, 63\n\t"                   //   the output lane
+          "v_writelane_b32 %[outacc], s54, m0\n\t"      //   the symbol into its output lane
           "s_lshr_b32 s59, 0x7fffffff, s59\n\t"
-          "v_writelane_b32 %[outacc], s54, m0\n\t"
-          "s_and_b32 s59, s59, s41\n\t"
-          "s_mov_b32 s60, s45\n\t"                      //   p0 = p1
-          "s_add_u32 s59, s59, s55\n\t"
-          "s_mov_b32 s45, s54\n\t"                      //   p1 = the symbol
-          "s_flbit_i32_b32 s58, s59\n\t"                // t
           "s_sub_u32 s57, s57, s52\n\t"                 //   v - B
-          "s_add_u32 s42, s55, 1\n\t"
+          "s_and_b32 s59, s59, s41\n\t"
           "s_mov_b32 s56, s49\n\t"                      //   the stream's next 32 bits below it
+          "s_add_u32 s59, s59, s55\n\t"
+          "s_flbit_i32_b32 s58, s59\n\t"                // t
           "s_lshl_b32 s42, s42, s58\n\t"                // M = (D + 1) << t
           "s_lshl_b64 s[56:57], s[56:57], s58\n\t"      // v
           "s_lshl_b32 s41, s41, s58\n\t"
@@ -1843,12 +1841,12 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
           "s_cmp_le_u32 s46, 32\n\t"
           "s_cbranch_scc1 Lrefill_%=\n"
           "Lrefilled_%=:\n\t"
-          "s_cmp_eq_u32 m0, 63\n\t"
+          "s_add_u32 m0, m0, 1\n\t"
+          "s_cmp_eq_u32 m0, 64\n\t"
           "s_cbranch_scc1 Lstore_%=\n"
           "Lstored_%=:\n\t"
-          "s_add_u32 s40, s40, 1\n\t"
-          "s_cmp_lt_u32 s40, s61\n\t"
-          "s_cbranch_scc1 Ltop_%=\n\t"
+          "s_add_u32 s61, s61, 1\n\t"                   // carry: the bound is reached
+          "s_cbranch_scc0 Ltop_%=\n\t"
           "s_branch Lout_%=\n"
           "Lrefill_%=:\n\t"                       // wb <= 32: the next word of the window behind the bits held
           "v_readlane_b32 s66, %[wcur], s47\n\t"
@@ -1860,15 +1858,21 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
           "s_add_u32 s47, s47, 1\n\t"
           "s_cmp_eq_u32 s47, 64\n\t"
           "s_cbranch_scc0 Lrefilled_%=\n\t"
-          "s_add_u32 s61, s40, 1\n\t"            // the window is used up: this symbol is the last of the run
+          "s_mov_b32 s61, -1\n\t"                // the window is used up: this symbol is the last of the run
           "s_branch Lrefilled_%=\n"
           "Lstore_%=:\n\t"                        // 64 symbols, one per lane
-          "s_and_b32 s63, s40, 0xffffffc0\n\t"
-          "v_or_b32_e32 v104, s63, %[lane]\n\t"
+          "v_or_b32_e32 v104, s40, %[lane]\n\t"
           "global_store_byte v104, %[outacc], %[out]\n\t"
+          "s_add_u32 s40, s40, 64\n\t"
+          "s_mov_b32 m0, 0\n\t"
           "s_branch Lstored_%=\n"
           "Lfar_%=:\n\t"                          // the next context's row is not in LDS: from the row table
-          "s_mul_i32 s63, s45, 0x50\n\t"
+          "s_add_i32 s63, m0, -1\n\t"             // (its first symbol is the one decoded before this one: the lane in front)
+          "s_and_b32 s63, s63, 63\n\t"
+          "s_nop 3\n\t"
+          "v_readlane_b32 s63, %[outacc], s63\n\t"
+          "s_min_u32 s63, s63, 0x4f\n\t"
+          "s_mul_i32 s63, s63, 0x50\n\t"
           "s_add_u32 s63, s63, s54\n\t"
           "s_mul_i32 s63, s63, %[S1]\n\t"
           "v_add_u32_e32 v104, s63, %[lane]\n\t"
@@ -1881,20 +1885,21 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
           "s_mov_b32 %[rare], 1\n"
           "Lout_%=:\n\t"
           "s_waitcnt lgkmcnt(0)\n\t"
+          "s_add_u32 %[i], s40, m0\n\t"
           "s_mov_b32 m0, s68\n\t"
-          "s_mov_b32 %[i], s40\n\ts_mov_b32 %[lo], s41\n\ts_mov_b32 %[M], s42\n\ts_mov_b32 %[v], s57\n\ts_mov_b32 %[qW], s44\n\t"
-          "s_mov_b32 %[p1], s45\n\ts_mov_b32 %[p0], s60\n\ts_mov_b32 %[wb], s46\n\ts_mov_b32 %[wi], s47\n\t"
+          "s_mov_b32 %[lo], s41\n\ts_mov_b32 %[M], s42\n\ts_mov_b32 %[v], s57\n\ts_mov_b32 %[qW], s44\n\t"
+          "s_mov_b32 %[wb], s46\n\ts_mov_b32 %[wi], s47\n\t"
           "s_mov_b32 %[wlo], s48\n\ts_mov_b32 %[whi], s49\n\t"
           "v_mov_b32 %[ex], v106\n\tv_mov_b32 %[ey], v107\n"
-          : [i] "+s"(zi), [lo] "+s"(zlo), [M] "+s"(zM), [v] "+s"(zv), [qW] "+s"(zqW), [p1] "+s"(zp1), [p0] "+s"(zp0), [wb] "+s"(zwb),
+          : [i] "+s"(zi), [lo] "+s"(zlo), [M] "+s"(zM), [v] "+s"(zv), [qW] "+s"(zqW), [wb] "+s"(zwb),
             [wi] "+s"(zwi), [wlo] "+s"(win_lo), [whi] "+s"(win_hi), [ex] "+v"(e.x), [ey] "+v"(e.y), [outacc] "+v"(outacc),
             [rare] "=&s"(rare)
-          : [n] "s"(zn), [span] "s"(zspan), [smin1] "s"(zsmin1), [S1] "s"(zS1), [out] "s"(zout), [rows] "s"(zrows), [cS] "v"(cS),
+          : [neg] "s"(zneg), [span] "s"(zspan), [smin1] "s"(zsmin1), [S1] "s"(zS1), [out] "s"(zout), [rows] "s"(zrows), [cS] "v"(cS),
             [cW] "v"(cW), [ldsb] "v"(cache_lds + lane8), [wcur] "v"(br.wcur), [lane] "v"((u32)lane)
-          : "memory", "vcc", "scc", "s68", "s40", "s41", "s42", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-            "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "v100", "v101", "v102",
+          : "memory", "vcc", "scc", "s68", "s40", "s41", "s42", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+            "s54", "s55", "s56", "s57", "s58", "s59", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "v100", "v101", "v102",
             "v103", "v104", "v106", "v107");
-      i = zi; lo = zlo; M = zM; v = zv; qW = zqW; p1 = zp1; p0 = zp0; br.wb = zwb; br.wi = zwi;
+      i = zi; lo = zlo; M = zM; v = zv; qW = zqW; br.wb = zwb; br.wi = zwi;
       br.win = ((u64)win_hi << 32) | win_lo;
       if (br.wi == 64) {  // (AcBitReader::refill's other half: the next 64 words of the block)
         br.wi = 0;
@@ -1902,6 +1907,11 @@ __global__ __launch_bounds__(64 * WPB) void ac_decode_tight_k(AcDecCachedArgs a)
         br.wcur = br.wnext;
         br.wnext = br.load_window(br.base + 256, lane);
       }
+      // the two symbols in front of symbol i (the generic step's context): its output lanes
+      p0 = (u32)__builtin_amdgcn_readlane(outacc, (i - 2u) & 63u);
+      p1 = (u32)__builtin_amdgcn_readlane(outacc, (i - 1u) & 63u);
+      p0 = p0 < AC_D ? p0 : AC_D - 1u;
+      p1 = p1 < AC_D ? p1 : AC_D - 1u;
       if (!rare) continue;
     }
     while (AC_DEC_TIGHT_CXX && i < n) {
