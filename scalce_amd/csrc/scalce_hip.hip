@@ -1937,13 +1937,14 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool f
   return SCALCE_OK;
 }
 
-// Blocks per workgroup of ac_encode_lanes_k.  A lane per block would be 64; the default is 48: all table rows of a
+// Blocks per workgroup of ac_encode_lanes_k.  A lane per block would be 64; the default is fewer: all table rows of a
 // workgroup's blocks go through ONE CU's vector memory pipeline (1024 scattered 16-byte reads per 0.75 us round at 64), and
 // beside another shard's streaming front stages -- when an L2 miss takes three times as long -- that pipeline, not the coder,
 // set the pace of a launch: 908 ms beside the ingest stage and 1299 ms beside the order stage at 64 blocks per workgroup
 // against 575 / 694 ms at 32 and 560 / 559 ms at 16 (543 ms alone; tools/coder_beside.py).  Fewer blocks per workgroup
-// are more CUs held per launch, CUs the front stages of the next shards do not get: in the bench's mix 48 is the best
-// trade (ms per shard at 32 / 40 / 48 / 56 / 64 blocks: 107.0 / 106.6 / 102.4 / 108.0 / 115.5).
+// are more CUs held per launch, CUs the front stages of the next shards do not get: in round 3's mix 48 was the best
+// trade (ms per shard at 32 / 40 / 48 / 56 / 64 blocks: 107.0 / 106.6 / 102.4 / 108.0 / 115.5); since
+// round 4 the default is 40 (below).
 static u32 ac_lanes_used() {
   const char *e = getenv("SCALCE_AC_LANES_USED");
   const int v = e ? atoi(e) : 40;  // (round 4, with the ring stores in the writer wave: 79.9 / 80.0 / 81.1 / 81.7 / 82.2 / 85.6 ms per shard at 32 / 36 / 40 / 44 / 48 / 56)
