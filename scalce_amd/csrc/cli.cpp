@@ -1232,7 +1232,7 @@ int main(int argc, char **argv) {
       case 'c':
         if (!strcmp(optarg, "gz") || !strcmp(optarg, "pigz")) o.container = 1;
         else if (!strcmp(optarg, "no")) o.container = 0;
-        else if (!strcmp(optarg, "bz")) FAIL("bzip2 containers are not built (no bzlib in this image); use gz or no\n");
+        else if (!strcmp(optarg, "bz")) FAIL("bzip2 containers are outside this build's scope (SURVEY.md section 2, #18: host-side container code); use gz or no\n");
         else FAIL("Unknown compression mode. See help for details.\n");
         break;
       case 'B': {
