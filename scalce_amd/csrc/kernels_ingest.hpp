@@ -925,7 +925,9 @@ constexpr u32 TRI_TILE = 64 * 1024;
 // fused rows (qstride > L, both multiples of 4) a unit of 16 symbols is one 16-byte load at a 4-byte boundary when it lies
 // inside a row and is put together from two rows when it does not; a thread finds (row, column) of its first unit by one
 // division per tile and moves on by additions.
-__global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, const u32 *prev, u32 pass,
+// (passes [pass, pass_end): a full 80-symbol alphabet needs up to TRI_MAX_PASSES of them, the usual 40 symbols one -- the
+//  passes behind the second go out as ONE launch that leaves at the first pass past the alphabet, not as eighteen empty ones)
+__global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n, const u32 *prev, u32 pass, u32 pass_end,
                                                              const u32 *range, u64 *freq4, unsigned long long *tile_counter,
                                                              u32 L, u32 qstride) {
   const u32 prev0 = prev[0], prev1 = prev[1];
@@ -938,6 +940,7 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
   const u32 lo = range[0], A = range[1];
   if (A == 0) return;
   const u32 AA = A * A, width = (2 * TRI_CAP) / AA;  // leading symbols per pass (>= 9)
+  for (; pass < pass_end; pass++) {
   const u32 d0 = pass * width;
   if (d0 >= A) return;                          // the alphabet is done
   const u32 used = (A - d0 < width ? A - d0 : width) * AA;
@@ -1018,6 +1021,8 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
       const u32 d = i / AA, rem = i - d * AA, bb = rem / A, cc = rem - bb * A;
       atomicAdd(&freq4[((u64)(first + d) * 80 + lo + bb) * 80 + lo + cc], (u64)v);
     }
+  }
+  __syncthreads();  // (the table is zeroed again by the next pass)
   }
 }
 

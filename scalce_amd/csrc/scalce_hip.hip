@@ -1036,8 +1036,9 @@ extern "C" int scalce_batch_quality(scalce_batch *b, void *stream) {
     LAUNCH(tri_range_k, 1, 1, 0, s, minmax, prev, range);
     unsigned long long *tiles = reinterpret_cast<unsigned long long *>(b->d_small64 + 300);  // one tile counter per pass
     HIP_TRY(c, hipMemsetAsync(tiles, 0, sizeof(u64) * TRI_MAX_PASSES, s));
-    for (u32 pass = 0; pass < TRI_MAX_PASSES; pass++)  // passes past the alphabet return at once
-      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, q, n, prev, pass, range, b->freq4[m].as<u64>(), tiles, (u32)b->L[m], b->qstride[m]);
+    for (u32 pass = 0; pass < 3; pass++)  // pass 0, pass 1, and whatever a wide alphabet needs behind them in one launch
+      LAUNCH(trigram_pass_k, 256, TRI_THREADS, 0, s, q, n, prev, pass, pass < 2 ? pass + 1 : (u32)TRI_MAX_PASSES, range, b->freq4[m].as<u64>(), tiles,
+             (u32)b->L[m], b->qstride[m]);
     {  // one count per symbol with two predecessors (the run's first two have them only when the caller passed qprev)
       const bool p0 = b->p.qprev[m][0] < 80, p1 = b->p.qprev[m][1] < 80;
       const u64 carried = p1 ? (p0 ? 2 : 1) : 0;
