@@ -1,19 +1,12 @@
-"""Shards in flight: the host-side scheduling loop around the C ABI's split entropy stage.
+"""Shards in flight: binding of the C ABI's scalce_pipeline_* (scalce_amd/csrc/pipeline.cpp).
 
 The reference keeps its cores busy by handing `-T` blocks per batch to coder threads while the reader goes on
-(arithmetic.cpp:349-357, compress.cpp:781-786).  The device-side counterpart: the arithmetic coder is a long kernel
-of one wavefront per 10 MiB block (or per four / eight blocks) that leaves the memory system and most lanes idle, so
-the front stages (ingest .. emit, and in a sharded run their collectives) of the NEXT shards run beside it on another
-stream.  What the measurements on MI355X fixed:
-
-* one `front` stream and `coder_streams` coder streams (bench.py: three, and GPU_MAX_HW_QUEUES=8 so that no two of them
-  share a hardware queue): HIP maps streams onto a handful of hardware queues, and any read-back that lands in a queue
-  behind a 0.6 s coder kernel waits for all of it;
-* shards are retired on an EVENT recorded behind their coder launch and read back over the front stream;
-* a launch takes `group` shards (scalce_batch_entropy_begin_group).  The one-block-per-lane coder holds ~10 CUs per shard
-  for ~0.6 s whatever the launch holds, so consecutive launches rotate over the coder streams and run side by side
-  (rounds 1-2, a wavefront per 1-8 blocks: one launch at a time on one stream);
-* `slots >= 2 * group` batches, so that the front stages of one group run while the previous groups are coded.
+(arithmetic.cpp:349-357, compress.cpp:781-786).  The device-side counterpart: the arithmetic coder is a long kernel that only
+depends on its own shard's front stages, so the front stages (ingest .. emit, and in a sharded run their collectives) of the
+NEXT shards run on one stream beside the coder launches of the previous ones on `coder_streams` others, `group` shards per
+launch, shards retired on events.  The loop itself -- slots, streams, events, which kernel the last launch of a run takes --
+is C++ behind the C ABI (rounds 1-3: Python, here); this class only turns its flags into the callbacks bench.py and the
+tests use.
 
 Usage:
     pipe = ShardPipeline(batches, group=3)
@@ -23,6 +16,8 @@ Usage:
         pipe.submit(slot, tag=shard)          # coder launch once `group` shards are waiting (or flush=True)
     pipe.drain()
 """
+import ctypes as C
+
 from . import host
 
 
@@ -35,111 +30,93 @@ class ShardPipeline:
         self.G = max(1, int(group))
         if self.G > 1 and self.D < 2 * self.G:
             raise ValueError("a grouped pipeline needs at least 2 * group batches")
-        self.front = torch.cuda.Stream()
-        # coder launches rotate over `coder_streams` streams: the one-block-per-lane coder (ac_encode_lanes_k) takes a
-        # fraction of a CU per 64 blocks for ~0.5 s whatever the size of the launch, so several launches run side by side
-        self.coders = [torch.cuda.Stream() for _ in range(max(1, int(coder_streams)))]
+        self.L = host.lib()
+        L = self.L
+        L.scalce_pipeline_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.scalce_pipeline_destroy.argtypes = [C.c_void_p]
+        L.scalce_pipeline_destroy.restype = None
+        L.scalce_pipeline_error.argtypes = [C.c_void_p]
+        L.scalce_pipeline_error.restype = C.c_char_p
+        for f in (L.scalce_pipeline_front_stream, L.scalce_pipeline_coder_stream):
+            f.restype = C.c_void_p
+        L.scalce_pipeline_front_stream.argtypes = [C.c_void_p]
+        L.scalce_pipeline_coder_stream.argtypes = [C.c_void_p, C.c_int]
+        L.scalce_pipeline_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.scalce_pipeline_submit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.scalce_pipeline_retire.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.scalce_pipeline_drain.argtypes = [C.c_void_p]
+        L.scalce_pipeline_flush_last.argtypes = [C.c_void_p]
+        arr = (C.c_void_p * self.D)(*[b.h for b in self.batches])
+        h = C.c_void_p()
+        rc = L.scalce_pipeline_create(arr, self.D, self.G, max(1, int(coder_streams)), 1 if sharded else 0, C.byref(h))
+        self.h = h
+        self._check(rc)
+        # the library's streams as torch streams (callers enqueue torch work and their own C ABI calls on them)
+        self.front = torch.cuda.ExternalStream(L.scalce_pipeline_front_stream(self.h))
+        self.coders = [torch.cuda.ExternalStream(L.scalce_pipeline_coder_stream(self.h, i)) for i in range(max(1, int(coder_streams)))]
         self.coder = self.coders[0]
-        self.tail_streams = [torch.cuda.Stream() for _ in range(3)]  # the halves of a run's last group: never behind a running launch
-        self._tail_launches = 0
-        self._launches = 0
         self.on_retire = on_retire
-        self.sharded = sharded          # shards arrive prepared (scalce_sharded_compress with SCALCE_SHARD_PREPARE_ONLY / _CODER_ASYNC)
+        self.sharded = sharded
         self.trace = trace
-        self._busy = [None] * self.D    # event behind the slot's coder launch
         self._tag = [None] * self.D
-        self._pending = []
         self._next = 0
-        import os
-        # launches of 1, 2, .. shards at the start of a run: measured (round 4) and left off -- the first slot comes back 80 ms
-        # sooner, the front stages of the next shards run beside one more launch: 89.1 against 88.1 ms per shard at 20 steps
-        self.ramp = not sharded and bool(os.environ.get("SCALCE_BENCH_RAMP"))
-        self._run_launches = 0          # launches since the pipeline was last drained
-        # the last group of a run in halves (submit): measured (round 4) and left off -- 88.4 against 86.4 ms per shard at 20 steps
-        # (what the smaller, faster launches gain at the end their CUs take from the last front stages)
-        self.tail = bool(os.environ.get("SCALCE_BENCH_TAIL"))
+
+    def _check(self, rc):
+        if rc:
+            msg = self.L.scalce_pipeline_error(self.h).decode() if self.h else "scalce_pipeline_create"
+            ctx = self.batches[0].ctx
+            raise RuntimeError(f"scalce pipeline: {msg} (rc {rc}): {self.L.scalce_last_error(ctx.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.scalce_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     # -- slots ---------------------------------------------------------------------------------------------
-    def acquire(self):
-        """Next batch in round-robin order, free to be overwritten (its previous shard retired)."""
-        slot = self._next
-        self._next = (self._next + 1) % self.D
-        if slot in self._pending:  # caller never submitted enough shards to launch: flush before reuse
-            self.flush()
-        self.retire(slot)
-        return slot, self.batches[slot]
-
-    def retire(self, slot):
-        ev = self._busy[slot]
-        if ev is None:
-            return
-        ev.synchronize()
+    def _retired(self, slot):
         if self.trace:
             self.trace(f"slot {slot}: coder event reached")
-        self.batches[slot].finish(self.front.cuda_stream)  # sizes of the coded streams, device error word
-        self._busy[slot] = None
         if self.on_retire:
             self.on_retire(slot, self.batches[slot], self._tag[slot])
         self._tag[slot] = None
 
+    def acquire(self):
+        """Next batch in round-robin order, free to be overwritten (its previous shard retired)."""
+        slot, had = C.c_int(), C.c_int()
+        self._check(self.L.scalce_pipeline_acquire(self.h, C.byref(slot), C.byref(had)))
+        self._next = (slot.value + 1) % self.D
+        if had.value:
+            self._retired(slot.value)
+        return slot.value, self.batches[slot.value]
+
+    def retire(self, slot):
+        had = C.c_int()
+        self._check(self.L.scalce_pipeline_retire(self.h, slot, C.byref(had)))
+        if had.value:
+            self._retired(slot)
+
     # -- coder launches ------------------------------------------------------------------------------------
     def submit(self, slot, tag=None, flush=False, remaining=None):
         """The front stages of `slot` are enqueued on `self.front`: launch the coder now or with the next shards.
-        remaining: shards of the run still to come behind this one (None: unknown).  The END of a run is what the last
-        launch takes after the last front stage -- ~0.6 s of an idle chip with one block per lane; with SCALCE_BENCH_TAIL=1 the
-        last group goes out in halves (with 6 pending + to come: 3, then 2, then 1), the smaller ones with kernels that are
-        sooner done (measured: no gain, off by default)."""
+        flush: the caller has no further shards -- the last launch of a run is picked for its own latency."""
         self._tag[slot] = tag
-        if self.G == 1:
-            b = self.batches[slot]
-            coder = self.coder
-            if not self.sharded:  # a sharded caller has already enqueued the coder on self.coder (ent_stream)
-                coder = self.coders[self._launches % len(self.coders)]
-                self._launches += 1
-                coder.wait_stream(self.front)
-                b.entropy_begin(None, coder.cuda_stream)
-            ev = self.torch.cuda.Event()
-            ev.record(coder)
-            self._busy[slot] = ev
-            return
-        self._pending.append(slot)
-        # the first launches of a run are smaller (1, 2, .. shards): a launch takes ~0.6 s whatever it holds, and nothing is
-        # coded -- no slot comes back -- until the first one has gone out
-        target = min(self.G, self._run_launches + 1) if self.ramp else self.G
-        tail = remaining is not None and self.tail and not self.sharded and remaining + len(self._pending) <= self.G
-        if tail and not flush and remaining > 0:
-            if len(self._pending) >= remaining:     # as many waiting as still to come: out they go
-                self.flush(mode=3 if remaining <= 2 else 2)
-            return
-        if len(self._pending) >= target or flush:
-            self.flush(last=flush, small=len(self._pending) < self.G and not flush)
-
-    def flush(self, last=False, small=False, mode=None):
-        """last: the caller has no further shards (the end of a run): the launch is picked for its own latency.
-        small: a launch of fewer than `group` shards with more on their way: the kernel that holds the fewest CUs.
-        mode: scalce_batch_entropy_begin_group_last's `last` argument given directly (tail launches)."""
-        if not self._pending:
-            return
-        if mode is not None or (last and self._tail_launches):
-            coder = self.tail_streams[self._tail_launches % len(self.tail_streams)]
-            self._tail_launches += 1
-        else:
-            coder = self.coders[self._launches % len(self.coders)]
-            self._launches += 1
-        self._run_launches += 1
-        host.entropy_begin_group([self.batches[sl] for sl in self._pending], self.front.cuda_stream, coder.cuda_stream,
-                                 last=0 if self.sharded else (mode if mode is not None else 1 if last else 2 if small else 0))
-        ev = self.torch.cuda.Event()
-        ev.record(coder)
-        for sl in self._pending:
-            self._busy[sl] = ev
-        self._pending = []
-        if self.trace:
+        launched = C.c_int()
+        self._check(self.L.scalce_pipeline_submit(self.h, slot, 1 if flush else 0, C.byref(launched)))
+        if launched.value and self.trace:
             self.trace("coder launched")
 
     def drain(self):
-        self.flush(last=True)
+        """What is pending goes out as the last launch of the run, every slot is waited for and collected (on_retire in
+        slot order).  With nobody to tell, scalce_pipeline_drain does the same in one call."""
+        if not (self.on_retire or self.trace):
+            self._check(self.L.scalce_pipeline_drain(self.h))
+            return
+        self._check(self.L.scalce_pipeline_flush_last(self.h))
         for slot in range(self.D):
             self.retire(slot)
-        self._run_launches = 0
-        self._tail_launches = 0
