@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(64) void ac_decode_k(AcDecArgs a) {
 //  * the rows of the W x W most frequent contexts (the W symbols with the largest totals) sit in LDS (128 KB, two
 //    blocks per workgroup share them), addressed by the symbols' ranks, no map in between;
 // and the next row is requested as soon as the symbol is known, before the renormalisation and the bit refill.
-constexpr u32 AC_DEC_CACHE_ENTRIES = 16384;  // x 8 bytes = 128 KB of LDS
+constexpr u32 AC_DEC_CACHE_ENTRIES = 19968;  // x 8 bytes = 156 KB of the CU's 160 KB of LDS (round 4: 128 KB; a row outside costs a symbol 110 ns more)
 struct AcDecCachedArgs {
   AcDecArgs d;
   const uint2 *rows;   // [6400][S1]

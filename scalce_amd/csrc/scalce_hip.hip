@@ -2772,6 +2772,7 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
     std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return tot[x] > tot[y]; });
     u32 W = 1;
     while (W < 32 && W < order.size() && (u64)(W + 1) * (W + 1) * ca.S1 <= AC_DEC_CACHE_ENTRIES) W++;
+    if (const char *e = getenv("SCALCE_AC_DECODE_W")) W = std::max<u32>(1, std::min<u32>(W, (u32)atoi(e)));  // (experiments: fewer contexts in LDS)
     ca.W = W;
     memset(ca.rank, 0xFF, sizeof ca.rank);
     for (u32 r = 0; r < W; r++) { ca.hot[r] = (u8)order[r]; ca.rank[order[r]] = (u8)r; }
