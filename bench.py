@@ -92,11 +92,6 @@ def main():
     from scalce_amd import format as fmt
     off, vals, Ls = fmt.sample_qmap(head)
     assert Ls == L
-    # shards per coder launch / shards in flight: 3 / 6 (199 GB of the 288 GB HBM at 50 M reads per shard on one GPU).  A
-    # sharded run also holds every in-flight shard's block range of the run-wide quality stream and the all-to-all
-    # buffers.  Measured with the 2-rank rehearsal (tools/mem_probe.sh; 20 M and 28 M reads, 4 and 6 in flight), per rank:
-    # 8 GB + 0.4 GB per million reads + 0.73 GB per million reads and shard in flight (x L / 100) = 246 GB at 50 M reads
-    # and six in flight.  A rank keeps 3 / 6 when that estimate plus a margin fits what is free now, else 2 / 4 (174 GB).
     # A sharded run goes through scalce_sharded_compress (C++ host, RCCL).  SCALCE_BENCH_FORCE_SHARDED=1 takes that path at
     # world 1 as well (every collective is then a real RCCL call of one rank); SCALCE_COMM=shm rehearses several ranks on
     # ONE GPU through the shared-memory transport.
@@ -124,19 +119,18 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-    # four shards per coder launch, up to three launches side by side on three streams, fourteen shards in flight (243 GB):
-    # a launch of the one-block-per-lane coder takes 0.56-0.65 s whatever it holds and 40 CUs for four shards, so the
-    # pipeline needs them side by side beside the front stages of the next four shards
-    # A sharded run (several ranks, ONE archive) also holds, per shard in flight, its block range of the run-wide quality
-    # stream and the all-to-all buffers: 246 GB at six in flight (tools/mem_probe.sh).  It keeps round 2's shape -- three
-    # shards per launch, six in flight, one coder stream, eight blocks per chain wave: with one stream a launch of the
-    # one-block-per-lane coder (0.6 s whatever it holds) would be all there is to a step.
+    # Shards per coder launch / in flight / coder streams: a launch of the one-block-per-lane coder takes ~0.5 s whatever it
+    # holds, so the pipeline wants launches side by side beside the front stages of the next shards, and as many slots as the
+    # card holds.
+    # (round 5: a sharded rank runs the SAME pipeline as one GPU on its own -- one block per lane, grouped launches on several
+    #  streams: its reordered stream lives in the shared workspace (scalce_batch_set_stream_scratch) and what stays on the rank
+    #  never goes through the transport, so a slot costs it what it costs the plain path)
     G = args.group
     auto_group = G is None
     if G is None:
-        G = 3 if sharded else 4
+        G = 4
     G = max(1, G)
-    D = max(1, args.inflight) if args.inflight is not None else (2 * G if sharded else 3 * G + 2)
+    D = max(1, args.inflight) if args.inflight is not None else 3 * G + 2
     # Every shard in flight has a text of its OWN (round 4; VERDICT r3: fourteen jobs that read one tensor are not fourteen
     # jobs a card can hold).  What is free now decides how many fit: ~20 GB of shared front-stage buffers + per shard in
     # flight its text (10.8 GB) and ~12.2 GB of the batch's own (reordered q' 5, coder blocks 5 sized for the worst case,
@@ -148,28 +142,25 @@ def main():
         # (the batch's own: reordered q' 5 GB, coder blocks 3.5 GB sized from the table, records 1.25, names 0.54, tables)
         # (a sharded rank also holds, per shard in flight, its block range of the run-wide quality stream and the exchange
         #  buffers: 188.6 GB at five in flight with their texts, measured at world 1 over RCCL)
-        per_slot = (10.7e9 if not sharded else 24e9) * scale + (nbytes if own_text else 0)
-        fit = int((free_b + (nbytes if own_text else 0) - 22e9 * scale - 5e9) // per_slot)
+        per_slot = 10.7e9 * scale + (nbytes if own_text else 0)
+        # shared: the front-stage workspace (~20 GB); a sharded rank adds the reordered stream (5 GB) and, with peers, the receive
+        # side of the q' exchange (5 GB) and of the row exchange (the rows that change owner, the re-ingested text)
+        shared = 22e9 * scale + (0 if not sharded else (6e9 + (0 if world == 1 else 5e9 + 1.3 * nbytes)) * scale)
+        fit = int((free_b + (nbytes if own_text else 0) - shared - 5e9) // per_slot)
         if world > 1:   # every rank takes the same shape
             tfit = torch.tensor([fit], dtype=torch.int64)
             dist.all_reduce(tfit, op=dist.ReduceOp.MIN)
             fit = int(tfit.item())
-        if sharded and fit < D:
-            # a sharded rank needs ~24 GB per shard in flight beside its text: seven fit a 288 GB card
-            if auto_group and fit < 2 * G:
-                G = max(1, fit // 2)
-            D = max(fit, 1)
-            print("bench: %.0f GB of HBM free: %d shards in flight, %d per coder launch" % (free_b / 1e9, D, G), file=sys.stderr)
-        elif fit < D:
-            if auto_group and not sharded:
+        if fit < D:
+            if auto_group:
                 # A coder launch takes ~0.6 s whatever it holds: what counts is that every group of slots has a stream of its
                 # own.  With twelve slots, six shards per launch on two streams, four on three and three on four measure the
                 # same at 20 steps (86.5 / 86.4 / 86.6 ms per shard, tools/pipe_shapes_r4.sh): six it is -- the fewest, largest
                 # launches of the dominant kernel.  Fewer than twelve: three per launch (91 ms at 3 / 11 / 3 against 103 at 4 / 11 / 2).
-                G = 6 if fit >= 12 else 3
+                G = 6 if fit >= 12 else (3 if fit >= 6 else max(1, fit // 2))
             print("bench: %.0f GB of HBM free: %d shards in flight instead of %d, %d per coder launch" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D, G), file=sys.stderr)
             D = fit
-    if G > 1 and not (sharded and args.inflight is None):
+    if G > 1:
         D = max(D, 2 * G)
     # slot i reads texts[i]: different seeds, the same record shape (sizes are equal: names and lengths are)
     texts = [text]
@@ -179,8 +170,6 @@ def main():
             assert texts[-1].numel() == nbytes
     else:
         texts = [text] * D
-    if sharded and "SCALCE_AC_BLOCKS_PER_WG" not in os.environ and D < 3 * G:
-        os.environ["SCALCE_AC_BLOCKS_PER_WG"] = "8"
     # -B: the reference's default, 4 GiB of record bytes per spill chunk (main.cpp:68) -- 50 M reads of 100 bp are 3 chunks
     B = int(os.environ.get("SCALCE_BENCH_BUCKET_SET", str(4 << 30)))
     # the shards in flight share ONE set of front-stage buffers (rows, tokens, events, sort scratch: dead once a shard is
@@ -198,9 +187,8 @@ def main():
         ws = None if os.environ.get("SCALCE_BENCH_OWN_WORKSPACES") else host.Workspace(ctxs[f])
         batches += [host.Batch(ctxs[f], L, max_reads=n + 8, max_text=nbytes + 64, qmap=[(off, vals), (off, vals)], bucket_set_size=B,
                                workspace=ws) for _ in range(D // F)]
-    if not sharded:
-        for b in batches:   # the coded blocks are framed when they are delivered (scalce_batch_qual_window), not by a copy pass
-            b.set_frame_on_demand(True)
+    for b in batches:   # the coded blocks are framed when they are delivered (scalce_batch_qual_window), not by a copy pass
+        b.set_frame_on_demand(True)
     batch = batches[0]
     state = {}
 
@@ -222,8 +210,7 @@ def main():
     DF = D // F
     # as many coder streams as groups fit the slots (every launch takes ~0.6 s whatever it holds: with a stream per group in
     # rotation no group waits for another's launch to end; 3 / 4 / 12 measured 88.1 ms per shard against 90.0 at 3 / 3 / 12)
-    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(6, DF // G)) if (G > 1 and DF >= 2 * G and not sharded) else
-                                         "3" if (G > 1 and DF >= 3 * G) else "1"))
+    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(6, DF // G)) if (G > 1 and DF >= 2 * G) else "1"))
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
                            coder_streams=n_coder_streams)
              for f in range(F)]
@@ -268,7 +255,7 @@ def main():
                     state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
                                                         stream=pipe.front.cuda_stream, result=state.get(slot))
             mark(f"shard {j}: front done")
-            pipe.submit(slot, tag=j, flush=j + 1 == k, remaining=k - j - 1)
+            pipe.submit(slot, tag=j, flush=j + 1 == k)
         pipe.drain()
 
     torch.cuda.synchronize()  # the synthetic shard was generated on the default stream
@@ -300,20 +287,63 @@ def main():
     # ---- the run proves its own output (never inside the timed region) ----
     parity = {}
     decode = None
-    if rank == 0 and sharded and world == 1 and not args.no_verify:
-        # the sharded path at world 1 (SCALCE_BENCH_FORCE_SHARDED=1: every collective a real RCCL call of one rank) builds the
-        # whole archive in one batch: the same three hashes must come out
+    if sharded and not args.no_verify:
         from scalce_amd import verify
+        last_slot = (pipe._next - 1) % DF
+        # (1) one rank (SCALCE_BENCH_FORCE_SHARDED=1: every collective a real RCCL call of one rank) builds the whole archive in one
+        # batch: the three hashes of the reference's own full-size files must come out
         gold_path = os.path.join(ROOT, "tests", "golden", "full_size_ref.json")
+        if rank == 0 and world == 1:
+            try:
+                gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
+                if gold and (gold["reads"], gold["length"], gold["seed"]) == (n, L, SEED0) and B == 4 << 30:
+                    got = verify.archive_hashes(batches[0], L, off, n)
+                    same = {k: got[k] == v["sha256"] for k, v in gold["files"].items()}
+                    parity["reference_full_size"] = {"ok": all(same.values()), "files": same,
+                                                     "what": "sharded path, one rank: SHA-256 of .scalce{n,r,q} of slot 0's shard equal to the reference's own compress() -T 1 files"}
+            except Exception as ex:  # noqa: BLE001
+                parity["reference_full_size"] = {"ok": False, "error": repr(ex)[:300]}
+        # (2) any number of ranks: the LAST timed shard comes back.  Every rank decodes the coder blocks it holds (its range of the
+        # run-wide stream) on the device, the symbols go back to the ranks that emitted the records (the block-range exchange run
+        # backwards), every rank rebuilds the FASTQ text of its records, and the record digests -- (count, two 64-bit sums of a
+        # per-record hash), summed over the ranks -- must equal the digests of the input texts summed over the ranks: records
+        # change owner between ranks, the run's multiset does not.  All of it collective: every rank takes part or none.
+        for i, b in enumerate(batches):
+            if i not in (0, last_slot):
+                b.close()
+        for i in range(len(texts)):
+            if i not in (0, last_slot):
+                texts[i] = None
+        torch.cuda.empty_cache()
+        tv0 = time.perf_counter()
+        mine = {"want": None, "got": None, "error": None}
         try:
-            gold = json.load(open(gold_path)) if os.path.exists(gold_path) else None
-            if gold and (gold["reads"], gold["length"], gold["seed"]) == (n, L, SEED0) and B == 4 << 30:
-                got = verify.archive_hashes(batches[0], L, off, n)
-                same = {k: got[k] == v["sha256"] for k, v in gold["files"].items()}
-                parity["reference_full_size"] = {"ok": all(same.values()), "files": same,
-                                                 "what": "sharded path, one rank: SHA-256 of .scalce{n,r,q} of slot 0's shard equal to the reference's own compress() -T 1 files"}
+            mine["want"] = verify.record_digest(texts[last_slot])
         except Exception as ex:  # noqa: BLE001
-            parity["reference_full_size"] = {"ok": False, "error": repr(ex)[:300]}
+            mine["error"] = "input digest: " + repr(ex)[:200]
+        try:   # (collective calls inside: a rank that failed above still takes part)
+            back = verify.sharded_records_text(comm, ctx, batches[last_slot], state[last_slot], L, off, dev)
+            mine["got"] = verify.record_digest(back)
+            del back
+        except Exception as ex:  # noqa: BLE001
+            mine["error"] = (mine["error"] or "") + " decode: " + repr(ex)[:200]
+        everyone = [mine]
+        if world > 1:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            errs = [f"rank {r}: {e['error']}" for r, e in enumerate(everyone) if e["error"]]
+            if errs:
+                parity["sharded_run"] = {"ok": False, "error": "; ".join(errs)[:400]}
+            else:
+                want = verify.digest_sum([e["want"] for e in everyone])
+                got = verify.digest_sum([e["got"] for e in everyone])
+                parity["sharded_run"] = {"ok": bool(want == got and want[0] == n * world), "records": got[0], "ranks": world,
+                                         "records_per_rank_out": [e["got"][0] for e in everyone],
+                                         "what": "last timed shard of the run (ONE archive over all ranks): every rank decodes the coder blocks it holds on the "
+                                                 "device, the symbols return to the ranks that emitted the records, every rank rebuilds its records' FASTQ "
+                                                 "text; (count, two 64-bit sums of per-record hashes) summed over the ranks equal to the input texts'",
+                                         "seconds": round(time.perf_counter() - tv0, 2)}
     if rank == 0 and not sharded and not args.no_verify:
         from scalce_amd import verify
         # the checks need room (5 GB of symbols, 10.8 GB of text, the digest's temporaries): everything but slot 0 and the slot
@@ -382,7 +412,7 @@ def main():
             parity["ref_full_shard"] = {"ok": False, "error": repr(ex)[:300]}
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and args.cpu_sample > 0:   # (rank 0's host cores, rank 0's own shard: any number of ranks)
         try:
             cpu, parity["sample"] = cpu_baseline(text, n, L, args.cpu_sample)
         except Exception as ex:  # noqa: BLE001
@@ -504,6 +534,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()   # (rank 0's CPU leg and checks run while the others wait here)
         dist.destroy_process_group()
 
 

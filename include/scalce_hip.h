@@ -26,8 +26,7 @@ extern "C" {
 #define SCALCE_ERR_HIP 2       /* HIP runtime failure (message in scalce_last_error) */
 #define SCALCE_ERR_FORMAT 3    /* malformed input: the cases where the reference prints (ERROR) and exits */
 #define SCALCE_ERR_CAPACITY 4  /* batch larger than the capacity it was created with */
-#define SCALCE_ERR_UNCUT 5     /* (rounds 1-3: scalce_sharded_compress refused a run that -B does not cut anywhere.  Since round 4 such
-                                  a run -- one spill chunk -- goes to rank 0 as a whole and the code is no longer returned.) */
+/* (5 was SCALCE_ERR_UNCUT in rounds 1-3: a run that -B does not cut is one spill chunk and goes to rank 0 as a whole) */
 
 #define SCALCE_AC_DEPTH 80                  /* arithmetic.h:47 */
 #define SCALCE_AC_BLOCK (10 * 1024 * 1024)  /* arithmetic.cpp:48 */
@@ -151,6 +150,12 @@ void scalce_batch_set_lean(scalce_batch *b, int lean);
  * rows lie back to back: for callers that read SCALCE_OUT_QINPUT as one array (sharded runs); lean batches do so by themselves.
  * Returns SCALCE_ERR_ARG when the batch cannot take the layout asked for. */
 int scalce_batch_set_fused_rows(scalce_batch *b, int on);
+/* Where the reordered q' stream of the emit stage lives (arithmetic.cpp:318-363 cuts it into 10 MiB blocks).  on = 1: in the
+ * workspace the batch shares with others instead of in the batch itself -- for callers that pass the stream on right behind
+ * the emit stage and never code it where it lies (scalce_sharded_compress: every rank hands its stream to the owners of the
+ * run-wide block ranges): SCALCE_OUT_QSTREAM is then valid until the next batch of the workspace runs its emit stage, and the
+ * batch holds 5 GB less per 50 M reads of 100 bp.  Not with -A (the stream is the output) or lean batches: SCALCE_ERR_ARG. */
+int scalce_batch_set_stream_scratch(scalce_batch *b, int on);
 /* edge[0..1] = the first two, edge[2..3] = the last two q' symbols of the rows held (input order), *nsym = how many there are,
  * *read_len (may be NULL) = symbols per row: what a rank of a sharded run tells its neighbours (qualities.cpp:179-198: prev[]
  * runs across reads, so two trigrams straddle every rank boundary).  Runs on `stream` and synchronises it. */
@@ -349,6 +354,10 @@ int scalce_comm_send(scalce_comm *c, const void *d_buf, uint64_t bytes, int peer
 int scalce_comm_recv(scalce_comm *c, void *d_buf, uint64_t bytes, int peer, void *stream);
 int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, const uint64_t *send_bytes, void *d_recv,
                              const uint64_t *recv_bytes, void *stream);
+/* The same with explicit offsets: the bytes for rank d start at d_send + send_off[d], those from rank src land at
+ * d_recv + recv_off[src] -- a rank sends ranges of a buffer where they lie and keeps its own part out of the transport. */
+int scalce_comm_all_to_all_vo(scalce_comm *c, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes,
+                              void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream);
 
 typedef struct {
   int32_t world, rank;

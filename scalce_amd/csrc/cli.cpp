@@ -35,7 +35,6 @@
 #include "../../include/scalce_hip.h"
 #include "pargz.hpp"
 
-static const int EXIT_UNCUT = 3;  // a rank's exit status: -B does not cut the run (scalce_sharded_compress: SCALCE_ERR_UNCUT)
 
 #ifndef SCALCE_VERSION
 #define SCALCE_VERSION "2.8-mi355x"
@@ -199,27 +198,32 @@ struct OutFile {
     // enough for every thread: deflate what is there, member by member (the stream never has to sit in memory whole)
     if (pending.size() >= MEMBER * (size_t)std::max(1, g_threads) * 2) flush_members(false);
   }
-  // The reference writes its containers at zlib's default level (buffio.cpp: gzopen(path, "wb")).  So does this writer where
-  // it pays: the name stream shrinks to a third.  The read stream is 2-bit packed bases, as good as incompressible (the
+  // The reference writes its containers at zlib's default level (buffio.cpp: gzopen(path, "wb")), and so does this writer for
+  // what deflate shrinks (names: to a third).  The read stream is 2-bit packed bases, as good as incompressible (the
   // reference's own gz gains 2.5 % on it) and the slowest thing zlib can be fed: ~20 MB/s per core at level 6 -- 3.6 of the
-  // 5.8 s of a 50 M-read run with -c gz.  A member whose first 32 KiB do not shrink by a tenth at level 1 is therefore
-  // Huffman-coded only (Z_HUFFMAN_ONLY: no match search, ~15 x the speed, within a percent of the size).
+  // 5.8 s of a 50 M-read run with -c gz.  A member none of whose sample windows (eight of 16 KiB, spread over the member)
+  // shrinks by a tenth at level 1 is therefore Huffman-coded only (Z_HUFFMAN_ONLY: no match search, ~15 x the speed, within
+  // a percent of the size).  SCALCE_GZ_ALWAYS_DEFAULT_LEVEL=1 turns that off; SCALCE_GZ_LEVEL sets another level for the rest.
   static bool hardly_compressible(const uint8_t *src, size_t n) {
-    if (getenv("SCALCE_GZ_ALWAYS_DEFAULT_LEVEL")) return false;
-    const size_t k = std::min<size_t>(n, 32u << 10);
-    if (k < 4096) return false;
-    uLongf got = compressBound((uLong)k);
-    std::vector<uint8_t> tmp(got);
-    if (compress2(tmp.data(), &got, src, (uLong)k, 1) != Z_OK) return false;
-    return got * 10 >= k * 9;
+    static const bool off = getenv("SCALCE_GZ_ALWAYS_DEFAULT_LEVEL") != nullptr;
+    if (off || n < 4096) return false;
+    const size_t win = std::min<size_t>(n, 16u << 10), nwin = n >= 8 * win ? 8 : 1;
+    std::vector<uint8_t> tmp(compressBound((uLong)win));
+    for (size_t i = 0; i < nwin; i++) {
+      const size_t at = nwin == 1 ? 0 : (n - win) / (nwin - 1) * i;
+      uLongf got = (uLongf)tmp.size();
+      if (compress2(tmp.data(), &got, src + at, (uLong)win, 1) != Z_OK) return false;
+      if (got * 10 < win * 9) return false;   // this part does shrink: the member goes through deflate proper
+    }
+    return true;
   }
   static void deflate_member(const uint8_t *src, size_t n, std::vector<uint8_t> &out) {
     z_stream z;
     memset(&z, 0, sizeof z);
     const bool fast = n && hardly_compressible(src, n);
-    // (what does shrink -- names -- goes at level 3: 2.4 x the speed of the default 6 for a tenth more bytes of a stream that
-    //  is an eighth of the archive; SCALCE_GZ_LEVEL sets another)
-    static const int level = getenv("SCALCE_GZ_LEVEL") ? atoi(getenv("SCALCE_GZ_LEVEL")) : 3;
+    // (what does shrink -- names -- goes at zlib's default level, the reference's: level 3 is 2.4 x the speed for a tenth more
+    //  bytes of that stream; SCALCE_GZ_LEVEL=3 asks for it)
+    static const int level = getenv("SCALCE_GZ_LEVEL") ? atoi(getenv("SCALCE_GZ_LEVEL")) : Z_DEFAULT_COMPRESSION;
     if (deflateInit2(&z, fast ? 1 : level, Z_DEFLATED, 15 + 16, 8, fast ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY) != Z_OK) FAIL("deflateInit2 failed\n");
     out.resize(deflateBound(&z, (uLong)n) + 64);
     z.next_in = const_cast<Bytef *>(src); z.avail_in = (uInt)n;
@@ -817,7 +821,6 @@ static int rank_main(const Options &o, const std::vector<std::string> &files, co
   memset(&res, 0, sizeof res);
   {
     const int rc = scalce_sharded_compress(comm, ctx, b, d_text[0], hi[0] - lo[0], nm == 2 ? d_text[1] : nullptr, nm == 2 ? hi[1] - lo[1] : 0, 0, s, nullptr, &res);
-    if (rc == SCALCE_ERR_UNCUT) _exit(EXIT_UNCUT);  // every rank alike; nothing has been written yet
     if (rc) exit(1);
   }
   for (int m = 0; m < nm; m++) hipFree(d_text[m]);
@@ -1059,7 +1062,7 @@ static int multi_gpu_compress(const Options &o_in, const std::vector<std::string
   }
   // Ranks are collected in the order they end.  One that fails on its own (a crash, an error outside the collective
   // protocol of scalce_sharded_compress) leaves the others waiting for it in a collective: the first bad exit ends them.
-  int bad = 0, uncut = 0;
+  int bad = 0;
   size_t left = kids.size();
   while (left) {
     int st = 0;
@@ -1070,8 +1073,7 @@ static int multi_gpu_compress(const Options &o_in, const std::vector<std::string
     *it = -1;
     left--;
     const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
-    if (WIFEXITED(st) && WEXITSTATUS(st) == EXIT_UNCUT) uncut++;
-    else if (!ok && !bad) {
+    if (!ok && !bad) {
       bad = 1;
       for (pid_t o2 : kids) if (o2 > 0) kill(o2, SIGTERM);
     }
@@ -1082,7 +1084,6 @@ static int multi_gpu_compress(const Options &o_in, const std::vector<std::string
     fprintf(stderr, "(ERROR) a rank failed\n");
     return 1;
   }
-  if (uncut) return EXIT_UNCUT;  // every rank found the same: -B does not cut this run (the caller goes on with one GPU)
   if (o_in.container != 0) {  // compress.cpp:249: the arithmetic-coded stream is never containerised
     const int hw = (int)std::thread::hardware_concurrency();
     g_threads = o_in.threads > 0 ? o_in.threads : std::max(1, std::min(64, hw - 1));
@@ -1276,12 +1277,8 @@ int main(int argc, char **argv) {
     }
   }
   if (o.gpus > 1 && !o.decompress) {  // forks before anything touches a GPU
-    const int rc = multi_gpu_compress(o, files, argv[0]);
-    if (rc != EXIT_UNCUT) return rc;
-    // The archive of N GPUs is the one-GPU archive only while rank boundaries can sit on spill-chunk boundaries
-    // (compress.cpp:708-715): a run that -B does not cut anywhere is one chunk, and one chunk is one GPU's work.
-    LOG("** -B %llu does not cut this input into spill chunks: compressing on one GPU (give a smaller -B to use %d) **\n",
-        (unsigned long long)o.bucket_set_size, o.gpus);
+    // (a run that -B does not cut anywhere is one chunk: scalce_sharded_compress sends all its rows to rank 0)
+    return multi_gpu_compress(o, files, argv[0]);
   }
   scalce_ctx *ctx = nullptr;
   if (scalce_ctx_create(0, &ctx)) FAIL("%s\n", scalce_last_error(ctx));

@@ -13,12 +13,14 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 #include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,25 +29,22 @@
 
 namespace {
 
-// ---- the few RCCL entry points used, resolved at run time -------------------------------------------------
-typedef struct ncclComm *ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0 };
-enum { ncclUint8 = 1, ncclUint64 = 5 };  // ncclDataType_t (rccl.h)
-enum { ncclSum = 0, ncclMax = 2 };        // ncclRedOp_t
+// ---- the few RCCL entry points used.  Types, enum values and prototypes are <rccl/rccl.h>'s own (decltype of the declared
+// functions); only the ADDRESSES are resolved at run time, so that inside a PyTorch process the one RCCL torch has loaded
+// is the one that runs.
 struct Rccl {
   void *lib = nullptr;
-  int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  int (*CommDestroy)(ncclComm_t) = nullptr;
-  int (*CommCount)(ncclComm_t, int *) = nullptr;
-  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string error;
   bool load() {
     if (lib) return true;
@@ -108,7 +107,7 @@ struct scalce_comm {
 static hipError_t cm_copy(const scalce_comm *c, void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t s);
 #define CM_NCCL(c, expr)                                                                                               \
   do {                                                                                                                 \
-    int r_ = (expr);                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                                          \
     if (r_ != ncclSuccess) { (c)->err = std::string(#expr) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"); return SCALCE_ERR_HIP; } \
   } while (0)
 
@@ -310,46 +309,62 @@ extern "C" int scalce_comm_recv(scalce_comm *c, void *d_buf, uint64_t bytes, int
 extern "C" int scalce_comm_all_to_all_v(scalce_comm *c, const void *d_send, const uint64_t *send_bytes, void *d_recv,
                                         const uint64_t *recv_bytes, void *stream) {
   if (!c || !send_bytes || !recv_bytes) return SCALCE_ERR_ARG;
+  std::vector<uint64_t> so(c->world), ro(c->world);
+  uint64_t a = 0, b = 0;
+  for (int r = 0; r < c->world; r++) { so[r] = a; ro[r] = b; a += send_bytes[r]; b += recv_bytes[r]; }
+  return scalce_comm_all_to_all_vo(c, d_send, so.data(), send_bytes, d_recv, ro.data(), recv_bytes, stream);
+}
+
+// The same with explicit offsets: the bytes for rank d start at d_send + send_off[d], those from rank src land at
+// d_recv + recv_off[src] (a rank that keeps its own part where it is sends 0 bytes to itself and leaves the hole in place).
+extern "C" int scalce_comm_all_to_all_vo(scalce_comm *c, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes,
+                                         void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream) {
+  if (!c || !send_bytes || !recv_bytes || !send_off || !recv_off) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const uint8_t *src = static_cast<const uint8_t *>(d_send);
   uint8_t *dst = static_cast<uint8_t *>(d_recv);
   if (c->world == 1 && !c->nccl) {
     if (send_bytes[0] != recv_bytes[0]) { c->err = "all_to_all_v: sizes disagree"; return SCALCE_ERR_ARG; }
-    if (send_bytes[0]) CM_HIP(c, cm_copy(c, dst, src, send_bytes[0], hipMemcpyDeviceToDevice, s));
+    if (send_bytes[0]) CM_HIP(c, cm_copy(c, dst + recv_off[0], src + send_off[0], send_bytes[0], hipMemcpyDeviceToDevice, s));
     return SCALCE_OK;
   }
   if (!c->shm) {
     // The usual grouped send / receive pattern, in pieces of at most 1 GiB: RCCL takes a size_t count, but a 5 GB message
     // (the q' bytes of a 50 M-read shard) did not arrive whole -- the coded stream of a world-1 run over RCCL came out 18 %
     // larger than over a plain copy (round 4; sends and receives to one peer match in the order they are issued).
-    const uint64_t PIECE = 1ull << 30;
+    static const uint64_t PIECE = getenv("SCALCE_COMM_PIECE") ? strtoull(getenv("SCALCE_COMM_PIECE"), nullptr, 10) : (1ull << 30);  // (tools/rccl_big_send.py)
+    bool any = false;
+    for (int r = 0; r < c->world; r++) any = any || send_bytes[r] || recv_bytes[r];
+    if (!any) return SCALCE_OK;
     CM_NCCL(c, g_rccl.GroupStart());
-    uint64_t so = 0, ro = 0;
     for (int r = 0; r < c->world; r++) {
       for (uint64_t a = 0; a < send_bytes[r]; a += PIECE)
-        CM_NCCL(c, g_rccl.Send(src + so + a, (size_t)std::min<uint64_t>(PIECE, send_bytes[r] - a), ncclUint8, r, c->nccl, s));
+        CM_NCCL(c, g_rccl.Send(src + send_off[r] + a, (size_t)std::min<uint64_t>(PIECE, send_bytes[r] - a), ncclUint8, r, c->nccl, s));
       for (uint64_t a = 0; a < recv_bytes[r]; a += PIECE)
-        CM_NCCL(c, g_rccl.Recv(dst + ro + a, (size_t)std::min<uint64_t>(PIECE, recv_bytes[r] - a), ncclUint8, r, c->nccl, s));
-      so += send_bytes[r];
-      ro += recv_bytes[r];
+        CM_NCCL(c, g_rccl.Recv(dst + recv_off[r] + a, (size_t)std::min<uint64_t>(PIECE, recv_bytes[r] - a), ncclUint8, r, c->nccl, s));
     }
     CM_NCCL(c, g_rccl.GroupEnd());
     return SCALCE_OK;
   }
+  // rehearsal transport: every rank packs what it sends into its slot (destination order), everybody picks up its part
   uint64_t total = 0;
   for (int r = 0; r < c->world; r++) total += send_bytes[r];
   if (total > c->slot_bytes) { c->err = "shm transport: message larger than a slot (rehearsal transport)"; return SCALCE_ERR_CAPACITY; }
-  if (total) CM_HIP(c, cm_copy(c, c->slots + (size_t)c->rank * c->slot_bytes, src, total, hipMemcpyDeviceToHost, s));
+  {
+    uint64_t at = 0;
+    for (int r = 0; r < c->world; r++) {
+      if (send_bytes[r]) CM_HIP(c, cm_copy(c, c->slots + (size_t)c->rank * c->slot_bytes + at, src + send_off[r], send_bytes[r], hipMemcpyDeviceToHost, s));
+      at += send_bytes[r];
+    }
+  }
   for (int r = 0; r < c->world; r++) c->hdr->sizes[c->rank][r] = send_bytes[r];
   CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);
-  uint64_t ro = 0;
   for (int r = 0; r < c->world; r++) {
     if (c->hdr->sizes[r][c->rank] != recv_bytes[r]) { c->err = "all_to_all_v: a sender's size differs from what the receiver expects"; pthread_barrier_wait(&c->hdr->barrier); return SCALCE_ERR_ARG; }
     uint64_t off = 0;
     for (int d = 0; d < c->rank; d++) off += c->hdr->sizes[r][d];
-    if (recv_bytes[r]) CM_HIP(c, cm_copy(c, dst + ro, c->slots + (size_t)r * c->slot_bytes + off, recv_bytes[r], hipMemcpyHostToDevice, s));
-    ro += recv_bytes[r];
+    if (recv_bytes[r]) CM_HIP(c, cm_copy(c, dst + recv_off[r], c->slots + (size_t)r * c->slot_bytes + off, recv_bytes[r], hipMemcpyHostToDevice, s));
   }
   CM_HIP(c, cm_sync(c, s));
   pthread_barrier_wait(&c->hdr->barrier);

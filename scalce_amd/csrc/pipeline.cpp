@@ -53,7 +53,7 @@ int flush(scalce_pipeline *p, int last, int *launched) {
   hipStream_t coder = p->coders[p->launches++ % p->coders.size()];
   std::vector<scalce_batch *> grp;
   for (int sl : p->pending) grp.push_back(p->b[sl]);
-  const int rc = scalce_batch_entropy_begin_group_last(grp.data(), (int)grp.size(), p->front, coder, p->external ? 0 : (last ? 1 : 0));
+  const int rc = scalce_batch_entropy_begin_group_last(grp.data(), (int)grp.size(), p->front, coder, last ? 1 : 0);
   if (rc) { p->err = "scalce_batch_entropy_begin_group_last failed"; return rc; }
   for (int sl : p->pending) {
     PL_HIP(p, hipEventRecord(p->ev[sl], coder));

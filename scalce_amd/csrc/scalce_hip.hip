@@ -302,14 +302,16 @@ struct scalce_workspace {
   DBuf tw_cells, tw_cand, tw_bits, tw_base;  // the tie-break in windows (tokenize_windows)
   DBuf tile_mm[2];                           // per text tile: smallest / largest q' symbol (ingest_tiles2_k)
   const void *tile_mm_owner[2] = {nullptr, nullptr};  // the batch whose piece they describe (batches share a workspace)
+  const void *walk_owner = nullptr;          // the batch whose first walk tok_bucket / tok_pos hold (scalce_batch_chunk_plan)
   DBuf cell_sorted;                          // name cells in output order (emit stage)
+  DBuf qs_shared[2];                         // reordered q' stream of batches that only pass it on (scalce_batch_set_stream_scratch)
   void free_all() {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
                    &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
                    &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
                    &cand_place, &Gseg, &cand_fixed, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
                    &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
-                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1], &cell_sorted};
+                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1], &cell_sorted, &qs_shared[0], &qs_shared[1]};
     for (DBuf *d : all)
       if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
     row_cap = piece_rows_cap = 0;
@@ -348,6 +350,8 @@ struct scalce_batch {
   u64 tri_expected[2] = {0, 0};  // trigrams counted so far (tri_check_k)
   u64 names_in_used = 0;     // bytes of the long-name store in use
   u64 S_rows = ~0ull;        // rows the record-size prefix sums in S cover (scalce_batch_chunk_plan), ~0 = stale
+  u64 walk_rows = 0;         // rows [0, walk_rows) whose first tokenizer walk (tok_bucket / tok_pos) scalce_batch_chunk_plan has
+                             // already done: scalce_batch_tokenize_begin over exactly these rows does not walk them again
   u64 text_bytes[2] = {0, 0};
   const u8 *piece_text[2] = {nullptr, nullptr};  // the piece ingested last (its line index is built on demand)
   bool line_index_ok[2] = {false, false};
@@ -366,7 +370,13 @@ struct scalce_batch {
   DBuf &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty, &cand_place, &Gseg, &cand_fixed;
   DBuf &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start;
   // what the coder and the caller read behind the emit stage: the batch's own
-  DBuf freq4[2], table[2], qs[2], counts_total, bucket_name_bytes, ac_scan;
+  DBuf freq4[2], table[2], qs_own[2], counts_total, bucket_name_bytes, ac_scan;
+  // The reordered q' stream: the batch's own (the coder reads it long after the emit stage), or -- scalce_batch_set_stream_scratch,
+  // sharded runs: the stream is handed to other ranks right behind the emit stage and the coder reads what came back -- the
+  // workspace's, valid until the next batch of the workspace runs its emit stage.
+  bool qs_in_ws = false;
+  DBuf &qs(int m) { return qs_in_ws ? ws->qs_shared[m] : qs_own[m]; }
+  const DBuf &qs(int m) const { return qs_in_ws ? ws->qs_shared[m] : qs_own[m]; }
   const u64 *sorted_keys = nullptr;  // phase-1 keys in output order (order stage), consumed by the emit stage
   u32 key_end_bits = 0, key_bucket_shift = 0, key_bucket_mask = 0;
   DBuf &perm_a, &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b, &run_pos;
@@ -479,7 +489,7 @@ static void release(DBuf &d) {
 }
 
 static void free_all(scalce_batch *b) {
-  DBuf *all[] = {&b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs[0], &b->qs[1], &b->counts_total, &b->bucket_name_bytes,
+  DBuf *all[] = {&b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs_own[0], &b->qs_own[1], &b->counts_total, &b->bucket_name_bytes,
                  &b->ac_scan, &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->ac_tab[0], &b->ac_cum[0], &b->ac_blocks[0],
                  &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1], &b->ac_sizes[1], &b->ac_off[1],
                  &b->ac_desc, &b->out_qual[0], &b->out_qual[1], &b->ac_tab8[0], &b->ac_tab8[1], &b->q_compact, &b->fuse_q, &b->fuse_cells};
@@ -876,11 +886,14 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
 static void batch_restart(scalce_batch *b) {
   b->N = b->base = b->NP = 0;
   b->S_rows = ~0ull;
+  b->walk_rows = 0;
   b->tok_done = b->tok_base = b->tok_n = 0;
   b->appending = false;
   b->names_in_used = 0;
   b->tri_expected[0] = b->tri_expected[1] = 0;
   b->ingested[0] = b->ingested[1] = false;
+  // (frames laid out but not copied belong to the shard that is being replaced: scalce_batch_qual_window must not serve them)
+  for (int m = 0; m < 2; m++) { b->frame_virtual[m] = 0; b->frame_off_host[m].clear(); }
 }
 
 extern "C" int scalce_batch_reset(scalce_batch *b) {
@@ -992,6 +1005,12 @@ extern "C" void scalce_batch_set_lean(scalce_batch *b, int lean) {
   b->lean = lean != 0;
   if (b->lean) unfuse(b);
 }
+extern "C" int scalce_batch_set_stream_scratch(scalce_batch *b, int on) {
+  if (!b) return SCALCE_ERR_ARG;
+  if (on && (b->p.no_ac || b->lean)) return SCALCE_ERR_ARG;  // -A: the stream IS the output (compress.cpp:389-390)
+  b->qs_in_ws = on != 0;
+  return SCALCE_OK;
+}
 extern "C" int scalce_batch_set_fused_rows(scalce_batch *b, int on) {
   if (!b) return SCALCE_ERR_ARG;
   if (!on) unfuse(b);
@@ -1098,8 +1117,8 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     b->ntie = b->nev = 0;
     return SCALCE_OK;
   }
-  // pass A: every read
-  {
+  // pass A: every read (unless scalce_batch_chunk_plan has walked exactly these rows already: sharded runs)
+  if (!(b->tok_base == 0 && b->walk_rows == N && b->ws->walk_owner == b)) {
     TokArgs a;
     a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
     a.packed = packed0; a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
@@ -1118,6 +1137,8 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
   }
+  b->walk_rows = 0;  // (the scans below rewrite tok_pos)
+  b->ws->walk_owner = nullptr;
   // tie reads: compact, then size the candidate lists by their hit counts
   ENSURE(b, b->tie_read, sizeof(u32) * (N + 1));
   exclusive_scan<u32>(TieFlag{b->tok_pos.as<u32>()}, N,
@@ -1559,6 +1580,8 @@ extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint6
     else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
     else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
     else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+    b->walk_rows = b->tok_done == 0 ? N : 0;  // (tok_bucket / tok_pos are indexed from the first row not tokenized yet)
+    b->ws->walk_owner = b;
   }
   ENSURE(b, b->S, sizeof(u64) * (N + 2));
   ENSURE(b, b->scan_ws, sizeof(u64) * (scan_ws_elems(N + 1) + 1024));
@@ -1813,14 +1836,14 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
       // lie in ONE row of the ingest stage's making (128 bytes = one aligned line at 100 bp), fetched whole into LDS with every
       // thread's loads in flight at once.  One random line per record instead of three (packed row + q' row for
       // gather_rows_k, each paying its own).
-      ENSURE(b, b->qs[0], (size_t)b->L[0] * N + 64);
+      ENSURE(b, b->qs(0), (size_t)b->L[0] * N + 64);
       a.frow = b->q[0].as<u8>(); a.stride = (int)b->qstride[0]; a.cell_off = b->row_cell_off; a.pwords = (int)b->row_pwords;
       a.packed = a.frow + b->row_cell_off;
       a.qunits = ((u32)b->L[0] + 15) / 16;
       a.qmagic = ((1ull << 32) + a.qunits - 1) / a.qunits;
       a.rmagic = ((1ull << 32) + (b->qstride[0] >> 4) - 1) / (b->qstride[0] >> 4);
       a.lmagic = ((1ull << 32) + (u32)b->L[0] - 1) / (u32)b->L[0];
-      a.qs = b->qs[0].as<u8>();
+      a.qs = b->qs(0).as<u8>();
       if (const char *e = getenv("SCALCE_EMIT_ABLATE")) {  // timing experiments only: the output is wrong
         if (strchr(e, 'q')) a.qs = nullptr;
         if (strchr(e, 'p')) a.pwords = 0;
@@ -1840,14 +1863,14 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     for (int m = 0; m < b->nm; m++) {
       const u32 w = (u32)b->L[m];
       if (m == 0 && b->fused) continue;  // (emit_reads_k<true> has done it)
-      ENSURE(b, b->qs[m], (size_t)w * N + 64);
-      LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)b->qstride[m], w, b->qs[m].as<u8>());
+      ENSURE(b, b->qs(m), (size_t)w * N + 64);
+      LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)b->qstride[m], w, b->qs(m).as<u8>());
       if (b->lean) {
         // q' in input order is dead once its reordered copy exists.  Mate 1's buffer becomes mate 2's reordered stream (an
         // allocation and a release of tens of GB each cost a good part of a second), the last one is released.
         HIP_TRY(c, hipStreamSynchronize(s));
-        if (m == 0 && b->nm == 2 && !b->qs[1].p && b->q[0].cap >= (size_t)b->L[1] * N + 64) {
-          b->qs[1] = b->q[0];
+        if (m == 0 && b->nm == 2 && !b->qs(1).p && b->q[0].cap >= (size_t)b->L[1] * N + 64) {
+          b->qs(1) = b->q[0];
           b->q[0] = DBuf();
         } else {
           release(b->q[m]);
@@ -2264,6 +2287,8 @@ static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, h
     nsym[m] = N * (u64)b->L[m];
     nblk[m] = cdiv(nsym[m], AC_BLOCK_SYMS);
     most = nblk[m] > most ? nblk[m] : most;
+    b->frame_virtual[m] = 0;   // this path writes the framed stream itself: a layout left by an earlier shard is void
+    b->frame_off_host[m].clear();
     int rc = ac_table_for(b, m, d_table_override, nsym[m], s);
     if (rc) return rc;
     b->out_qual_bytes[m] = 0;
@@ -2276,7 +2301,7 @@ static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, h
       if (w0 >= nblk[m]) continue;
       const u64 off = (u64)w0 * AC_BLOCK_SYMS;
       const u64 n = std::min<u64>(nsym[m] - off, (u64)W * AC_BLOCK_SYMS);
-      jobs[nj] = AcJob{b, m, b->qs[m].as<u8>() + off, n, 0, false};
+      jobs[nj] = AcJob{b, m, b->qs(m).as<u8>() + off, n, 0, false};
       int rc = ac_prepare(jobs[nj], s, /*framed_output=*/false, /*full_stride=*/true);  // (windows are collected as they go: no second try)
       if (rc) return rc;
       nj++;
@@ -2328,7 +2353,7 @@ extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_tab
       const u64 nsym = N * (u64)b->L[m];
       int rc = ac_table_for(b, m, d_table_override, nsym, s);
       if (rc) return rc;
-      jobs[m] = AcJob{b, m, b->qs[m].as<u8>(), nsym, 0, false};
+      jobs[m] = AcJob{b, m, b->qs(m).as<u8>(), nsym, 0, false};
       if ((rc = ac_prepare(jobs[m], s))) return rc;
       total += jobs[m].nblk;
     }
@@ -2346,7 +2371,7 @@ extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_tab
     }
     int rc = ac_table_for(b, m, d_table_override, nsym, s);
     if (rc) return rc;
-    if ((rc = encode_stream(b, m, b->qs[m].as<u8>(), nsym, s))) return rc;
+    if ((rc = encode_stream(b, m, b->qs(m).as<u8>(), nsym, s))) return rc;
   }
   return SCALCE_OK;
 }
@@ -2375,7 +2400,7 @@ extern "C" int scalce_batch_entropy_begin_group_last(scalce_batch **bs, int n, v
     for (int m = 0; m < b->nm; m++) {
       const u64 own = b->N * (u64)b->L[m];
       if (b->p.no_ac) { b->out_qual_bytes[m] = own; continue; }
-      AcJob j{b, m, b->ent_external[m] ? b->ent_sym[m] : b->qs[m].as<u8>(), b->ent_external[m] ? b->ent_nsym[m] : own, 0, false};
+      AcJob j{b, m, b->ent_external[m] ? b->ent_sym[m] : b->qs(m).as<u8>(), b->ent_external[m] ? b->ent_nsym[m] : own, 0, false};
       if (!b->ent_external[m]) { int rc = ac_table_for(b, m, nullptr, own, ps); if (rc) return rc; }
       b->ent_external[m] = false;
       int rc = ac_prepare(j, ps, /*framed_output=*/!frames_at_collect());
@@ -2562,7 +2587,7 @@ extern "C" int scalce_batch_qual_window(scalce_batch *b, int mate, uint64_t offs
   if (offset > b->out_qual_bytes[mate] || nbytes > b->out_qual_bytes[mate] - offset) { set_err(c, "window beyond the stream"); return SCALCE_ERR_ARG; }
   if (!nbytes) return SCALCE_OK;
   if (b->p.no_ac || !b->frame_virtual[mate]) {  // the stream exists as such
-    const u8 *src = b->p.no_ac ? b->qs[mate].as<u8>() : b->out_qual[mate].as<u8>();
+    const u8 *src = b->p.no_ac ? b->qs(mate).as<u8>() : b->out_qual[mate].as<u8>();
     HIP_TRY(c, hipMemcpyAsync(dst, src + offset, nbytes, hipMemcpyDefault, s));
     return SCALCE_OK;
   }
@@ -2603,14 +2628,14 @@ extern "C" int scalce_batch_output(const scalce_batch *b, int which, int mate, c
     case SCALCE_OUT_READS: *d_ptr = b->out_reads[mate].p; *nbytes = b->out_reads_bytes[mate]; break;
     case SCALCE_OUT_NAMES: *d_ptr = b->out_names.p; *nbytes = b->out_names_bytes; break;
     case SCALCE_OUT_QUAL:
-      *d_ptr = b->p.no_ac ? b->qs[mate].p : b->out_qual[mate].p;
+      *d_ptr = b->p.no_ac ? b->qs(mate).p : b->out_qual[mate].p;
       *nbytes = b->out_qual_bytes[mate];
       break;
     case SCALCE_OUT_TABLE: *d_ptr = b->table[mate].p; *nbytes = sizeof(u32) * 512000; break;
     case SCALCE_OUT_FREQ4: *d_ptr = b->freq4[mate].p; *nbytes = sizeof(u64) * 512000; break;
     case SCALCE_OUT_TOKENS: *d_ptr = b->tokens.p; *nbytes = sizeof(int32_t) * 2 * b->N; break;
     case SCALCE_OUT_PERM: *d_ptr = b->perm; *nbytes = sizeof(u32) * b->N; break;
-    case SCALCE_OUT_QSTREAM: *d_ptr = b->qs[mate].p; *nbytes = b->N * (u64)b->L[mate]; break;
+    case SCALCE_OUT_QSTREAM: *d_ptr = b->qs(mate).p; *nbytes = b->N * (u64)b->L[mate]; break;
     case SCALCE_OUT_BUCKET_COUNTS: *d_ptr = b->tok_open ? b->counts.p : b->counts_total.p; *nbytes = sizeof(u64) * nb1; break;
     case SCALCE_OUT_QINPUT:
       *nbytes = b->N * (u64)b->L[mate];

@@ -233,6 +233,12 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
   }
   res->world = W;
   res->rank = rank;
+  // The reordered q' stream of this call is only passed on (step 8): it lives in the workspace the batch shares with the other
+  // shards in flight, not in the batch -- 5 GB less per slot at 50 M reads of 100 bp.  (Not under -A: the stream is the output.)
+  struct StreamScratch {
+    scalce_batch *b; bool on;
+    ~StreamScratch() { if (on) scalce_batch_set_stream_scratch(b, 0); }
+  } stream_scratch{b, scalce_batch_set_stream_scratch(b, 1) == SCALCE_OK};
   static std::string last_error;
   // SCALCE_SHARD_TRACE=1: where a rank's time goes (the stream is drained at every mark: for looking, not for timing runs)
   const bool trace = getenv("SCALCE_SHARD_TRACE") != nullptr;
@@ -468,19 +474,29 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     // start-up skew of one settle per rank in front -- with several shards in flight the ranks work on different shards.
     // SCALCE_SHARD_TIE_ROUNDS=1 keeps the rounds (comparisons).
     {
+      const uint32_t stride = nb1 + 1;
+      u64 *d_msg = nullptr;  // the chain's message: [0] status of the ranks in front (0 = fine), [1 ..] their counts per bucket
+      local([&] { d_msg = mem.alloc<u64>(stride); });  // (before the agree(): a rank that cannot even hold the message stops everybody there)
       local([&] { SH_RC(ctx, scalce_batch_tokenize_begin(b, s)); });
       if (W > 1) agree("tokenizer"); else if (local_err.rc) throw local_err;
-      const uint32_t stride = nb1 + 1;
       static const bool rounds_mode = getenv("SCALCE_SHARD_TIE_ROUNDS") != nullptr;
       if (!rounds_mode) {
-        u64 *d_msg = mem.alloc<u64>(stride);       // [0] status of the ranks in front (0 = fine), [1 ..] their counts per bucket
+        // Everything between the receive and the send runs under local(): whatever fails here -- the receive itself, a copy,
+        // the settle, the counts -- this rank still SENDS (status = its error code), so the rank behind never sits in a receive
+        // that nobody answers (RCCL has no timeout), and every rank reaches the agree() below and throws there together.
         u64 upstream = 0;
         if (rank > 0) {
-          SH_CM(comm, scalce_comm_recv(comm, d_msg, (size_t)stride * 8, rank - 1, s));
-          SH_HIP(hipMemcpyAsync(&upstream, d_msg, 8, hipMemcpyDeviceToHost, s));
-          SH_HIP(hipStreamSynchronize(s));
+          // (the receive is posted even when this rank has already failed: the rank in front sends in any case, and a send
+          //  that nobody takes would block its stream in front of the agree() below)
+          try {
+            SH_CM(comm, scalce_comm_recv(comm, d_msg, (size_t)stride * 8, rank - 1, s));
+            SH_HIP(hipMemcpyAsync(&upstream, d_msg, 8, hipMemcpyDeviceToHost, s));
+            SH_HIP(hipStreamSynchronize(s));
+          } catch (const Fail &f) {
+            if (!local_err.rc) { local_err = f; if (!local_err.rc) local_err.rc = SCALCE_ERR_HIP; }
+          }
         } else {
-          SH_HIP(hipMemsetAsync(d_msg, 0, (size_t)stride * 8, s));
+          local([&] { SH_HIP(hipMemsetAsync(d_msg, 0, (size_t)stride * 8, s)); });
         }
         if (!upstream)
           local([&] { SH_RC(ctx, scalce_batch_tokenize_settle(b, rank > 0 ? reinterpret_cast<const uint64_t *>(d_msg + 1) : nullptr, s)); });
@@ -489,14 +505,20 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         res->rounds = 1;
         res->sweeps = 0;
         if (rank + 1 < W) {
-          u64 status = upstream ? upstream : (local_err.rc ? 2 + (u64)local_err.rc : 0);
-          if (!local_err.rc) {
+          local([&] {
             SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dp, &nb));
             hipLaunchKernelGGL(add_counts_into_k, dim3((nb1 + 255) / 256), dim3(256), 0, s, nb1, static_cast<const u64 *>(dp), d_msg + 1);
+          });
+          // the message goes out whatever happened above; only a send that itself fails is left to the transport's own error
+          // (the peer of a dead communicator gets an error from its receive, not a hang)
+          const u64 status = upstream ? upstream : (local_err.rc ? 2 + (u64)local_err.rc : 0);
+          hipError_t he = hipMemcpyAsync(d_msg, &status, 8, hipMemcpyHostToDevice, s);
+          if (he == hipSuccess) he = hipStreamSynchronize(s);  // `status` is a stack variable
+          const int src = scalce_comm_send(comm, d_msg, (size_t)stride * 8, rank + 1, s);
+          if (!local_err.rc) {
+            if (he != hipSuccess) local_err = Fail{std::string("tie-break chain, status word: ") + hipGetErrorString(he), SCALCE_ERR_HIP};
+            else if (src) local_err = Fail{std::string("scalce_comm_send (tie-break chain): ") + scalce_comm_error(comm), src};
           }
-          SH_HIP(hipMemcpyAsync(d_msg, &status, 8, hipMemcpyHostToDevice, s));
-          SH_HIP(hipStreamSynchronize(s));  // `status` is a stack variable
-          SH_CM(comm, scalce_comm_send(comm, d_msg, (size_t)stride * 8, rank + 1, s));
         }
       } else {
       u64 *d_mine = mem.alloc<u64>(stride), *d_all = mem.alloc<u64>((size_t)W * stride), *d_prior = mem.alloc<u64>(nb1);
@@ -581,14 +603,47 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         for (int r = 0; r < W; r++) recv_total += recvb[r];
         SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_QSTREAM, m, &dp, &nb));
         if (nb != N * Lm) throw Fail{"internal: reordered stream has an unexpected size", SCALCE_ERR_ARG};
-        uint8_t *d_got = mem.alloc<uint8_t>(recv_total);
+        // What stays on this rank never goes through the transport: its pieces are copied straight from the local stream
+        // (at one rank that is everything: 5 GB per 50 M-read shard that round 4 sent to itself through ncclSend / ncclRecv,
+        // 16 of that path's 19 ms).  The receive buffer only holds what other ranks send, in rank order.
+        u64 self_at = 0, local_off = 0;   // where the own bytes would lie in a full receive buffer / where they lie in the local stream
+        for (int r = 0; r < rank; r++) { self_at += recvb[r]; local_off += sendb[r]; }
+        const u64 self_bytes = recvb[rank];
+        if (self_bytes != sendb[rank]) throw Fail{"internal: block-range plan disagrees with itself about the bytes that stay", SCALCE_ERR_ARG};
+        std::vector<uint64_t> sb = sendb, rb = recvb;
+        sb[rank] = 0;
+        rb[rank] = 0;
+        uint8_t *d_got = mem.alloc<uint8_t>(recv_total - self_bytes);
         uint8_t *d_mine = keep_alloc<uint8_t>(res, m, hi - lo + 16);
-        SH_CM(comm, scalce_comm_all_to_all_v(comm, dp, sendb.data(), d_got, recvb.data(), s));
+        // (the send buffer is the local stream itself, every range where it lies; the own range is the hole in the middle)
+        if (W > 1) {
+          std::vector<uint64_t> so(W), ro(W);
+          u64 a = 0, g = 0;
+          for (int r = 0; r < W; r++) { so[r] = a; ro[r] = g; a += sendb[r]; g += rb[r]; }
+          SH_CM(comm, scalce_comm_all_to_all_vo(comm, dp, so.data(), sb.data(), d_got, ro.data(), rb.data(), s));
+        }
         if (!psrc.empty()) {
+          // pieces are source-major: [from ranks in front | own | from ranks behind]; the own ones read the local stream
+          std::vector<uint64_t> ps_o, pd_o, ps_x, pd_x;
+          u64 own_total = 0, other_total = 0;
+          for (size_t i = 0; i < psrc.size(); i++) {
+            const u64 len = (i + 1 < psrc.size() ? psrc[i + 1] : recv_total) - psrc[i];
+            if (psrc[i] >= self_at && psrc[i] < self_at + self_bytes) { ps_o.push_back(psrc[i] - self_at); pd_o.push_back(pdst[i]); own_total += len; }
+            else { ps_x.push_back(psrc[i] < self_at ? psrc[i] : psrc[i] - self_bytes); pd_x.push_back(pdst[i]); other_total += len; }
+          }
+          if (own_total != self_bytes || other_total != recv_total - self_bytes) throw Fail{"internal: block-range pieces do not add up", SCALCE_ERR_ARG};
           uint64_t *d_ps = mem.alloc<uint64_t>(psrc.size()), *d_pd = mem.alloc<uint64_t>(psrc.size());
-          SH_HIP(hipMemcpyAsync(d_ps, psrc.data(), psrc.size() * 8, hipMemcpyHostToDevice, s));
-          SH_HIP(hipMemcpyAsync(d_pd, pdst.data(), pdst.size() * 8, hipMemcpyHostToDevice, s));
-          SH_RC(ctx, scalce_copy_pieces(ctx, d_got, d_mine, d_ps, d_pd, (uint32_t)psrc.size(), recv_total, s));
+          if (!ps_x.empty()) {
+            SH_HIP(hipMemcpyAsync(d_ps, ps_x.data(), ps_x.size() * 8, hipMemcpyHostToDevice, s));
+            SH_HIP(hipMemcpyAsync(d_pd, pd_x.data(), pd_x.size() * 8, hipMemcpyHostToDevice, s));
+            SH_RC(ctx, scalce_copy_pieces(ctx, d_got, d_mine, d_ps, d_pd, (uint32_t)ps_x.size(), other_total, s));
+          }
+          if (!ps_o.empty()) {
+            uint64_t *d_ps2 = d_ps + ps_x.size(), *d_pd2 = d_pd + ps_x.size();
+            SH_HIP(hipMemcpyAsync(d_ps2, ps_o.data(), ps_o.size() * 8, hipMemcpyHostToDevice, s));
+            SH_HIP(hipMemcpyAsync(d_pd2, pd_o.data(), pd_o.size() * 8, hipMemcpyHostToDevice, s));
+            SH_RC(ctx, scalce_copy_pieces(ctx, static_cast<const uint8_t *>(dp) + local_off, d_mine, d_ps2, d_pd2, (uint32_t)ps_o.size(), own_total, s));
+          }
           SH_HIP(hipStreamSynchronize(s));  // the piece lists are host vectors of this scope
         }
         res->sym_lo[m] = lo;

@@ -294,6 +294,12 @@ class Comm:
     def all_reduce_sum_u64(self, d_buf, count, stream=0):
         self._check(self.L.scalce_comm_all_reduce_sum_u64(self.h, d_buf, int(count), stream))
 
+    def all_to_all_v(self, d_send, send_bytes, d_recv, recv_bytes, stream=0):
+        """send_bytes[d] bytes to every rank d (consecutive ranges of d_send), recv_bytes[src] from every rank src."""
+        sb = (C.c_uint64 * self.world)(*[int(x) for x in send_bytes])
+        rb = (C.c_uint64 * self.world)(*[int(x) for x in recv_bytes])
+        self._check(self.L.scalce_comm_all_to_all_v(self.h, d_send, sb, d_recv, rb, stream))
+
     def close(self):
         if self.h:
             self.L.scalce_comm_destroy(self.h)
@@ -309,6 +315,24 @@ def sharded_compress(comm, ctx, batch, d_text1, n1, d_text2=None, n2=0, flags=0,
     if rc:
         raise ScalceError(f"[{rc}] sharded run failed on rank {comm.rank} (message on stderr)")
     return res
+
+
+def shard_plan_blocks(world, rank, nb1, counts, read_len):
+    """scalce_shard_plan_blocks: the run-wide reordered quality stream dealt out in ranges of whole 10 MiB blocks.
+    counts = [world][nb1] reads per (rank, bucket).  Returns (send_bytes, recv_bytes, lo, hi, piece_src, piece_dst)."""
+    L = lib()
+    u64p = C.POINTER(C.c_uint64)
+    L.scalce_shard_plan_blocks.argtypes = [C.c_int, C.c_int, C.c_uint32, u64p, C.c_uint64, u64p, u64p, u64p, u64p, u64p, u64p, u64p]
+    flat = np.ascontiguousarray(counts, dtype=np.uint64).reshape(-1)
+    send, recv = np.zeros(world, np.uint64), np.zeros(world, np.uint64)
+    ps, pd = np.zeros(world * nb1 + 1, np.uint64), np.zeros(world * nb1 + 1, np.uint64)
+    lo, hi, npc = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = L.scalce_shard_plan_blocks(world, rank, nb1, flat.ctypes.data_as(u64p), int(read_len), send.ctypes.data_as(u64p),
+                                    recv.ctypes.data_as(u64p), C.byref(lo), C.byref(hi), ps.ctypes.data_as(u64p), pd.ctypes.data_as(u64p),
+                                    C.byref(npc))
+    if rc:
+        raise ScalceError(f"[{rc}] scalce_shard_plan_blocks")
+    return send, recv, int(lo.value), int(hi.value), ps[: npc.value].copy(), pd[: npc.value].copy()
 
 
 def shard_result_free(res):

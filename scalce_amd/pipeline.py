@@ -102,7 +102,7 @@ class ShardPipeline:
             self._retired(slot)
 
     # -- coder launches ------------------------------------------------------------------------------------
-    def submit(self, slot, tag=None, flush=False, remaining=None):
+    def submit(self, slot, tag=None, flush=False):
         """The front stages of `slot` are enqueued on `self.front`: launch the coder now or with the next shards.
         flush: the caller has no further shards -- the last launch of a run is picked for its own latency."""
         self._tag[slot] = tag

@@ -122,3 +122,60 @@ def archive_hashes(batch, read_len, phred, n_reads):
     h.update(batch.output(host.OUT_NAMES, 0).tobytes())
     out["1.scalcen"] = h.hexdigest()
     return out
+
+
+def sharded_records_text(comm, ctx, batch, res, read_len, phred, device):
+    """One rank's part of a sharded run's self-check (bench.py at N > 1): the inverse of what scalce_sharded_compress did with
+    the quality stream.  The rank decodes the coder blocks IT holds -- its range [sym_lo, sym_hi) of the run-wide reordered
+    stream, coded against the run-wide table -- on the device; the symbols go back to the ranks whose records they belong to
+    (the block-range plan run backwards: pieces out of the range, an all-to-all with send and receive sizes swapped), and
+    every rank rebuilds the FASTQ text of the records it emitted from its own read and name streams and the symbols that came
+    back.  Returns that text (uint8 device tensor); the caller sums record_digest() of it over the ranks and compares with
+    the sum over the inputs -- records change owner between ranks, the multiset of the run does not."""
+    import ctypes as C
+
+    import torch
+    W, rank, nb1 = comm.world, comm.rank, int(res.nb1)
+    counts = np.ctypeslib.as_array(res.counts, shape=(W * nb1,)).copy().reshape(W, nb1)
+    send, recv, lo, hi, psrc, pdst = host.shard_plan_blocks(W, rank, nb1, counts, read_len)
+    assert (lo, hi) == (int(res.sym_lo[0]), int(res.sym_hi[0])), "block-range plan differs from the run's"
+    n_local = int(res.reads_local)
+    assert int(counts[rank].sum()) == n_local
+    nmine = hi - lo
+    sym = torch.empty(nmine + 64, dtype=torch.uint8, device=device)
+    if nmine:
+        p, nbytes = batch.output_ptr(host.OUT_QUAL, 0)
+        ctx.ac_decode(batch.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nmine, sym.data_ptr())
+    # pieces of my range -> what every source rank sent, source-major (the layout the forward all-to-all delivered)
+    recv_total = int(recv.sum())
+    assert recv_total == nmine
+    got = torch.empty(recv_total + 64, dtype=torch.uint8, device=device)
+    if len(psrc):
+        order = np.argsort(pdst, kind="stable")     # copy_pieces wants its pieces in source order: here the range itself
+        src_off = torch.from_numpy(pdst[order].astype(np.int64)).to(device)
+        dst_off = torch.from_numpy(psrc[order].astype(np.int64)).to(device)
+        ctx.copy_pieces(sym.data_ptr(), got.data_ptr(), src_off.data_ptr(), dst_off.data_ptr(), len(order), recv_total)
+    torch.cuda.synchronize()
+    del sym
+    back = torch.empty(n_local * read_len + 64, dtype=torch.uint8, device=device)
+    assert int(send.sum()) == n_local * read_len
+    comm.all_to_all_v(got.data_ptr(), recv, back.data_ptr(), send)   # sizes swapped: the way back
+    torch.cuda.synchronize()
+    del got
+    reads = batch.output(host.OUT_READS, 0)
+    names = batch.output(host.OUT_NAMES, 0)
+    L = ctx.L
+    cap = L.scalce_fastq_text_bytes(read_len, n_local, len(names), None)
+    out = torch.empty(cap + 64, dtype=torch.uint8, device=device)
+    nb = C.c_uint64(0)
+    if n_local:
+        ctx._check(L.scalce_fastq_records(ctx.h, read_len, 1, reads.ctypes.data, len(reads), n_local, back.data_ptr(), int(phred),
+                                          names.ctypes.data, len(names), b"", 0, out.data_ptr(), cap, C.byref(nb), None, 0))
+        torch.cuda.synchronize()
+    return out[: nb.value]
+
+
+def digest_sum(digests):
+    """Sum of (records, s1, s2) triples modulo 2^64: the digest of the union of the texts."""
+    m = (1 << 64) - 1
+    return (sum(d[0] for d in digests), sum(d[1] for d in digests) & m, sum(d[2] for d in digests) & m)

@@ -38,6 +38,14 @@ CASES = {
     # several input files in one run; the first holds fewer records than -s: the quality sample stops at its end
     # (get_quality_stats reads files[0] only, compress.cpp:761, qualities.cpp:66-78)
     "multi": dict(SE, flags=["-s", "5000", "-p", "30"], files=[700, 19300, 10000], oracle=False),
+    # what real FASTQ holds beside ACGTN: lower-case bases (soft-masked) and IUPAC ambiguity letters -- getval (const.cpp:47-49,
+    # const.h:127) maps a c g t like A C G T and every other letter to 0 (= A); only an upper-case 'N' zeroes the quality
+    # (qualities.cpp:183), and a base whose quality maps to 0 comes back as 'N' (decompress.cpp:350-351)
+    "se100_letters": dict(SE, flags=[], letters=True),
+    "se100_letters_p30": dict(SE, flags=["-p", "30"], letters=True),
+    # Phred+64 qualities (Illumina 1.3-1.7): no character below 64 in the sample -> offset 64 (qualities.cpp:99-104)
+    "se100_phred64": dict(SE, flags=[], phred64=True),
+    "se100_phred64_p30": dict(SE, flags=["-p", "30"], phred64=True),
 }
 
 
@@ -73,6 +81,17 @@ def write_inputs(name, d):
     mates = []
     for m, seed in enumerate([c["seed"]] + ([c["seed2"]] if paired(name) else [])):
         bases, quals = synth.reads_and_quals(c["n"], c["L"], seed=seed, **c["kw"])
+        if c.get("letters"):
+            import numpy as np
+            rng = np.random.default_rng(seed + 1000)
+            low = rng.random(bases.shape) < 0.12                     # soft-masked stretches and single bases, 'n' among them
+            low[rng.integers(0, c["n"], 200), :] = True              # (whole reads in lower case as well)
+            bases = np.where(low, bases | 0x20, bases)
+            amb = np.frombuffer(b"RYKMSWBDHVUXryksw", dtype=np.uint8)
+            hit = rng.random(bases.shape) < 0.01
+            bases = np.where(hit, amb[rng.integers(0, len(amb), bases.shape)], bases)
+        if c.get("phred64"):
+            quals = quals + 31
         if paired(name):
             text = synth.fastq_bytes_fast(bases, quals, prefix="p.", suffix="/%d" % (m + 1))
         else:

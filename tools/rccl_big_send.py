@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Where does a large RCCL send / receive stop?  (round 4 found that a 5 GB ncclSend / ncclRecv of one rank to itself did not
+arrive whole; comm.cpp sends in pieces of 1 GiB since.)  One rank, the library's own communicator, SCALCE_COMM_PIECE set so
+large that every message goes out as ONE ncclSend / ncclRecv pair: for several sizes around 2^32 bytes, how many leading
+bytes of the message arrived and where the first wrong byte is.
+usage (GPU box):  python tools/rccl_big_send.py"""
+import os
+import sys
+
+os.environ["SCALCE_COMM_PIECE"] = str(1 << 40)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from scalce_amd import host  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    comm = host.Comm(0, 1, 0, unique_id=host.Comm.unique_id())
+    G = 1 << 30
+    for n in (3 * G, 4 * G - 4096, 4 * G, 4 * G + (1 << 20), 5 * G, 5 * G + 12345):
+        src = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 >> 7).to(torch.uint8)
+        dst = torch.zeros(n, dtype=torch.uint8, device=dev)
+        comm.all_to_all_v(src.data_ptr(), [n], dst.data_ptr(), [n])
+        torch.cuda.synchronize()
+        bad = (src != dst)
+        nbad = int(bad.sum())
+        first = int(bad.nonzero()[0]) if nbad else -1
+        last = int(bad.nonzero()[-1]) if nbad else -1
+        print(f"one ncclSend/ncclRecv of {n} bytes ({n / G:.3f} GiB): {nbad} wrong bytes, first at {first}, last at {last}"
+              + (f" = 2^32 + {first - (1 << 32)}" if first >= (1 << 32) else ""), flush=True)
+        del src, dst, bad
+        torch.cuda.empty_cache()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()
