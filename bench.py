@@ -132,34 +132,35 @@ def main():
     G = max(1, G)
     D = max(1, args.inflight) if args.inflight is not None else 3 * G + 2
     # Every shard in flight has a text of its OWN (round 4; VERDICT r3: fourteen jobs that read one tensor are not fourteen
-    # jobs a card can hold).  What is free now decides how many fit: ~20 GB of shared front-stage buffers + per shard in
-    # flight its text (10.8 GB) and ~12.2 GB of the batch's own (reordered q' 5, coder blocks 5 sized for the worst case,
-    # records 1.25, names 0.54, tables; the framed stream is no longer a second copy: scalce_batch_set_frame_on_demand).
+    # jobs a card can hold).  What is free now decides how many fit.
     own_text = not args.shared_input
+    in_place = not sharded and not os.environ.get("SCALCE_BENCH_NO_INPLACE")
     if args.inflight is None:
         free_b, _ = torch.cuda.mem_get_info()
         scale = (n * L) / 5e9
-        # (the batch's own: reordered q' 5 GB, coder blocks 3.5 GB sized from the table, records 1.25, names 0.54, tables)
-        # (a sharded rank also holds, per shard in flight, its block range of the run-wide quality stream and the exchange
-        #  buffers: 188.6 GB at five in flight with their texts, measured at world 1 over RCCL)
-        per_slot = 10.7e9 * scale + (nbytes if own_text else 0)
+        # a slot: its text (10.8 GB) + reordered q' 5 GB (the coder writes its blocks over it: scalce_batch_set_code_in_place),
+        # records 1.25, names 0.54, tables; a sharded rank's stream is a buffer handed to the batch and coded into block buffers
+        # of its own (3.2 GB, sized from the table)
+        per_slot = (7.4e9 if in_place else 10.7e9) * scale + (nbytes if own_text else 0)
         # shared: the front-stage workspace (~20 GB); a sharded rank adds the reordered stream (5 GB) and, with peers, the receive
-        # side of the q' exchange (5 GB) and of the row exchange (the rows that change owner, the re-ingested text)
-        shared = 22e9 * scale + (0 if not sharded else (6e9 + (0 if world == 1 else 5e9 + 1.3 * nbytes)) * scale)
+        # side of the q' exchange (5 GB), the rows that change owner (text in, half a chunk at most) and the second set of row
+        # arrays (scalce_batch_rewindow, 9 GB)
+        shared = 22e9 * scale + (0 if not sharded else (6e9 + (0 if world == 1 else 14e9 + 0.5 * nbytes)) * scale)
         fit = int((free_b + (nbytes if own_text else 0) - shared - 5e9) // per_slot)
         if world > 1:   # every rank takes the same shape
             tfit = torch.tensor([fit], dtype=torch.int64)
             dist.all_reduce(tfit, op=dist.ReduceOp.MIN)
             fit = int(tfit.item())
-        if fit < D:
+        want = D if not auto_group else 18   # (more slots than that buy nothing: three launches of five or six cover a launch's latency)
+        if fit != D and (fit < D or auto_group):
+            D = max(1, min(fit, want))
             if auto_group:
-                # A coder launch takes ~0.6 s whatever it holds: what counts is that every group of slots has a stream of its
-                # own.  With twelve slots, six shards per launch on two streams, four on three and three on four measure the
-                # same at 20 steps (86.5 / 86.4 / 86.6 ms per shard, tools/pipe_shapes_r4.sh): six it is -- the fewest, largest
-                # launches of the dominant kernel.  Fewer than twelve: three per launch (91 ms at 3 / 11 / 3 against 103 at 4 / 11 / 2).
-                G = 6 if fit >= 12 else (3 if fit >= 6 else max(1, fit // 2))
-            print("bench: %.0f GB of HBM free: %d shards in flight instead of %d, %d per coder launch" % (free_b / 1e9, max(fit, 2 * G if G > 1 else 1), D, G), file=sys.stderr)
-            D = fit
+                # A coder launch takes ~0.5 s whatever it holds: what counts is that every group of slots has a stream of its own
+                # and that a slot is free when the front stream wants one.  Twelve slots: six shards per launch on two streams, four
+                # on three and three on four measure the same at 20 steps (tools/pipe_shapes_r4.sh): six it is -- the fewest, largest
+                # launches of the dominant kernel.  Fifteen and more (round 5, coding in place): five per launch on three streams.
+                G = 5 if D >= 15 else (6 if D >= 12 else (3 if D >= 6 else max(1, D // 2)))
+            print("bench: %.0f GB of HBM free: %d shards in flight, %d per coder launch" % (free_b / 1e9, D, G), file=sys.stderr)
     if G > 1:
         D = max(D, 2 * G)
     # slot i reads texts[i]: different seeds, the same record shape (sizes are equal: names and lengths are)
@@ -189,6 +190,8 @@ def main():
                                workspace=ws) for _ in range(D // F)]
     for b in batches:   # the coded blocks are framed when they are delivered (scalce_batch_qual_window), not by a copy pass
         b.set_frame_on_demand(True)
+        if in_place:    # ... and written over the symbols they were coded from (the texts stay where they are: a shard whose
+            b.set_code_in_place(True)   # block outgrows its input is run again from its text)
     batch = batches[0]
     state = {}
 
@@ -246,7 +249,8 @@ def main():
             tx = texts[slot_of_pipe[id(pipe)] + slot]
             with torch.cuda.stream(pipe.front):
                 if not sharded:
-                    b.front(tx.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream)
+                    b.front(tx.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream,
+                            0 if os.environ.get("SCALCE_BENCH_NO_SIDE") else pipe.side.cuda_stream)
                 elif G == 1:
                     state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
                                                         stream=pipe.front.cuda_stream, coder_stream=pipe.coder.cuda_stream,
@@ -504,6 +508,7 @@ def main():
                        "bucket_set_size": B, "spill_chunks": stats["chunks"],
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
                        "shards_in_flight": D, "shards_per_coder_launch": G, "coder_streams": n_coder_streams, "front_threads": F,
+                       "coded_in_place": bool(in_place),
                        "inputs": ("one text tensor per shard in flight: %d distinct synthetic shards of the same shape (seeds %d + 7919 k), "
                                   "each resident in HBM before the timed region; step j reads the text of slot j mod %d" % (D, SEED0, D)) if own_text
                                  else "ONE text tensor read by every shard in flight (--shared-input)",
@@ -730,6 +735,21 @@ def cpu_baseline(text, n, L, sample):
         if rc != 0:
             raise RuntimeError("CPU leg failed")
         dt4, rc4 = run_cpu(T, "cpuT") if T > 1 else (None, 1)
+        # BASELINE.md section 2, line C1 as written: 1 M reads, -T 1 -c gz (BASELINE.json configs[0]; 17.8 MB/s in the survey's
+        # container) -- the same-node counterpart of that table
+        c1 = None
+        if use_ref and sample >= 1_000_000:
+            end1 = int(nl[4 * 1_000_000 - 1]) + 1
+            fq1 = os.path.join(d, "c1_1.fq")
+            head[:end1].tofile(fq1)
+            t0 = time.perf_counter()
+            r = subprocess.run([ref, "compress", pbin, fq1, os.path.join(d, "c1"), "-c", "gz", "-T", "1", "-t", os.path.join(d, "tmp_c1")],
+                               capture_output=True, text=True)
+            dtc = time.perf_counter() - t0
+            if r.returncode == 0:
+                c1 = {"value": round(end1 / dtc / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference",
+                      "sample": f"BASELINE.json configs[0]: first 1000000 records ({end1} bytes), ref_full compress -c gz -T 1, {dtc:.2f} s wall"}
+            os.remove(fq1)
         what = ("oracle/_ref/ref_full compress -c no (the reference's own compress(), file in, archive out)" if use_ref
                 else "orc_cli compress -c no (C restatement)")
         dec = None
@@ -748,7 +768,7 @@ def cpu_baseline(text, n, L, sample):
         cpu = {"value": round(end / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "reference" if use_ref else "port",
                "decompress": dec,
                "sample": f"first {sample} records ({end} bytes) of the same shard, {what} -T 1, {dt:.2f} s wall incl. file I/O on tmpfs",
-               "host_cpus": os.cpu_count(),
+               "host_cpus": os.cpu_count(), "configs0_gz": c1,
                "threads_default": None if rc4 != 0 else {
                    "value": round(end / dt4 / 1e6, 2), "unit": "MB/s", "cores": T, "kind": "reference" if use_ref else "port",
                    "sample": f"same sample, -T {T} (main.cpp:171 default thread count"

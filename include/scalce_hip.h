@@ -156,6 +156,15 @@ int scalce_batch_set_fused_rows(scalce_batch *b, int on);
  * run-wide block ranges): SCALCE_OUT_QSTREAM is then valid until the next batch of the workspace runs its emit stage, and the
  * batch holds 5 GB less per 50 M reads of 100 bp.  Not with -A (the stream is the output) or lean batches: SCALCE_ERR_ARG. */
 int scalce_batch_set_stream_scratch(scalce_batch *b, int on);
+/* Coding in place.  on = 1: in grouped launches (scalce_batch_entropy_begin_group) the coder writes block k's bytes over block
+ * k's own symbols -- the output of a block lags its input (arithmetic.cpp:85-169 emits fewer bits than it reads symbols' worth)
+ * -- and the batch holds no block buffers (3.2 GB less per 50 M reads of 100 bp; SCALCE_OUT_QSTREAM is gone once the shard is
+ * coded).  A block whose output would catch up with its input cannot be coded again from symbols that are already
+ * overwritten: the shard is then run again from its TEXT with buffers of its own when it is collected, so the caller keeps
+ * the text passed to scalce_batch_front / _ingest where it is until the shard has been collected.  Not with -A or lean
+ * batches (SCALCE_ERR_ARG); a stream handed in by the caller (sharded runs) is never coded in place. */
+int scalce_batch_set_code_in_place(scalce_batch *b, int on);
+uint64_t scalce_batch_reruns(const scalce_batch *b);  /* shards of this batch that had to be run again from their text */
 /* edge[0..1] = the first two, edge[2..3] = the last two q' symbols of the rows held (input order), *nsym = how many there are,
  * *read_len (may be NULL) = symbols per row: what a rank of a sharded run tells its neighbours (qualities.cpp:179-198: prev[]
  * runs across reads, so two trigrams straddle every rank boundary).  Runs on `stream` and synchronises it. */
@@ -190,6 +199,13 @@ int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint64_t *cuts_h
 /* Byte offset, in the text of the piece ingested last, at which record `row` (0 .. rows of that piece) begins; runs on
  * `stream`, behind the ingest of that piece. */
 int scalce_batch_text_offset(scalce_batch *b, int mate, uint64_t row, uint64_t *offset, void *stream);
+/* Sharded runs: the row range a rank holds changes at both ends once the run-wide spill-chunk cuts are known (rank boundaries
+ * move to the nearest cut, compress.cpp:702-715): rows [keep_first, keep_first + keep_rows) of the batch stay as they are, the
+ * records of `front` (FASTQ text on the device, whole records, 16-byte aligned; [mate]) become rows in front of them, those of
+ * `back` rows behind them.  Only the records that arrive are ingested and walked; the quality statistics are not touched (every
+ * record was counted by the rank that ingested it first).  Before any tokenization of the batch. */
+int scalce_batch_rewindow(scalce_batch *b, uint64_t keep_first, uint64_t keep_rows, const uint8_t *const front[2],
+                          const uint64_t front_bytes[2], const uint8_t *const back[2], const uint64_t back_bytes[2], void *stream);
 /* Spill-chunk boundaries given by the caller instead of the -B rule: starts[0] = 0 < starts[1] < ...;
  * records of chunk i precede those of chunk i+1 inside every bucket (merge order, compress.cpp:104-159).
  * A sharded run uses one chunk per shard. */
@@ -247,6 +263,11 @@ int scalce_copy_pieces(scalce_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, co
 /* all of the above in order */
 int scalce_batch_compress(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2,
                           uint64_t n2, void *stream);
+/* Every stage in front of the entropy coder (ingest .. emit) of a shard resident as text (mate 2: NULL / 0 for single-end).
+ * side_stream (may be NULL): the quality statistics run there beside the tie-break and the order stage; `stream` waits for
+ * them before anything the caller enqueues next. */
+int scalce_batch_front(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2, void *stream,
+                       void *side_stream);
 /* Synchronises `stream`, checks the device error word, fills the host-side result sizes. */
 int scalce_batch_finish(scalce_batch *b, void *stream);
 
@@ -416,6 +437,7 @@ void scalce_pipeline_destroy(scalce_pipeline *p);
 const char *scalce_pipeline_error(const scalce_pipeline *p);
 void *scalce_pipeline_front_stream(scalce_pipeline *p);
 void *scalce_pipeline_coder_stream(scalce_pipeline *p, int i);
+void *scalce_pipeline_side_stream(scalce_pipeline *p);  /* a second front stream (scalce_batch_front: side_stream) */
 int scalce_pipeline_acquire(scalce_pipeline *p, int *slot, int *retired);
 int scalce_pipeline_submit(scalce_pipeline *p, int slot, int no_more_shards, int *launched);
 int scalce_pipeline_retire(scalce_pipeline *p, int slot, int *had_shard);

@@ -84,8 +84,14 @@ struct AcBlockDesc {
   u32 n;                // symbols in the block
   u32 index;            // block index inside its stream (error reports)
   u32 cap;              // bytes the block may write at dst (multiple of 4)
+  u32 flags;            // AC_BLOCK_IN_PLACE: dst IS the block's symbols (scalce_batch_set_code_in_place) -- the coded bytes go over
+                        // what the coder has already consumed, and a block whose output would catch up with its input reports
+                        // E_ACOVERFLOW instead
+  u32 *log;             // ac_encode_lanes_k: the block's carry notes (AclSink), `log_cap` words; null: at the end of dst
+  u32 log_cap;
   u32 pad_;
 };
+constexpr u32 AC_BLOCK_IN_PLACE = 1u;
 struct AcEncArgs {
   const u8 *sym;
   u64 nsym;
@@ -105,6 +111,7 @@ struct AcEncArgs {
   u32 lanes_used;      // ac_encode_lanes_k: blocks per workgroup (0 = 64)
   u32 pairing;         // ac_encode_lanes_k with two sets: which roles share a SIMD (experiments)
   u32 test_poison;     // test hook: every test_poison-th super-round pretends a step hit the full-range exit (0 = off)
+  u32 inplace_shift;   // test hook (SCALCE_AC_INPLACE_TEST): blocks coded in place may only use 2^-shift of what they have consumed
 };
 // index of the SIMD a wave runs on: XCC_ID[3:0] | HW_ID{se_id, sh_id, cu_id}[15:8] | HW_ID simd_id[5:4]
 constexpr u32 AC_SIMD_KEYS = 16u << 10;
@@ -843,6 +850,8 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
     const int h = wv - 1;
     u32 *buf0 = bufs[h][0], *buf1 = bufs[h][1];
     AcSink sink[2];
+    u32 wcap_all[2];
+    bool in_place[2];
     const SCALCE_GLOBAL u8 *sp[2];        // (global, not generic: see SCALCE_GLOBAL)
     const SCALCE_GLOBAL u32x4 *tabp[2];
     u32 nb[2];
@@ -895,7 +904,12 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       sp[e] = (const SCALCE_GLOBAL u8 *)dsc.sym;
       tabp[e] = (const SCALCE_GLOBAL u32x4 *)dsc.tab;
       sink[e].dst = (SCALCE_GLOBAL u32 *)dsc.dst;
-      sink[e].wcap = dsc.cap / 4;
+      wcap_all[e] = dsc.cap / 4;
+      in_place[e] = (dsc.flags & AC_BLOCK_IN_PLACE) != 0;
+      // In place: the words of super-round r's stores must lie in front of what this wave has taken out of the block for good.
+      // The symbols of super-round r + 3 are in registers when super-round r packs (they were requested a super-round earlier
+      // and looked up at its top), those of r + 4 are in flight: 16 words per super-round, two super-rounds of margin.
+      sink[e].wcap = in_place[e] ? (wcap_all[e] < 32u ? wcap_all[e] : 32u) : wcap_all[e];
       if (nb[e]) sink[e].carry = ((u32)sp[e][0] << 24) | ((nb[e] > 1 ? (u32)sp[e][1] : 0u) << 16);
       e62[e] = e63[e] = 0;
       const uint4 o0 = lookup(e, sym_at(e, lane), 0), o1 = lookup(e, sym_at(e, 64 + lane), 64);
@@ -926,6 +940,9 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       if constexpr (!decltype(first)::value) {  // (super-round 0 has nothing to pack: peeled, so that every pass of the
                                                 //  loop issues its stores -- see ac_pack2)
         u32 rH[2], rK[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+          if (in_place[e]) { const u32 lim = (16u * (r + 2u)) >> a.inplace_shift; sink[e].wcap = lim < wcap_all[e] ? lim : wcap_all[e]; }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
           const uint2 v = outcome(rec[(r - 1) & 1][2 * h + e][lane], hist[e][0], recfmt[(r - 1) & 1][2 * h + e]);
@@ -968,6 +985,7 @@ __global__ __launch_bounds__(64 * (1 + 32 / R)) void ac_encode_rows_k(AcEncArgs 
       const uint2 v = outcome(rec[r & 1][2 * h + e][lane], hist[e][0], recfmt[r & 1][2 * h + e]);
       const bool valid = ((r << 6) + lane < nb[e]) && !(r == 0 && lane < 2);
       u32 *buf = e ? buf1 : buf0;
+      sink[e].wcap = wcap_all[e];  // (every symbol of the block has been taken: what is left may use all of it)
       sink[e].to_plain(buf, lane);
       sink[e].pack(buf, lane, a.slow_threshold, valid ? v.x : 0u, valid ? v.y : 0u);
       const u32 bytes = sink[e].finish(buf, lane, final_lo[2 * h + e]);

@@ -104,13 +104,17 @@ template <int LW>
 struct AclSink {
   SCALCE_GLOBAL u32 *dst;
   u32 wcap;      // words the block may write
+  SCALCE_GLOBAL u32 *logtop;  // the carry notes grow DOWN from here: the last word of the block's own buffer, or of a log of its own
+  u32 logcap;    // ... and how many there may be (0: they share the block's buffer with the coded words)
   u32 w2, w1, w0;
   u32 Qb;        // stream position of the next B's top bit
   u32 ncar;      // smallest w2 seen right after a step of this round added its carry: 0 = a carry may have left w2 (step())
   u32 nlog;      // notes in the log
   bool over;
-  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 cap_words, u32 s0, u32 s1) {
+  __device__ __forceinline__ void init(SCALCE_GLOBAL u32 *d, u32 cap_words, SCALCE_GLOBAL u32 *log, u32 log_words, u32 s0, u32 s1) {
     dst = d; wcap = cap_words;
+    logtop = log ? log + (log_words - 1u) : d + (cap_words - 1u);
+    logcap = log ? log_words : 0u;
     w2 = 0; w1 = (s0 << 24) | (s1 << 16); w0 = 0;  // the two raw symbols (arithmetic.cpp:110-120): 16 bits of X
     Qb = 16; ncar = ~0u; nlog = 0; over = false;    // (w2 = the empty word in front of the block: ring slot 0, never taken out)
   }
@@ -120,7 +124,8 @@ struct AclSink {
   }
   // room for a round's words and notes?  (once per round: a lane that runs out of room stops and reports)
   __device__ __forceinline__ bool room() {
-    if ((Qb >> 5) + 2 * ACL_STEPS + 2 + nlog >= wcap) over = true;
+    if ((Qb >> 5) + 2 * ACL_STEPS + 2 + (logcap ? 0u : nlog) >= wcap) over = true;
+    if (logcap && nlog + ACL_STEPS + 2 >= logcap) over = true;
     return !over;
   }
   // the step: X += B at bit Qb, then on to Qa.  Reports the word that may still take a carry as it stands now (val) and
@@ -157,7 +162,7 @@ struct AclSink {
     w2 = __builtin_addc(w2, 0u, c1, &c2);
     const u32 wq = Qb >> 5;
     if (c2 != 0u) {
-      dst[wcap - 1u - nlog] = wq - 2u;  // (wq >= 2: a carry out of w2 needs 32 ones there, the empty word in front of the block has none)
+      *(logtop - nlog) = wq - 2u;  // (wq >= 2: a carry out of w2 needs 32 ones there, the empty word in front of the block has none)
       nlog++;
     }
     if ((Qa >> 5) != wq) { w2 = w1; w1 = w0; w0 = 0u; }  // (the words are those step() reported: only the note is new)
@@ -183,7 +188,7 @@ struct AclSink {
       const bool c = __builtin_add_overflow(v, ulp, &v);
       if (c) {
         w2 += 1u;
-        if (w2 == 0u && !over) { dst[wcap - 1u - nlog] = (u32)(wi - 1); nlog++; }
+        if (w2 == 0u && !over) { *(logtop - nlog) = (u32)(wi - 1); nlog++; }
       }
     }
     const u32 bits = Qb + 2u;
@@ -199,7 +204,7 @@ struct AclSink {
     if (nlog && !over) {  // the carries noted on the way, into the words as they stand now
       __threadfence();
       for (u32 e = 0; e < nlog; e++) {
-        const int k = (int)__hip_atomic_load(&dst[wcap - 1u - e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int k = (int)__hip_atomic_load(logtop - e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         carry_back(dst, wcap, k);
       }
     }
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
       {
         const SCALCE_GLOBAL u8 *sp = (const SCALCE_GLOBAL u8 *)dp->sym;
         const u32 s0 = n ? (u32)sp[0] : 0u, s1 = n > 1 ? (u32)sp[1] : 0u;
-        sk.init((SCALCE_GLOBAL u32 *)dp->dst, dp->cap / 4, s0, s1);
+        sk.init((SCALCE_GLOBAL u32 *)dp->dst, dp->cap / 4, (SCALCE_GLOBAL u32 *)dp->log, dp->log_cap, s0, s1);
       }
       sh.pub[0][lane] = 0;
       sh.pub[1][lane] = 0;
@@ -527,14 +532,25 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
     SCALCE_GLOBAL u32 *dst = (SCALCE_GLOBAL u32 *)dp->dst;
     const u32 wcap = dp->cap / 4;
     u32 wo = 0;  // words of this lane's block in global memory (multiple of 32 until the end)
+    // In place (AC_BLOCK_IN_PLACE: dst IS the block's symbols): a line may only go where the gather wave has been for good.  In
+    // iteration i that wave is requesting round i + SLOTS - 1 out of chunks of eight rounds it loaded eight rounds earlier; what
+    // is in flight lies behind round i: lines end in front of round i - 1 (4 words per round).  A line that is ready and may
+    // not go is the end of the block -- its output has caught up with its input: E_ACOVERFLOW, nothing more is written (the
+    // host runs the shard again with buffers of its own).
+    const bool in_place = have && (dp->flags & AC_BLOCK_IN_PLACE) != 0;
+    bool dead = false;
     auto word = [&](u32 k) -> u32 { return __builtin_bswap32(sh.stage[(k + 1u) & (RING - 1)][lane]); };
     // Whole 128-byte lines, the lines of TWO blocks per visit: threads 0..31 store the 32 words of one block's line, threads
     // 32..63 those of another's -- one coalesced 128-byte store each, and a visit per pair of lines that ARE ready.  (Round 3:
     // every lane stored its own line in eight 16-byte pieces, all lanes masked but the ready ones -- 64 scattered pieces per
     // instruction, and the visit cost the same ~1900 cycles for one ready lane as for forty; with some lane ready in nearly
     // every round it was half of this wave's time.)
-    auto drain = [&](u32 lim) {
-      u64 ready = __ballot(inrow && lim >= wo + 32u);
+    auto drain = [&](u32 lim, u32 words_taken) {
+      if (in_place && !dead && lim >= wo + 32u && wo + 32u > words_taken) {
+        dead = true;
+        dev_fail(dp->err, E_ACOVERFLOW, dp->index, 4u * (wo + 32u));
+      }
+      u64 ready = __ballot(inrow && !dead && lim >= wo + 32u);
       while (ready) {
         const u32 la = (u32)__builtin_ctzll(ready);
         ready &= ready - 1;
@@ -576,7 +592,7 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
     barrier_lds_only();
     for (u32 i = 0; i < nr_wg; i++) {  // iteration i: the records of round i - 2 (the sink took it in iteration i - 1), then what it published there
       if (i > 1) apply(i - 2);
-      if (i > 0) drain(inrow ? sh.pub[(i - 1) & 1][lane] : 0u);
+      if (i > 0) drain(inrow ? sh.pub[(i - 1) & 1][lane] : 0u, i > 1 ? (4u * (i - 1u)) >> a.inplace_shift : 0u);
       barrier_lds_only();
     }
     barrier_lds_only();  // the sink's last round is in the records
@@ -584,8 +600,8 @@ __global__ __launch_bounds__(256 * SETS) void ac_encode_lanes_k(AcEncArgs a) {
       if (nr_wg > 1) apply(nr_wg - 2);
       apply(nr_wg - 1);
       const u32 lim = inrow ? sh.pub[nr_wg & 1][lane] : 0u;
-      drain(lim);
-      for (; wo < lim; wo++)
+      drain(lim, ~0u);   // (every symbol has been taken)
+      for (; wo < lim && !dead; wo++)
         if (wo < wcap) dst[wo] = word(wo);
       __threadfence();
     }

@@ -564,22 +564,60 @@ __global__ __launch_bounds__(256) void compact_q_k(u64 nrec, const u8 *frow, u32
   }
 }
 
-// piecewise copy (sharded runs: received quality bytes -> their place in the run-wide stream).  Pieces are
-// contiguous in src and sorted; thread i moves src bytes [8i, 8i+8).
+// piecewise copy (sharded runs: quality bytes -> their place in a rank's range of the run-wide stream).  Pieces are
+// contiguous in src and sorted by piece_src; dst offsets are arbitrary.  A workgroup takes 16 KB of src in 16-byte granules
+// of the ADDRESS space (src itself may start anywhere: a rank's own part begins in the middle of its local stream): one
+// binary search per workgroup finds the piece its span starts in (pieces are a few hundred KB: the threads walk on from
+// there), a granule that lies inside one piece is one aligned 16-byte load and -- by the alignment of its destination --
+// one 16-byte store, four 4-byte stores or sixteen bytes.  (Rounds 1-4: eight bytes per thread, a binary search per
+// thread and byte stores -- 10 of the 19 ms the block-range step of a 50 M-read shard took at one rank.)
+constexpr u32 CP_CHUNKS = 4;  // granules per thread
 __global__ __launch_bounds__(256) void copy_pieces_k(const u8 *src, u8 *dst, const u64 *piece_src, const u64 *piece_dst,
                                                     u32 np, u64 total) {
-  const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  if (i0 >= total) return;
-  u32 lo = 0, hi = np;  // last piece with piece_src <= i0
-  while (hi - lo > 1) {
-    const u32 mid = (lo + hi) >> 1;
-    if (piece_src[mid] <= i0) lo = mid; else hi = mid;
+  __shared__ u32 p_first;
+  const u32 a = (u32)((uintptr_t)src & 15u);     // src = sal + a, sal 16-byte aligned
+  const u8 *sal = src - a;
+  const u64 span0 = (u64)blockIdx.x * (256u * 16u * CP_CHUNKS);   // in sal coordinates: logical offset = x - a
+  if (threadIdx.x == 0) {
+    const u64 i0 = span0 > a ? span0 - a : 0;
+    u32 lo = 0, hi = np;  // last piece with piece_src <= i0
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (piece_src[mid] <= i0) lo = mid; else hi = mid;
+    }
+    p_first = lo;
   }
-  u32 p = lo;
-  const u64 i1 = i0 + 8 < total ? i0 + 8 : total;
-  for (u64 i = i0; i < i1; i++) {
-    while (p + 1 < np && piece_src[p + 1] <= i) p++;
-    dst[piece_dst[p] + (i - piece_src[p])] = src[i];
+  __syncthreads();
+  u32 p = p_first;
+#pragma unroll 1
+  for (u32 c = 0; c < CP_CHUNKS; c++) {
+    const u64 x0 = span0 + ((u64)c * 256u + threadIdx.x) * 16u;
+    if (x0 >= total + a) break;
+    const u64 b0 = x0 > a ? x0 - a : 0, b1 = (x0 + 16 - a) < total ? (x0 + 16 - a) : total;  // logical bytes of this granule
+    while (p + 1 < np && piece_src[p + 1] <= b0) p++;
+    const uint4 v = *reinterpret_cast<const uint4 *>(sal + x0);
+    const bool whole = b1 - b0 == 16 && (p + 1 == np || piece_src[p + 1] >= b1);
+    if (whole) {
+      u8 *d = dst + piece_dst[p] + (b0 - piece_src[p]);
+      const u32 al = (u32)((uintptr_t)d & 15u);
+      if (al == 0) *reinterpret_cast<uint4 *>(d) = v;
+      else if ((al & 3u) == 0) {
+        u32 *d4 = reinterpret_cast<u32 *>(d);
+        d4[0] = v.x; d4[1] = v.y; d4[2] = v.z; d4[3] = v.w;
+      } else {
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+      }
+    } else {
+      u32 q = p;
+      for (u64 i = b0; i < b1; i++) {
+        while (q + 1 < np && piece_src[q + 1] <= i) q++;
+        const u32 k = (u32)(i + a - x0);
+        const u32 word = k < 8 ? (k < 4 ? v.x : v.y) : (k < 12 ? v.z : v.w);   // (selects: an indexed array would live in scratch)
+        dst[piece_dst[q] + (i - piece_src[q])] = (u8)(word >> (8 * (k & 3)));
+      }
+    }
   }
 }
 

@@ -305,13 +305,15 @@ struct scalce_workspace {
   const void *walk_owner = nullptr;          // the batch whose first walk tok_bucket / tok_pos hold (scalce_batch_chunk_plan)
   DBuf cell_sorted;                          // name cells in output order (emit stage)
   DBuf qs_shared[2];                         // reordered q' stream of batches that only pass it on (scalce_batch_set_stream_scratch)
+  DBuf alt_packed[2], alt_q[2], alt_namelen, alt_namecell, alt_name_in_off, alt_tok_bucket, alt_tok_pos;  // second set of row arrays (scalce_batch_rewindow)
   void free_all() {
     DBuf *all[] = {&line_end[0], &line_end[1], &tile[0], &tile[1], &packed[0], &packed[1], &q[0], &q[1], &namelen, &namecell, &outlen,
                    &names_in, &name_in_off, &prior_buf, &tok_bucket, &tok_pos, &tie_index, &tie_read, &tie_off, &tie_ncand, &cand_bucket,
                    &cand_pos, &choice, &ev_off, &ev_bucket, &ev_init, &ev_sorted, &ev_tmp, &ev_place, &chosen, &G, &seg, &dirty,
                    &cand_place, &Gseg, &cand_fixed, &bucket, &endv, &tokens, &counts, &bucket_first, &bucket_off, &chunk, &chunk_start, &perm_a,
                    &perm_b, &key_a, &key_b, &hist, &scan_ws, &S, &run_head, &run_hcount, &run_rank, &runid, &run_items_a, &run_items_b,
-                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1], &cell_sorted, &qs_shared[0], &qs_shared[1]};
+                   &run_pos, &name_off, &tw_cells, &tw_cand, &tw_bits, &tw_base, &tile_mm[0], &tile_mm[1], &cell_sorted, &qs_shared[0], &qs_shared[1],
+                   &alt_packed[0], &alt_packed[1], &alt_q[0], &alt_q[1], &alt_namelen, &alt_namecell, &alt_name_in_off, &alt_tok_bucket, &alt_tok_pos};
     for (DBuf *d : all)
       if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
     row_cap = piece_rows_cap = 0;
@@ -402,7 +404,7 @@ struct scalce_batch {
   bool timing = false;
   float stage_ms[ST_COUNT] = {0};
   int stage_launches[ST_COUNT] = {0};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_group = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_group = nullptr, ev_side = nullptr;
   // HIP-event pairs around every ac_encode_k launch (the dominant kernel); read by scalce_batch_kernel_ms
   bool ktiming = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
@@ -429,6 +431,16 @@ struct scalce_batch {
   u32 qstride[2] = {0, 0}, row_cell_off = 0, row_pwords = 0;
   DBuf q_compact, fuse_q, fuse_cells;  // SCALCE_OUT_QINPUT of fused rows on request; classic arrays of a piece the indexed kernels took
   u64 ac_stride[2] = {0, 0};
+  // Coding in place (scalce_batch_set_code_in_place): the coder's output goes over the symbols it has consumed -- block k's bytes
+  // begin where block k's symbols began, ac_base = the reordered stream itself, ac_stride = 10 MiB -- and the batch holds no
+  // block buffers at all (3.2 GB per 50 M reads of 100 bp).  A block whose output would catch up with its input reports
+  // E_ACOVERFLOW; its symbols are gone by then, so the shard is run again FROM ITS TEXT with buffers of its own
+  // (entropy_rerun_from_text: the caller keeps the text of a shard in place until the shard is collected).
+  bool code_in_place = false, in_place_suspended = false;
+  u64 reruns = 0;                          // shards run again from their text (entropy_rerun_from_text)
+  bool in_place_now[2] = {false, false};   // the last launch coded this mate's stream in place
+  u8 *ac_base[2] = {nullptr, nullptr};     // block k of the last launch: ac_base + k * ac_stride
+  DBuf ac_log[2];                          // carry notes of ac_encode_lanes_k when the block's buffer has no room for them
   const u8 *ac_last_sym[2] = {nullptr, nullptr};  // what the last launch coded (for the recode)
   u64 ac_last_nsym[2] = {0, 0};
   bool frame_on_demand = false;
@@ -492,7 +504,8 @@ static void free_all(scalce_batch *b) {
   DBuf *all[] = {&b->freq4[0], &b->freq4[1], &b->table[0], &b->table[1], &b->qs_own[0], &b->qs_own[1], &b->counts_total, &b->bucket_name_bytes,
                  &b->ac_scan, &b->out_reads[0], &b->out_reads[1], &b->out_names, &b->ac_tab[0], &b->ac_cum[0], &b->ac_blocks[0],
                  &b->ac_sizes[0], &b->ac_off[0], &b->ac_tab[1], &b->ac_cum[1], &b->ac_blocks[1], &b->ac_sizes[1], &b->ac_off[1],
-                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1], &b->ac_tab8[0], &b->ac_tab8[1], &b->q_compact, &b->fuse_q, &b->fuse_cells};
+                 &b->ac_desc, &b->out_qual[0], &b->out_qual[1], &b->ac_tab8[0], &b->ac_tab8[1], &b->q_compact, &b->fuse_q, &b->fuse_cells,
+                 &b->ac_log[0], &b->ac_log[1]};
   for (DBuf *d : all)
     if (d->p) { hipFree(d->p); d->p = nullptr; d->cap = 0; }
   if (b->owns_ws) { b->ws->free_all(); delete b->ws; }
@@ -503,10 +516,14 @@ static void free_all(scalce_batch *b) {
   if (b->ac_desc_host) hipHostFree(b->ac_desc_host);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev_side) hipEventDestroy(b->ev_side);
+  if (b->ev_group) hipEventDestroy(b->ev_group);
   for (auto &pr : b->kev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static inline int sz_read(int l) { return (l + 3) / 4; }
+// room behind the reordered stream: the last block of a stream coded in place may write this much more than it holds symbols
+constexpr size_t AC_INPLACE_PAD = 65536;
 
 // run-wide arrays indexed by row: room for `rows` of them, the first `used` rows kept
 static int reserve_rows(scalce_batch *b, u64 rows, u64 used, hipStream_t s) {
@@ -946,6 +963,42 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
 // consumed[m] says how many bytes of each piece that was, the caller hands the rest in again in front of the next
 // piece.  Ingest, quality counters and the tie-break of the new rows (against all rows before them) run here; order,
 // emit and entropy run once, over everything, when the caller has no more input.
+static int first_walk(scalce_batch *b, u64 row0, u64 n, u64 tok_row0, hipStream_t s);
+static int entropy_rerun_from_text(scalce_batch *b, hipStream_t s);
+// the ingest half of scalce_batch_append: as many complete records as both mates' pieces hold -> rows [N, N + nrec)
+static int ingest_piece(scalce_batch *b, const uint8_t *const text[2], const u64 nbytes[2], bool final_piece, uint64_t consumed[2], hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  consumed[0] = consumed[1] = 0;
+  u64 nlines[2] = {0, 0}, nrec = ~0ull;
+  u8 last[2] = {'\n', '\n'};
+  StageTimer tm(b, ST_INGEST, s);
+  for (int m = 0; m < b->nm; m++)
+    if (nbytes[m]) { int rc = piece_count(b, m, text[m], nbytes[m], s, &nlines[m], &last[m]); if (rc) return rc; }
+  HIP_TRY(c, hipStreamSynchronize(s));
+  for (int m = 0; m < b->nm; m++) nrec = nlines[m] / 4 < nrec ? nlines[m] / 4 : nrec;
+  if (final_piece) {
+    for (int m = 0; m < b->nm; m++)
+      if ((nlines[m] & 3) || last[m] != '\n') {
+        set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)(4 * b->N + nlines[m]));
+        return SCALCE_ERR_FORMAT;
+      }
+    if (b->nm == 2 && nlines[0] != nlines[1]) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
+  }
+  b->base = b->N;
+  b->NP = nrec;
+  if (b->base + nrec >= (1ull << 32) - 64) { set_err(c, "a batch holds fewer than 2^32 reads"); return SCALCE_ERR_CAPACITY; }
+  { int rc = reserve_rows(b, b->base + nrec, b->base, s); if (rc) return rc; }
+  for (int m = 0; m < b->nm; m++) {
+    int rc = piece_unpack(b, m, text[m], nbytes[m], nrec, s);
+    if (rc) return rc;
+    b->ingested[m] = true;
+    consumed[m] = nrec ? b->piece_consumed[m] : 0;  // behind the newline that ends the last record taken
+  }
+  HIP_TRY(c, hipStreamSynchronize(s));
+  b->N = b->base + nrec;
+  return SCALCE_OK;
+}
+
 extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2,
                                    int flags, uint64_t consumed[2], void *stream) {
   const int final_piece = flags & SCALCE_APPEND_FINAL;
@@ -957,39 +1010,97 @@ extern "C" int scalce_batch_append(scalce_batch *b, const uint8_t *d_text1, uint
   if (!b->appending) { batch_restart(b); b->appending = true; }
   const uint8_t *text[2] = {d_text1, d_text2};
   const u64 nbytes[2] = {n1, b->nm == 2 ? n2 : 0};
-  consumed[0] = consumed[1] = 0;
-  u64 nlines[2] = {0, 0}, nrec = ~0ull;
-  u8 last[2] = {'\n', '\n'};
-  {
-    StageTimer tm(b, ST_INGEST, s);
-    for (int m = 0; m < b->nm; m++)
-      if (nbytes[m]) { int rc = piece_count(b, m, text[m], nbytes[m], s, &nlines[m], &last[m]); if (rc) return rc; }
-    HIP_TRY(c, hipStreamSynchronize(s));
-    for (int m = 0; m < b->nm; m++) nrec = nlines[m] / 4 < nrec ? nlines[m] / 4 : nrec;
-    if (final_piece) {
-      for (int m = 0; m < b->nm; m++)
-        if ((nlines[m] & 3) || last[m] != '\n') {
-          set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)(4 * b->N + nlines[m]));
-          return SCALCE_ERR_FORMAT;
-        }
-      if (b->nm == 2 && nlines[0] != nlines[1]) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
-    }
-    b->base = b->N;
-    b->NP = nrec;
-    if (b->base + nrec >= (1ull << 32) - 64) { set_err(c, "a batch holds fewer than 2^32 reads"); return SCALCE_ERR_CAPACITY; }
-    { int rc = reserve_rows(b, b->base + nrec, b->base, s); if (rc) return rc; }
-    for (int m = 0; m < b->nm; m++) {
-      int rc = piece_unpack(b, m, text[m], nbytes[m], nrec, s);
-      if (rc) return rc;
-      b->ingested[m] = true;
-      consumed[m] = nrec ? b->piece_consumed[m] : 0;  // behind the newline that ends the last record taken
-    }
-    HIP_TRY(c, hipStreamSynchronize(s));
-  }
-  b->N = b->base + nrec;
-  int rc;
+  int rc = ingest_piece(b, text, nbytes, final_piece != 0, consumed, s);
+  if (rc) return rc;
   if (!(flags & SCALCE_APPEND_NO_QUALITY) && (rc = scalce_batch_quality(b, stream))) return rc;
   if (!(flags & SCALCE_APPEND_NO_TOKENIZE) && (rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
+  return SCALCE_OK;
+}
+
+// Sharded runs: the rows this rank holds change at both ends (rank boundaries move to spill-chunk boundaries, sharded.cpp) --
+// rows [keep_first, keep_first + keep_rows) stay, the records of `front` go in front of them, those of `back` behind (FASTQ text,
+// whole records, either may be empty).  Rounds 1-4 rebuilt the whole range from text: a second ingest and a second first walk of
+// every row (+21 ms per 50 M-read shard).  Here the rows that stay stay: the run-wide row arrays and the first walk's tokens are
+// swapped against a second set in the workspace, the new set takes [front | kept | back] -- only the moved records are ingested
+// and walked, the kept rows are one device copy (rows, name cells, tokens: ~185 bytes per read); nothing at all is copied when
+// only the back end moves.  Quality statistics are NOT touched: every record was counted by the rank that ingested it first.
+extern "C" int scalce_batch_rewindow(scalce_batch *b, uint64_t keep_first, uint64_t keep_rows, const uint8_t *const front[2],
+                                     const uint64_t front_bytes[2], const uint8_t *const back[2], const uint64_t back_bytes[2], void *stream) {
+  if (!b || !front || !back || !front_bytes || !back_bytes || keep_first + keep_rows > b->N) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (b->tok_open || b->tok_done) { set_err(c, "rewindow: the rows have been tokenized already"); return SCALCE_ERR_ARG; }
+  scalce_workspace *w = b->ws;
+  const bool walked = b->walk_rows == b->N && w->walk_owner == b && b->N > 0;  // (scalce_batch_chunk_plan has been here)
+  const bool have_front = front_bytes[0] != 0;
+  uint64_t used[2];
+  const u64 fb[2] = {front_bytes[0], b->nm == 2 ? front_bytes[1] : 0}, bb[2] = {back_bytes[0], b->nm == 2 ? back_bytes[1] : 0};
+  u64 nfront = 0;
+  b->S_rows = ~0ull;
+  b->appending = true;
+  // rows the new range may hold (a record is at least "@x", L bases, "+", L qualities and four newlines): the tokens of the
+  // first walk are sized for it BEFORE the kept ones move -- growing the array later would lose them
+  const u64 rows_bound = keep_rows + fb[0] / (2 * (u64)b->L[0] + 7) + bb[0] / (2 * (u64)b->L[0] + 7) + 8;
+  if (!have_front && keep_first == 0) {
+    b->N = keep_rows;  // only the back end moves: rows beyond keep_rows are dropped where they lie
+    if (walked) {
+      int rc = ensure_keep(b, b->tok_bucket, sizeof(u32) * (rows_bound + 1), sizeof(u32) * keep_rows, s);
+      if (!rc) rc = ensure_keep(b, b->tok_pos, sizeof(u32) * (rows_bound + 1), sizeof(u32) * keep_rows, s);
+      if (rc) return rc;
+    }
+  } else {
+    // the row arrays change places with the workspace's second set; the new set is filled [front | kept | back]
+    DBuf *cur[] = {&b->packed[0], &b->packed[1], &b->q[0], &b->q[1], &b->namelen, &b->namecell, &b->name_in_off, &b->tok_bucket, &b->tok_pos};
+    DBuf *alt[] = {&w->alt_packed[0], &w->alt_packed[1], &w->alt_q[0], &w->alt_q[1], &w->alt_namelen, &w->alt_namecell, &w->alt_name_in_off,
+                   &w->alt_tok_bucket, &w->alt_tok_pos};
+    const size_t elem[] = {(size_t)b->stride[0], (size_t)b->stride[1], (size_t)b->qstride[0], (size_t)b->qstride[1], 1, 16, 8, 4, 4};
+    for (size_t i = 0; i < sizeof(cur) / sizeof(cur[0]); i++) {
+      if (!cur[i]->p) continue;             // (an array this batch does not use: mate 2, names, long names)
+      const bool tok = cur[i] == &b->tok_bucket || cur[i] == &b->tok_pos;
+      ENSURE(b, *alt[i], std::max<size_t>(cur[i]->cap, tok ? sizeof(u32) * (rows_bound + 1) : 0));  // same capacity: reserve_rows sees one row_cap for both sets
+      std::swap(*cur[i], *alt[i]);
+    }
+    // (the long-name STORE stays: name_in_off holds absolute positions in it, and the names of the rows that leave are only lost space)
+    const u64 names_used = b->names_in_used;
+    b->N = b->base = b->NP = 0;
+    if (have_front) {
+      int rc = ingest_piece(b, front, fb, true, used, s);
+      if (rc) return rc;
+      if (used[0] != fb[0] || (b->nm == 2 && used[1] != fb[1])) { set_err(c, "rewindow: the front text is not whole records"); return SCALCE_ERR_FORMAT; }
+    }
+    nfront = b->N;
+    { int rc = reserve_rows(b, nfront + keep_rows, nfront, s); if (rc) return rc; }
+    if (keep_rows) {
+      for (size_t i = 0; i < sizeof(cur) / sizeof(cur[0]); i++) {
+        if (!cur[i]->p || !alt[i]->p) continue;
+        const bool tok = cur[i] == &b->tok_bucket || cur[i] == &b->tok_pos;
+        if (tok && !walked) continue;
+        if (cur[i] == &b->name_in_off && !names_used) continue;
+        HIP_TRY(c, hipMemcpyAsync(cur[i]->as<u8>() + nfront * elem[i], alt[i]->as<u8>() + keep_first * elem[i], keep_rows * elem[i],
+                                  hipMemcpyDeviceToDevice, s));
+      }
+    }
+    b->N = nfront + keep_rows;
+    b->base = b->N; b->NP = 0;
+    b->ingested[0] = true; b->ingested[1] = b->nm == 2;
+  }
+  const u64 nkept_end = b->N;
+  if (bb[0]) {
+    int rc = ingest_piece(b, back, bb, true, used, s);
+    if (rc) return rc;
+    if (used[0] != bb[0] || (b->nm == 2 && used[1] != bb[1])) { set_err(c, "rewindow: the back text is not whole records"); return SCALCE_ERR_FORMAT; }
+  }
+  // the first walk of the rows that came in (the kept rows keep theirs)
+  if (walked && b->tok_bucket.cap >= sizeof(u32) * (b->N + 1) && b->tok_pos.cap >= sizeof(u32) * (b->N + 1)) {
+    int rc = first_walk(b, 0, nfront, 0, s);
+    if (!rc) rc = first_walk(b, nkept_end, b->N - nkept_end, 0, s);
+    if (rc) return rc;
+    b->walk_rows = b->N;
+    w->walk_owner = b;
+  } else {
+    b->walk_rows = 0;  // (scalce_batch_tokenize_begin walks every row)
+  }
   return SCALCE_OK;
 }
 
@@ -1004,6 +1115,13 @@ extern "C" void scalce_batch_set_lean(scalce_batch *b, int lean) {
   if (!b) return;
   b->lean = lean != 0;
   if (b->lean) unfuse(b);
+}
+extern "C" uint64_t scalce_batch_reruns(const scalce_batch *b) { return b ? b->reruns : 0; }
+extern "C" int scalce_batch_set_code_in_place(scalce_batch *b, int on) {
+  if (!b) return SCALCE_ERR_ARG;
+  if (on && (b->p.no_ac || b->lean)) return SCALCE_ERR_ARG;
+  b->code_in_place = on != 0;
+  return SCALCE_OK;
 }
 extern "C" int scalce_batch_set_stream_scratch(scalce_batch *b, int on) {
   if (!b) return SCALCE_ERR_ARG;
@@ -1080,6 +1198,33 @@ static void anchor_args(const scalce_ctx *c, const scalce_batch *b, const u8 *pa
   a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
 }
 
+// pass A of the tokenizer over rows [row0, row0 + n): longest core, its last base, hits at that length, tie flag -> tok_bucket /
+// tok_pos at index (row - tok_row0), tok_row0 = the row index 0 of those arrays stands for
+static int first_walk(scalce_batch *b, u64 row0, u64 n, u64 tok_row0, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  if (!n) return SCALCE_OK;
+  const u8 *packed0 = b->packed[0].as<u8>() + row0 * (u64)b->stride[0];
+  TokArgs a;
+  a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
+  a.packed = packed0; a.nrec = n; a.L = b->L[0]; a.stride = b->stride[0];
+  a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>() + (row0 - tok_row0); a.tok_pos = b->tok_pos.as<u32>() + (row0 - tok_row0);
+  const size_t sh = (size_t)a.lds_states * 20;
+  a.kmer = c->d_kmer; a.id8_first = c->id8_first;
+  if (c->anchor_K) {
+    AnchorArgs g;
+    anchor_args(c, b, packed0, n, g);
+    g.tok_bucket = a.tok_bucket; g.tok_pos = a.tok_pos;
+    LAUNCH(tokenize_anchor_k<false>, cdiv(n, 256), 256, 0, s, g);
+  } else if (c->d_kmer && tok_pipelined()) {
+    if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(n, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+    else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(n, TOKP_THREADS), TOKP_THREADS, 0, s, a);
+  }
+  else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(n, TOK_THREADS), TOK_THREADS, 0, s, a);
+  else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(n, TOK_THREADS), TOK_THREADS, sh, s, a);
+  else LAUNCH(tokenize_k<false>, cdiv(n, TOK_THREADS), TOK_THREADS, 0, s, a);
+  return SCALCE_OK;
+}
+
 // ---- stage 2: tokenize ------------------------------------------------------------------------------
 extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
   if (!b || !b->ingested[0]) return SCALCE_ERR_ARG;
@@ -1117,25 +1262,10 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
     b->ntie = b->nev = 0;
     return SCALCE_OK;
   }
-  // pass A: every read (unless scalce_batch_chunk_plan has walked exactly these rows already: sharded runs)
+  // pass A: every read (unless scalce_batch_chunk_plan / scalce_batch_rewindow have walked exactly these rows already: sharded runs)
   if (!(b->tok_base == 0 && b->walk_rows == N && b->ws->walk_owner == b)) {
-    TokArgs a;
-    a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
-    a.packed = packed0; a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
-    a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
-    const size_t sh = (size_t)a.lds_states * 20;
-    a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    if (c->anchor_K) {
-      AnchorArgs g;
-      anchor_args(c, b, packed0, N, g);
-      LAUNCH(tokenize_anchor_k<false>, cdiv(N, 256), 256, 0, s, g);
-    } else if (c->d_kmer && tok_pipelined()) {
-      if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
-      else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
-    }
-    else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
-    else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
-    else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+    int rc = first_walk(b, b->tok_base, N, b->tok_base, s);
+    if (rc) return rc;
   }
   b->walk_rows = 0;  // (the scans below rewrite tok_pos)
   b->ws->walk_owner = nullptr;
@@ -1562,24 +1692,9 @@ extern "C" int scalce_batch_chunk_plan(scalce_batch *b, uint64_t carry_in, uint6
   if (!N) return SCALCE_OK;
   ENSURE(b, b->tok_bucket, sizeof(u32) * (N + 1));
   ENSURE(b, b->tok_pos, sizeof(u32) * (N + 1));
-  if (b->S_rows != N) {  // (a second call with another carry_in only redoes the cuts)
-    TokArgs a;
-    a.next = c->d_next; a.outinfo = c->d_outinfo; a.n_states = (u32)c->A.n_states; a.lds_states = (u32)c->tok_lds_states;
-    a.packed = b->packed[0].as<u8>(); a.nrec = N; a.L = b->L[0]; a.stride = b->stride[0];
-    a.root_bucket = (u32)c->A.n_buckets; a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
-    a.kmer = c->d_kmer; a.id8_first = c->id8_first;
-    const size_t sh = (size_t)a.lds_states * 20;
-    if (c->anchor_K) {
-      AnchorArgs g;
-      anchor_args(c, b, a.packed, N, g);
-      LAUNCH(tokenize_anchor_k<false>, cdiv(N, 256), 256, 0, s, g);
-    } else if (c->d_kmer && tok_pipelined()) {
-      if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
-      else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(N, TOKP_THREADS), TOKP_THREADS, 0, s, a);
-    }
-    else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
-    else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(N, TOK_THREADS), TOK_THREADS, sh, s, a);
-    else LAUNCH(tokenize_k<false>, cdiv(N, TOK_THREADS), TOK_THREADS, 0, s, a);
+  if (b->S_rows != N && !(b->tok_done == 0 && b->walk_rows == N && b->ws->walk_owner == b)) {  // (a second call with another carry_in only redoes the cuts)
+    int rc = first_walk(b, 0, N, 0, s);
+    if (rc) return rc;
     b->walk_rows = b->tok_done == 0 ? N : 0;  // (tok_bucket / tok_pos are indexed from the first row not tokenized yet)
     b->ws->walk_owner = b;
   }
@@ -1836,7 +1951,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
       // lie in ONE row of the ingest stage's making (128 bytes = one aligned line at 100 bp), fetched whole into LDS with every
       // thread's loads in flight at once.  One random line per record instead of three (packed row + q' row for
       // gather_rows_k, each paying its own).
-      ENSURE(b, b->qs(0), (size_t)b->L[0] * N + 64);
+      ENSURE(b, b->qs(0), (size_t)b->L[0] * N + 64 + AC_INPLACE_PAD);
       a.frow = b->q[0].as<u8>(); a.stride = (int)b->qstride[0]; a.cell_off = b->row_cell_off; a.pwords = (int)b->row_pwords;
       a.packed = a.frow + b->row_cell_off;
       a.qunits = ((u32)b->L[0] + 15) / 16;
@@ -1863,7 +1978,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     for (int m = 0; m < b->nm; m++) {
       const u32 w = (u32)b->L[m];
       if (m == 0 && b->fused) continue;  // (emit_reads_k<true> has done it)
-      ENSURE(b, b->qs(m), (size_t)w * N + 64);
+      ENSURE(b, b->qs(m), (size_t)w * N + 64 + AC_INPLACE_PAD);
       LAUNCH(gather_rows_k, gather_grid(N, w), 256, 0, s, N, b->perm, b->q[m].as<u8>(), (u64)b->qstride[m], w, b->qs(m).as<u8>());
       if (b->lean) {
         // q' in input order is dead once its reordered copy exists.  Mate 1's buffer becomes mate 2's reordered stream (an
@@ -1916,9 +2031,10 @@ struct AcJob {
   u32 max_total = 0;
 };
 static const u64 AC_STRIDE = (u64)AC_BLOCK_SYMS + 4096;  // the reference's own output buffer is 10 MiB (arithmetic.cpp:301)
+constexpr u32 AC_LOG_WORDS = 1024;        // carry notes per block coded in place (a note needs 32 ones in a row in the stream)
 
 // table -> reciprocal fractions, buffers; one short wait for the largest context total
-static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool full_stride = false) {
+static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool full_stride = false, bool allow_in_place = false) {
   scalce_batch *b = j.b;
   scalce_ctx *c = b->ctx;
   const int m = j.m;
@@ -1950,7 +2066,17 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool f
     }
     b->ac_stride[m] = stride;
   }
-  ENSURE(b, b->ac_blocks[m], (size_t)j.nblk * b->ac_stride[m] + 4096 + 64);  // (the frame kernels read a few words past a block's bytes)
+  // in place: only the batch's own reordered stream, whole (the kernels of a grouped launch all know how; ac_encode_k does not)
+  b->in_place_now[m] = allow_in_place && b->code_in_place && !b->in_place_suspended && !b->qs_in_ws && j.nblk &&
+                       j.sym == b->qs(m).as<u8>() && b->qs(m).cap >= j.nsym + 64 + AC_INPLACE_PAD;
+  if (b->in_place_now[m]) {
+    b->ac_stride[m] = AC_BLOCK_SYMS;
+    b->ac_base[m] = b->qs(m).as<u8>();
+    ENSURE(b, b->ac_log[m], sizeof(u32) * AC_LOG_WORDS * (size_t)j.nblk + 64);
+  } else {
+    ENSURE(b, b->ac_blocks[m], (size_t)j.nblk * b->ac_stride[m] + 4096 + 64);  // (the frame kernels read a few words past a block's bytes)
+    b->ac_base[m] = b->ac_blocks[m].as<u8>();
+  }
   ENSURE(b, b->ac_sizes[m], sizeof(u32) * (j.nblk + 2));
   ENSURE(b, b->ac_off[m], sizeof(u64) * (j.nblk + 2));
   // the framed stream is sized for the worst case (every block at its cap): no size has to come back from the
@@ -2006,6 +2132,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
   a.chain_prio = getenv("SCALCE_AC_CHAIN_PRIO") ? (u32)atoi(getenv("SCALCE_AC_CHAIN_PRIO")) : 3u;
   a.helper_prio = getenv("SCALCE_AC_HELPER_PRIO") ? (u32)atoi(getenv("SCALCE_AC_HELPER_PRIO")) : 0u;
   a.test_poison = getenv("SCALCE_AC_TEST_POISON") ? (u32)atoi(getenv("SCALCE_AC_TEST_POISON")) : 0u;  // test hook
+  a.inplace_shift = getenv("SCALCE_AC_INPLACE_TEST") ? 2u : 0u;  // test hook: a block coded in place catches up with its input
   a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
   auto join = [&]() -> int {  // `s` continues behind everything enqueued on `ps` so far
@@ -2031,7 +2158,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     if (njobs != 1) { set_err(c, "internal: ac_encode_k takes one job"); return SCALCE_ERR_ARG; }
     scalce_batch *b = jobs[0].b;
     const int m = jobs[0].m;
-    a.sym = jobs[0].sym; a.nsym = jobs[0].nsym; a.tab = b->ac_tab[m].as<uint4>(); a.out = b->ac_blocks[m].as<u8>();
+    a.sym = jobs[0].sym; a.nsym = jobs[0].nsym; a.tab = b->ac_tab[m].as<uint4>(); a.out = b->ac_base[m];
     a.out_stride = b->ac_stride[m]; a.out_cap = (u32)b->ac_stride[m]; a.out_size = b->ac_sizes[m].as<u32>(); a.err = b->d_err;
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 3 * total)); }
     { int rc = join(); if (rc) return rc; }
@@ -2073,9 +2200,16 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
         const u64 off = (u64)k * AC_BLOCK_SYMS;
         x.sym = jobs[i].sym + off;
         x.tab = lanes ? reinterpret_cast<const uint4 *>(b->ac_tab8[m].as<u64>()) : b->ac_tab[m].as<uint4>();
-        x.dst = reinterpret_cast<u32 *>(b->ac_blocks[m].as<u8>() + (u64)k * b->ac_stride[m]);
+        x.dst = reinterpret_cast<u32 *>(b->ac_base[m] + (u64)k * b->ac_stride[m]);
         x.cap = (u32)b->ac_stride[m];
-        x.pad_ = 0;
+        x.flags = 0; x.log = nullptr; x.log_cap = 0; x.pad_ = 0;
+        if (b->in_place_now[m]) {   // the block's own symbols are its buffer; the last block of a stream may run into the padding
+          const u64 left = jobs[i].nsym - (u64)k * AC_BLOCK_SYMS;
+          if (left < AC_BLOCK_SYMS) x.cap = (u32)std::min<u64>(AC_BLOCK_SYMS, (left + AC_INPLACE_PAD) & ~3ull);
+          x.flags = AC_BLOCK_IN_PLACE;
+          x.log = b->ac_log[m].as<u32>() + (size_t)k * AC_LOG_WORDS;
+          x.log_cap = AC_LOG_WORDS;
+        }
         x.out_size = b->ac_sizes[m].as<u32>() + k;
         x.err = b->d_err;
         x.n = (u32)std::min<u64>(AC_BLOCK_SYMS, jobs[i].nsym - off);
@@ -2153,7 +2287,7 @@ static int ac_frame(AcJob &j, hipStream_t s) {
     { int rc = read_u64(b, b->d_small64 + 8 + m, &total, 1, s); if (rc) return rc; }
     if (b->out_qual[m].cap < total + 64) ENSURE(b, b->out_qual[m], (size_t)(total + total / 16) + (32u << 20));
   }
-  LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), j.nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), b->ac_stride[m],
+  LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), j.nblk), 256, 0, s, b->ac_base[m], b->ac_stride[m],
          b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
   b->ent_pending[m] = j.nblk;
   return SCALCE_OK;
@@ -2196,13 +2330,38 @@ static int entropy_recode_full(scalce_batch *b, hipStream_t s) {
   return SCALCE_OK;
 }
 
+// A block coded in place caught up with its own input (kernels_acl.hpp, writer wave; kernels_ac.hpp, helper waves): the symbols
+// it had consumed are under its output, nothing can be coded again from them.  The shard is run again from its TEXT -- which a
+// caller that turns coding in place on keeps where it was until the shard is collected -- with block buffers of its own.
+// Never seen on quality strings (their code is shorter than their symbols by a third and more from the first round on);
+// SCALCE_AC_INPLACE_TEST=1 makes the kernels' bound so tight that it happens (tests).
+static int entropy_rerun_from_text(scalce_batch *b, hipStream_t s) {
+  scalce_ctx *c = b->ctx;
+  if (b->appending || b->base != 0 || !b->piece_text[0] || (b->nm == 2 && !b->piece_text[1])) {
+    set_err(c, "a block coded in place outgrew its input and the shard's text is not at hand to run it again (scalce_batch_set_code_in_place)");
+    return SCALCE_ERR_CAPACITY;
+  }
+  static const bool dbg = getenv("SCALCE_DEBUG_ALLOC") != nullptr;
+  if (dbg) fprintf(stderr, "scalce: batch %p: a block coded in place caught up with its input: the shard is run again from its text\n", (void *)b);
+  const u8 *t1 = b->piece_text[0], *t2 = b->nm == 2 ? b->piece_text[1] : nullptr;
+  const u64 n1 = b->text_bytes[0], n2 = b->nm == 2 ? b->text_bytes[1] : 0;
+  for (int m = 0; m < 2; m++) { b->frame_deferred[m] = 0; b->ent_pending[m] = 0; b->in_place_now[m] = false; }
+  b->in_place_suspended = true;
+  b->reruns++;
+  int rc = scalce_batch_front(b, t1, n1, t2, n2, s, nullptr);
+  if (!rc) rc = scalce_batch_entropy(b, nullptr, s);
+  b->in_place_suspended = false;
+  return rc;
+}
+
 // second half of the entropy stage: wait for the coder and read the size of the framed stream(s)
 static int entropy_collect(scalce_batch *b, hipStream_t s) {
   {
-    bool open = false, tight = false;
+    bool open = false, tight = false, in_place = false;
     for (int m = 0; m < b->nm; m++) {
       open |= b->frame_deferred[m] != 0 || b->ent_pending[m] != 0;
       tight |= b->ac_stride[m] != 0 && b->ac_stride[m] < AC_STRIDE;
+      in_place |= b->in_place_now[m];
     }
     if (open && tight) {
       DevErr e;
@@ -2213,6 +2372,7 @@ static int entropy_collect(scalce_batch *b, hipStream_t s) {
           fprintf(stderr, "scalce: batch %p: block %llu outgrew its %llu-byte buffer (it needed %u): coding the shard again at the full stride\n",
                   (void *)b, (unsigned long long)e.where, (unsigned long long)b->ac_stride[0], e.aux);
         HIP_TRY(b->ctx, hipMemsetAsync(b->d_err, 0, sizeof(DevErr), s));
+        if (in_place) return entropy_rerun_from_text(b, s);   // (collects by itself)
         int rc = entropy_recode_full(b, s);
         if (rc) return rc;
       }
@@ -2320,7 +2480,7 @@ static int entropy_windowed(scalce_batch *b, const uint32_t *d_table_override, h
         ENSURE(b, b->out_qual[m], est);
       }
       if ((rc = ensure_keep(b, b->out_qual[m], used[m] + total + 64, used[m], s))) return rc;
-      LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), jobs[i].nblk), 256, 0, s, b->ac_blocks[m].as<u8>(), b->ac_stride[m],
+      LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), jobs[i].nblk), 256, 0, s, b->ac_base[m], b->ac_stride[m],
              b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>() + used[m]);
       used[m] += total;
       b->k_out_bytes += total - 4ull * jobs[i].nblk;
@@ -2403,7 +2563,7 @@ extern "C" int scalce_batch_entropy_begin_group_last(scalce_batch **bs, int n, v
       AcJob j{b, m, b->ent_external[m] ? b->ent_sym[m] : b->qs(m).as<u8>(), b->ent_external[m] ? b->ent_nsym[m] : own, 0, false};
       if (!b->ent_external[m]) { int rc = ac_table_for(b, m, nullptr, own, ps); if (rc) return rc; }
       b->ent_external[m] = false;
-      int rc = ac_prepare(j, ps, /*framed_output=*/!frames_at_collect());
+      int rc = ac_prepare(j, ps, /*framed_output=*/!frames_at_collect(), /*full_stride=*/false, /*allow_in_place=*/true);
       if (rc) return rc;
       jobs.push_back(j);
     }
@@ -2500,7 +2660,7 @@ extern "C" int scalce_copy_pieces(scalce_ctx *c, const uint8_t *d_src, uint8_t *
   if (!c) return SCALCE_ERR_ARG;
   if (!npieces || !total_bytes) return SCALCE_OK;
   HIP_TRY(c, hipSetDevice(c->device));
-  LAUNCH(copy_pieces_k, cdiv(cdiv(total_bytes, 8), 256), 256, 0, (hipStream_t)stream, d_src, d_dst,
+  LAUNCH(copy_pieces_k, cdiv(total_bytes + 15, 256 * 16 * CP_CHUNKS), 256, 0, (hipStream_t)stream, d_src, d_dst,
          reinterpret_cast<const u64 *>(d_piece_src), reinterpret_cast<const u64 *>(d_piece_dst), npieces, (u64)total_bytes);
   return SCALCE_OK;
 }
@@ -2515,6 +2675,36 @@ extern "C" int scalce_batch_compress(scalce_batch *b, const uint8_t *t1, uint64_
   if ((rc = scalce_batch_order(b, stream))) return rc;
   if ((rc = scalce_batch_emit(b, stream))) return rc;
   if ((rc = scalce_batch_entropy(b, nullptr, stream))) return rc;
+  return SCALCE_OK;
+}
+
+// Every stage in front of the entropy coder (ingest .. emit) of a shard that is resident as text, on `stream`.  side_stream
+// (may be NULL): the quality statistics (qualities.cpp:185-198: one pass of LDS atomics over the q' rows, 4 ms per 50 M reads)
+// run there, beside the tie-break's windows -- a few hundred launches of ~13 us each that leave most of the chip idle -- and the
+// order stage; `stream` waits for them before it returns to the caller's next call (the coder's table is built from them).
+extern "C" int scalce_batch_front(scalce_batch *b, const uint8_t *t1, uint64_t n1, const uint8_t *t2, uint64_t n2, void *stream,
+                                  void *side_stream) {
+  if (!b) return SCALCE_ERR_ARG;
+  scalce_ctx *c = b->ctx;
+  hipStream_t s = (hipStream_t)stream, q = (hipStream_t)side_stream;
+  int rc;
+  if ((rc = scalce_batch_ingest(b, 0, t1, n1, stream))) return rc;
+  if (b->nm == 2 && (rc = scalce_batch_ingest(b, 1, t2, n2, stream))) return rc;
+  if (!q || q == s || b->timing) {
+    if ((rc = scalce_batch_quality(b, stream))) return rc;
+    if ((rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
+  } else {
+    if ((rc = scalce_batch_tokenize_begin(b, stream))) return rc;   // both walks, the events: the chip is busy
+    if (!b->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&b->ev_side, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(b->ev_side, s));
+    HIP_TRY(c, hipStreamWaitEvent(q, b->ev_side, 0));
+    if ((rc = scalce_batch_quality(b, side_stream))) return rc;
+    HIP_TRY(c, hipEventRecord(b->ev_side, q));
+    if ((rc = scalce_batch_tokenize_settle(b, nullptr, stream))) return rc;
+  }
+  if ((rc = scalce_batch_order(b, stream))) return rc;
+  if ((rc = scalce_batch_emit(b, stream))) return rc;
+  if (q && q != s && !b->timing) HIP_TRY(c, hipStreamWaitEvent(s, b->ev_side, 0));
   return SCALCE_OK;
 }
 
@@ -2598,7 +2788,7 @@ extern "C" int scalce_batch_qual_window(scalce_batch *b, int mate, uint64_t offs
   if (off.size() != (size_t)nblk) { set_err(c, "internal: frame layout not collected"); return SCALCE_ERR_ARG; }
   const u32 b0 = (u32)(std::upper_bound(off.begin(), off.end(), (u64)offset) - off.begin()) - 1u;  // off[0] = 0 <= offset
   const u32 b1 = (u32)(std::lower_bound(off.begin(), off.end(), (u64)(offset + nbytes)) - off.begin());
-  LAUNCH(ac_frame_window_k, dim3(cdiv(b->ac_stride[mate], 16 * 256), b1 - b0), 256, 0, s, b->ac_blocks[mate].as<u8>(), b->ac_stride[mate],
+  LAUNCH(ac_frame_window_k, dim3(cdiv(b->ac_stride[mate], 16 * 256), b1 - b0), 256, 0, s, b->ac_base[mate], b->ac_stride[mate],
          b->ac_sizes[mate].as<u32>(), b->ac_off[mate].as<u64>(), (u64)offset, (u64)(offset + nbytes), static_cast<u8 *>(dst), b0);
   return launch_failed(c);
 }
@@ -2610,7 +2800,7 @@ static int materialize_frames(scalce_batch *b, int m) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
   ENSURE(b, b->out_qual[m], (size_t)b->out_qual_bytes[m] + 64);
-  LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), b->frame_virtual[m]), 256, 0, (hipStream_t) nullptr, b->ac_blocks[m].as<u8>(), b->ac_stride[m],
+  LAUNCH(ac_frame_k, dim3(cdiv(b->ac_stride[m], 16 * 256), b->frame_virtual[m]), 256, 0, (hipStream_t) nullptr, b->ac_base[m], b->ac_stride[m],
          b->ac_sizes[m].as<u32>(), b->ac_off[m].as<u64>(), b->out_qual[m].as<u8>());
   HIP_TRY(c, hipDeviceSynchronize());
   b->frame_virtual[m] = 0;

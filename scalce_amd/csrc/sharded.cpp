@@ -4,7 +4,8 @@
 // is exchanged, nothing else (sizes for 8 ranks x 50 M reads of 100 bp):
 //   spill rule      compress.cpp:702-715  running record bytes of the open chunk: a chain of `world` 8-byte messages, then
 //                                         an all-gather of the cuts; rank boundaries move to the nearest cut and the records
-//                                         in between change owner AS TEXT (at most half a chunk per boundary, ~2.6 GB)
+//                                         in between change owner AS TEXT (at most half a chunk per boundary, ~2.6 GB); the
+//                                         rows that stay are kept as they are (scalce_batch_rewindow)
 //   quality model   qualities.cpp:179-198 all-reduce of the 80^3 counters (4 MB per mate) + the trigrams that straddle a
 //                                         rank boundary (all-gather of 4 edge symbols)
 //   tie-break       reads.cpp:246,420     per round an all-gather of the per-bucket counts (125 KB); a rank's prior is the
@@ -375,9 +376,13 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     for (int r = 1; r < W; r++) anything_moves = anything_moves || gn[r] != g[r];
     if (anything_moves) {
       // Rows [g[rank], g[rank + 1]) were ingested here; rows [gn[d], gn[d + 1]) belong to rank d now.  My rows go to their new
-      // owners in rank order, which is the order they have in my text: the text itself is the send buffer.
-      uint8_t *newtext[2] = {nullptr, nullptr};
-      u64 newbytes[2] = {0, 0};
+      // owners in rank order, which is the order they have in my text: the text itself is the send buffer, every range where it
+      // lies.  What arrives from the ranks in front goes IN FRONT of the rows that stay, what arrives from the ranks behind goes
+      // behind them; the rows that stay are not ingested again (scalce_batch_rewindow; rounds 1-4 rebuilt the whole range from
+      // text: a second ingest and a second first walk of every row).
+      const uint8_t *front_text[2] = {nullptr, nullptr}, *back_text[2] = {nullptr, nullptr};
+      uint64_t front_bytes[2] = {0, 0}, back_bytes[2] = {0, 0};
+      const u64 keep_lo = clampu(gn[rank], g[rank], g[rank + 1]), keep_hi = clampu(gn[rank + 1], g[rank], g[rank + 1]);
       for (int m = 0; m < nm; m++) {
         std::vector<uint64_t> sendb(W, 0), recvb(W, 0), start(W + 1, 0);
         for (int d = 0; d <= W; d++) {
@@ -391,31 +396,27 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
         // who receives how much from whom
         std::vector<u64> all = gather_host<u64>(comm, sendb.data(), (size_t)W, d_small, d_gather, s);
         for (int src = 0; src < W; src++) recvb[src] = all[(size_t)src * W + rank];
-        const u64 kept = sendb[rank];
-        u64 total = 0, before_self = 0;
-        for (int src = 0; src < W; src++) { if (src < rank) before_self += recvb[src]; total += recvb[src]; }
-        newbytes[m] = total;
-        newtext[m] = mem.alloc<uint8_t>(newbytes[m] + 256);
-        // everything but the rows that stay goes through the all-to-all
-        std::vector<uint64_t> sb = sendb, rb = recvb;
+        u64 before_self = 0, after_self = 0;
+        for (int src = 0; src < W; src++) { if (src < rank) before_self += recvb[src]; else if (src > rank) after_self += recvb[src]; }
+        // everything but the rows that stay goes through the transport; the two parts land 16-byte aligned (the ingest kernels
+        // read their text in aligned 16-byte words)
+        const u64 back_at = (before_self + 15) & ~15ull;
+        uint8_t *d_recv = mem.alloc<uint8_t>(back_at + after_self + 256);
+        std::vector<uint64_t> sb = sendb, rb = recvb, so(W), ro(W);
         sb[rank] = 0;
         rb[rank] = 0;
-        uint8_t *d_send = mem.alloc<uint8_t>(nbytes[m] - kept + 256);
-        uint8_t *d_recv = mem.alloc<uint8_t>(total - kept + 256);
-        if (start[rank]) SH_HIP(hipMemcpyAsync(d_send, text[m], start[rank], hipMemcpyDeviceToDevice, s));
-        if (nbytes[m] > start[rank + 1])
-          SH_HIP(hipMemcpyAsync(d_send + start[rank], text[m] + start[rank + 1], nbytes[m] - start[rank + 1], hipMemcpyDeviceToDevice, s));
-        SH_CM(comm, scalce_comm_all_to_all_v(comm, d_send, sb.data(), d_recv, rb.data(), s));
-        if (before_self) SH_HIP(hipMemcpyAsync(newtext[m], d_recv, before_self, hipMemcpyDeviceToDevice, s));
-        if (kept) SH_HIP(hipMemcpyAsync(newtext[m] + before_self, text[m] + start[rank], kept, hipMemcpyDeviceToDevice, s));
-        if (total - kept - before_self)
-          SH_HIP(hipMemcpyAsync(newtext[m] + before_self + kept, d_recv + before_self, total - kept - before_self, hipMemcpyDeviceToDevice, s));
+        u64 fa = 0, ba = back_at;
+        for (int r = 0; r < W; r++) {
+          so[r] = start[r];
+          if (r < rank) { ro[r] = fa; fa += rb[r]; } else { ro[r] = ba; ba += rb[r]; }
+        }
+        SH_CM(comm, scalce_comm_all_to_all_vo(comm, text[m], so.data(), sb.data(), d_recv, ro.data(), rb.data(), s));
+        front_text[m] = d_recv; front_bytes[m] = before_self;
+        back_text[m] = d_recv + back_at; back_bytes[m] = after_self;
       }
       // the rows of the new range (their quality symbols were counted by whoever held them in the first pass)
       local([&] {
-        SH_RC(ctx, scalce_batch_reset(b));
-        SH_RC(ctx, scalce_batch_append(b, newtext[0], newbytes[0], nm == 2 ? newtext[1] : nullptr, newbytes[1],
-                                       SCALCE_APPEND_FINAL | SCALCE_APPEND_NO_QUALITY | SCALCE_APPEND_NO_TOKENIZE, used, s));
+        SH_RC(ctx, scalce_batch_rewindow(b, keep_lo - g[rank], keep_hi - keep_lo, front_text, front_bytes, back_text, back_bytes, s));
         if (scalce_batch_reads(b) != res->reads_local) throw Fail{"internal: row count after the exchange differs from the plan", SCALCE_ERR_ARG};
       });
     }

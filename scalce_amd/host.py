@@ -103,6 +103,7 @@ def lib():
     L.scalce_batch_entropy_begin_group.argtypes = [C.POINTER(vp), i32, vp, vp]
     L.scalce_batch_entropy_begin_group_last.argtypes = [C.POINTER(vp), i32, vp, vp, i32]
     L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
+    L.scalce_batch_front.argtypes = [vp, vp, u64, vp, u64, vp, vp]
     L.scalce_batch_finish.argtypes = [vp, vp]
     L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
     L.scalce_batch_set_frame_on_demand.argtypes = [vp, i32]
@@ -499,15 +500,10 @@ class Batch:
     def entropy_stream_prepare(self, mate, d_table, d_symbols, nsym, stream=0):
         self._check(self.L.scalce_batch_entropy_stream_prepare(self.h, mate, d_table, d_symbols, int(nsym), stream))
 
-    def front(self, d_text1, n1, d_text2=None, n2=0, stream=0):
-        """Every stage before the entropy coder (ingest .. emit) on `stream`."""
-        self.ingest(0, d_text1, n1, stream)
-        if self.params.paired:
-            self.ingest(1, d_text2, n2, stream)
-        self.quality(stream)
-        self.tokenize(None, stream)
-        self.order(stream)
-        self.emit(stream)
+    def front(self, d_text1, n1, d_text2=None, n2=0, stream=0, side_stream=0):
+        """Every stage before the entropy coder (ingest .. emit) on `stream` (scalce_batch_front); side_stream: the quality
+        statistics run there beside the tie-break."""
+        self._check(self.L.scalce_batch_front(self.h, d_text1, int(n1), d_text2, int(n2), stream, side_stream))
 
     def compress(self, d_text1, n1, d_text2=None, n2=0, stream=0):
         self._check(self.L.scalce_batch_compress(self.h, d_text1, int(n1), d_text2, int(n2), stream))
@@ -531,6 +527,17 @@ class Batch:
     def set_frame_on_demand(self, on=True):
         """The coded blocks are framed on their way out (qual_window) instead of by a copy pass behind the coder."""
         self._check(self.L.scalce_batch_set_frame_on_demand(self.h, int(on)))
+
+    def set_code_in_place(self, on=True):
+        """Grouped coder launches write a block's bytes over its own symbols (no block buffers); the caller keeps the shard's text
+        in place until the shard is collected (scalce_batch_set_code_in_place)."""
+        self._check(self.L.scalce_batch_set_code_in_place(self.h, int(on)))
+
+    @property
+    def reruns(self):
+        self.L.scalce_batch_reruns.restype = C.c_uint64
+        self.L.scalce_batch_reruns.argtypes = [C.c_void_p]
+        return int(self.L.scalce_batch_reruns(self.h))
 
     def qual_bytes(self, mate=0):
         n = C.c_uint64()

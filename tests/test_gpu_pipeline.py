@@ -44,10 +44,69 @@ def test_pipelined_shards_equal_one_shot_compress(group, slots, shared, patterns
         for i, (t, nb, n) in enumerate(shards):
             slot, b = pipe.acquire()
             with torch.cuda.stream(pipe.front):
-                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream)
+                # (second pass: the quality statistics on the pipeline's side stream, beside the tie-break)
+                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream, pipe.side.cuda_stream if rep else 0)
             pipe.submit(slot, tag=(rep, i), flush=(i + 1 == len(shards)))
     pipe.drain()
     assert len(got) == 2 * len(shards)
     for (rep, i), g in got.items():
         for w, name in ((host.OUT_QUAL, "qualities"), (host.OUT_READS, "reads"), (host.OUT_NAMES, "names")):
             assert len(g[w]) == len(want[i][w]) and (g[w] == want[i][w]).all(), f"shard {i} (pass {rep}): {name} differ"
+
+
+@pytest.mark.parametrize("bpw,overflow", [("", False), ("64", False), ("8", False), ("64", True), ("", True)])
+def test_coding_in_place_writes_the_same_streams(bpw, overflow, patterns_blob, monkeypatch):
+    """scalce_batch_set_code_in_place: the coder's blocks go over the symbols they were coded from (no block buffers: 3.2 GB less
+    per 50 M-read shard in flight) -- the same bytes through every kernel a grouped launch takes (four / eight blocks per chain
+    wave, one block per lane).  overflow: SCALCE_AC_INPLACE_TEST makes the kernels' bound so tight that a block's output catches
+    up with its input: its symbols are gone, the shard is run again from its text (arithmetic.cpp:85-169 knows no such case:
+    its output buffer is a buffer of its own)."""
+    import torch
+    from gpu_util import device_bytes
+    if bpw:
+        monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", bpw)
+    if overflow:
+        monkeypatch.setenv("SCALCE_AC_INPLACE_TEST", "1")
+    ctx = host.Context(0, patterns_bin=patterns_blob)
+    L = 100
+    sizes = [230_000, 120_000, 5_000, 40_000, 330_000, 110_000]   # 1 .. 4 coder blocks, the last one short or tiny
+    shards, want = [], []
+    for i, n in enumerate(sizes):
+        bases, quals = synth.reads_and_quals(n, L, seed=300 + i, dup_frac=0.1)
+        fq = synth.fastq_bytes_fast(bases, quals, prefix=f"q{i}.")
+        shards.append((device_bytes(fq), len(fq), n))
+    monkeypatch.delenv("SCALCE_AC_BLOCKS_PER_WG", raising=False)
+    for t, nb, n in shards:   # one shard at a time, block buffers of its own
+        b = host.Batch(ctx, L, n + 8, nb + 64)
+        b.compress(t.data_ptr(), nb)
+        b.finish()
+        want.append({w: b.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)})
+        b.close()
+    if bpw:
+        monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", bpw)
+    nmax, bmax = max(sizes), max(s[1] for s in shards)
+    ws = host.Workspace(ctx)
+    batches = [host.Batch(ctx, L, nmax + 8, bmax + 64, workspace=ws) for _ in range(6)]
+    for b in batches:
+        b.set_frame_on_demand(True)
+        b.set_code_in_place(True)
+    got = {}
+
+    def on_retire(slot, batch, tag):
+        got[tag] = {w: batch.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)}
+
+    pipe = ShardPipeline(batches, group=3, on_retire=on_retire)
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for i, (t, nb, n) in enumerate(shards):
+            slot, b = pipe.acquire()
+            with torch.cuda.stream(pipe.front):
+                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream, pipe.side.cuda_stream)
+            pipe.submit(slot, tag=(rep, i), flush=(i + 1 == len(shards)))
+    pipe.drain()
+    assert len(got) == 2 * len(shards)
+    for (rep, i), g in got.items():
+        for w, name in ((host.OUT_QUAL, "qualities"), (host.OUT_READS, "reads"), (host.OUT_NAMES, "names")):
+            assert len(g[w]) == len(want[i][w]) and (g[w] == want[i][w]).all(), f"shard {i} (pass {rep}): {name} differ"
+    reruns = sum(b.reruns for b in batches)
+    assert (reruns > 0) == overflow, f"{reruns} shards were run again from their text"

@@ -19,18 +19,25 @@ def main():
     dev = torch.device("cuda", 0)
     comm = host.Comm(0, 1, 0, unique_id=host.Comm.unique_id())
     G = 1 << 30
-    for n in (3 * G, 4 * G - 4096, 4 * G, 4 * G + (1 << 20), 5 * G, 5 * G + 12345):
+    for n in (G, 2 * G - 4096, 2 * G, 2 * G + (1 << 20), 3 * G, 4 * G - 4096, 4 * G, 4 * G + (1 << 20), 5 * G + 12345):
         src = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 >> 7).to(torch.uint8)
         dst = torch.zeros(n, dtype=torch.uint8, device=dev)
         comm.all_to_all_v(src.data_ptr(), [n], dst.data_ptr(), [n])
         torch.cuda.synchronize()
-        bad = (src != dst)
-        nbad = int(bad.sum())
-        first = int(bad.nonzero()[0]) if nbad else -1
-        last = int(bad.nonzero()[-1]) if nbad else -1
+        nbad, first, last = 0, -1, -1
+        for a in range(0, n, 1 << 28):       # (a nonzero() over billions of elements overflows torch's index arithmetic)
+            neq = src[a:a + (1 << 28)] != dst[a:a + (1 << 28)]
+            k = int(neq.sum())
+            if k:
+                nbad += k
+                idx = neq.to(torch.uint8)
+                if first < 0:
+                    first = a + int(idx.argmax())
+                last = a + idx.numel() - 1 - int(idx.flip(0).argmax())
+            del neq
         print(f"one ncclSend/ncclRecv of {n} bytes ({n / G:.3f} GiB): {nbad} wrong bytes, first at {first}, last at {last}"
-              + (f" = 2^32 + {first - (1 << 32)}" if first >= (1 << 32) else ""), flush=True)
-        del src, dst, bad
+              + (f" (first = 2^31 {first - (1 << 31):+d} = 2^32 {first - (1 << 32):+d})" if first >= 0 else ""), flush=True)
+        del src, dst
         torch.cuda.empty_cache()
     comm.close()
 
