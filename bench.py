@@ -97,6 +97,18 @@ def main():
     # ONE GPU through the shared-memory transport.
     sharded = world > 1 or bool(os.environ.get("SCALCE_BENCH_FORCE_SHARDED"))
     comm = None
+
+    def make_comm(k):
+        if os.environ.get("SCALCE_COMM") == "shm":
+            name = [("/scalce_bench_%d_%d" % (os.getpid(), k)) if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(name, src=0)
+            return host.Comm(local, world, rank, shm_name=name[0], slot_bytes=int(os.environ.get("SCALCE_SHM_SLOT", str(8 << 30))))
+        uid = [host.Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        return host.Comm(local, world, rank, unique_id=uid[0])
+
     if sharded:
         # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout is the one JSON line's, so
         # the banner goes to stderr
@@ -104,16 +116,7 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            if os.environ.get("SCALCE_COMM") == "shm":
-                name = [("/scalce_bench_%d" % os.getpid()) if rank == 0 else None]
-                if world > 1:
-                    dist.broadcast_object_list(name, src=0)
-                comm = host.Comm(local, world, rank, shm_name=name[0], slot_bytes=int(os.environ.get("SCALCE_SHM_SLOT", str(8 << 30))))
-            else:
-                uid = [host.Comm.unique_id() if rank == 0 else None]
-                if world > 1:
-                    dist.broadcast_object_list(uid, src=0)
-                comm = host.Comm(local, world, rank, unique_id=uid[0])
+            comm = make_comm(0)
             comm.barrier()
         finally:
             sys.stdout.flush()
@@ -135,6 +138,11 @@ def main():
     # jobs a card can hold).  What is free now decides how many fit.
     own_text = not args.shared_input
     in_place = not sharded and not os.environ.get("SCALCE_BENCH_NO_INPLACE")
+    # `fronts`: host threads, each with a front stream, a context, a set of front-stage buffers, D / fronts of the slots and -- in
+    # a sharded run -- a communicator of its own.  One is right for a GPU on its own (two measured the same, round 3).  A rank
+    # among several takes TWO: what a shard waits for between ranks -- the tie-break's chain (a settle per rank in front of it),
+    # the rows and q' bytes on the wire -- is then time the rank's other pipeline computes in.
+    F = max(1, int(os.environ.get("SCALCE_BENCH_FRONTS", "2" if (sharded and world > 1) else "1")))
     if args.inflight is None:
         free_b, _ = torch.cuda.mem_get_info()
         scale = (n * L) / 5e9
@@ -145,21 +153,27 @@ def main():
         # shared: the front-stage workspace (~20 GB); a sharded rank adds the reordered stream (5 GB) and, with peers, the receive
         # side of the q' exchange (5 GB), the rows that change owner (text in, half a chunk at most) and the second set of row
         # arrays (scalce_batch_rewindow, 9 GB)
-        shared = 22e9 * scale + (0 if not sharded else (6e9 + (0 if world == 1 else 14e9 + 0.5 * nbytes)) * scale)
+        shared = F * (22e9 * scale + (0 if not sharded else (6e9 + (0 if world == 1 else 14e9 + 0.5 * nbytes)) * scale))
         fit = int((free_b + (nbytes if own_text else 0) - shared - 5e9) // per_slot)
         if world > 1:   # every rank takes the same shape
             tfit = torch.tensor([fit], dtype=torch.int64)
             dist.all_reduce(tfit, op=dist.ReduceOp.MIN)
             fit = int(tfit.item())
-        want = D if not auto_group else 18   # (more slots than that buy nothing: three launches of five or six cover a launch's latency)
+        want = D if not auto_group else 16   # (more slots than that buy nothing: tools/r5_sweep.sh, 15 and 16 measure the same)
         if fit != D and (fit < D or auto_group):
             D = max(1, min(fit, want))
             if auto_group:
                 # A coder launch takes ~0.5 s whatever it holds: what counts is that every group of slots has a stream of its own
-                # and that a slot is free when the front stream wants one.  Twelve slots: six shards per launch on two streams, four
-                # on three and three on four measure the same at 20 steps (tools/pipe_shapes_r4.sh): six it is -- the fewest, largest
-                # launches of the dominant kernel.  Fifteen and more (round 5, coding in place): five per launch on three streams.
-                G = 5 if D >= 15 else (6 if D >= 12 else (3 if D >= 6 else max(1, D // 2)))
+                # and that a slot is free when the front stream wants one.  Six shards per launch on two streams: with twelve
+                # slots (round 4) 6 / 2, 4 / 3 and 3 / 4 measured the same; with fifteen (round 5, coding in place) 6 / 2 gives
+                # 74.0 ms per shard, 5 / 3 80.5, 7 / 2 81.1 (tools/r5_sweep.sh) -- a third launch side by side takes the CUs the
+                # front stages need (72-77 ms per front stage beside two launches of five against 48 beside two of six), and at
+                # the driver's 20 steps the last launch is two shards on the kernel with the lower latency.
+                G = 6 if D >= 12 else (3 if D >= 6 else max(1, D // 2))
+            if F > 1:   # every front takes D / F slots and at least two launches' worth of them
+                D -= D % F
+                if auto_group:
+                    G = 3 if D // F >= 6 else max(1, D // F // 2)
             print("bench: %.0f GB of HBM free: %d shards in flight, %d per coder launch" % (free_b / 1e9, D, G), file=sys.stderr)
     if G > 1:
         D = max(D, 2 * G)
@@ -179,10 +193,21 @@ def main():
     # of its own: the front stages are ~250 launches per shard with a dozen read-backs between them, and many of the
     # launches (late tie-break sweeps, radix passes over a few thousand keys) leave most of the chip idle -- a second
     # shard's front stages fill those holes
-    F = 1 if sharded else max(1, int(os.environ.get("SCALCE_BENCH_FRONTS", "1")))
     if F > 1:
         assert G > 1 and D % F == 0 and D // F >= 2 * G, "fronts: D / fronts >= 2 * group"
     ctxs = [ctx] + [host.Context(local, patterns_bin=blob) for _ in range(F - 1)]
+    comms = [comm]
+    if sharded:
+        for f in range(1, F):   # a communicator per front: their collectives interleave in any order across the two threads
+            sys.stdout.flush()
+            saved_stdout = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                comms.append(make_comm(f))
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                os.close(saved_stdout)
     batches = []
     for f in range(F):
         ws = None if os.environ.get("SCALCE_BENCH_OWN_WORKSPACES") else host.Workspace(ctxs[f])
@@ -213,7 +238,7 @@ def main():
     DF = D // F
     # as many coder streams as groups fit the slots (every launch takes ~0.6 s whatever it holds: with a stream per group in
     # rotation no group waits for another's launch to end; 3 / 4 / 12 measured 88.1 ms per shard against 90.0 at 3 / 3 / 12)
-    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(6, DF // G)) if (G > 1 and DF >= 2 * G) else "1"))
+    n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(2 if G >= 6 else 6, DF // G)) if (G > 1 and DF >= 2 * G) else "1"))
     pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
                            coder_streams=n_coder_streams)
              for f in range(F)]
@@ -241,23 +266,27 @@ def main():
             raise errs[0]
 
     slot_of_pipe = {id(p): f * DF for f, p in enumerate(pipes)}
+    front_of_pipe = {id(p): f for f, p in enumerate(pipes)}
 
     def run_on(pipe, k):
+        fr = front_of_pipe[id(pipe)]
+        comm, ctx = comms[fr], ctxs[fr]
         for j in range(k):
             slot, b = pipe.acquire()
             mark(f"shard {j}: front (slot {slot})")
-            tx = texts[slot_of_pipe[id(pipe)] + slot]
+            gslot = slot_of_pipe[id(pipe)] + slot
+            tx = texts[gslot]
             with torch.cuda.stream(pipe.front):
                 if not sharded:
                     b.front(tx.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream,
                             0 if os.environ.get("SCALCE_BENCH_NO_SIDE") else pipe.side.cuda_stream)
                 elif G == 1:
-                    state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
-                                                        stream=pipe.front.cuda_stream, coder_stream=pipe.coder.cuda_stream,
-                                                        result=state.get(slot))
+                    state[gslot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
+                                                         stream=pipe.front.cuda_stream, coder_stream=pipe.coder.cuda_stream,
+                                                         result=state.get(gslot))
                 else:
-                    state[slot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
-                                                        stream=pipe.front.cuda_stream, result=state.get(slot))
+                    state[gslot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
+                                                         stream=pipe.front.cuda_stream, result=state.get(gslot))
             mark(f"shard {j}: front done")
             pipe.submit(slot, tag=j, flush=j + 1 == k)
         pipe.drain()

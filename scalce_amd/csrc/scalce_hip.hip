@@ -2097,8 +2097,12 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool f
 // round 4 the default is 40 (below).
 static u32 ac_lanes_used() {
   const char *e = getenv("SCALCE_AC_LANES_USED");
-  const int v = e ? atoi(e) : 40;  // (round 4, with the ring stores in the writer wave: 79.9 / 80.0 / 81.1 / 81.7 / 82.2 / 85.6 ms per shard at 32 / 36 / 40 / 44 / 48 / 56)
-  return (u32)(v < 1 || v > 64 ? 40 : v);
+  // round 4 (twelve slots, block buffers of their own): 79.9 / 80.0 / 81.1 / 81.7 / 82.2 / 85.6 ms per shard at 32 / 36 / 40 / 44 / 48 / 56,
+  // 40 the default.  Round 5 (fifteen slots, coded in place, six shards per launch on two streams; tools/r5_sweep.sh): 79.3 / 79.6 /
+  // 74.0 / 74.6 / 75.2 / 77.9 / 81.8 at 24 / 28 / 32 / 36 / 40 / 48 / 56 -- a launch takes 0.47 s at 32 against 0.50 at 40, and with
+  // slots to spare the pipeline follows the launch's latency: 32.
+  const int v = e ? atoi(e) : 32;
+  return (u32)(v < 1 || v > 64 ? 32 : v);
 }
 
 // Sets of four waves per workgroup of ac_encode_lanes_k: 2 = eight waves over 2 x lanes_used blocks on one CU -- two thirds of

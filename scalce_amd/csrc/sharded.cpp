@@ -82,7 +82,9 @@ struct Arena {
   void *p = nullptr;
   size_t cap = 0;
 };
-static std::vector<Arena> g_scratch;
+// (per host thread: a caller that drives two pipelines from two threads -- each with a communicator of its own, so that one's
+//  waits overlap the other's work -- gives each its own scratch)
+static thread_local std::vector<Arena> g_scratch;
 struct DevMem {
   size_t next = 0;
   template <typename T> T *alloc(size_t n) {
@@ -240,7 +242,7 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     scalce_batch *b; bool on;
     ~StreamScratch() { if (on) scalce_batch_set_stream_scratch(b, 0); }
   } stream_scratch{b, scalce_batch_set_stream_scratch(b, 1) == SCALCE_OK};
-  static std::string last_error;
+  static thread_local std::string last_error;
   // SCALCE_SHARD_TRACE=1: where a rank's time goes (the stream is drained at every mark: for looking, not for timing runs)
   const bool trace = getenv("SCALCE_SHARD_TRACE") != nullptr;
   double t_last = 0;
