@@ -278,8 +278,7 @@ def main():
             tx = texts[gslot]
             with torch.cuda.stream(pipe.front):
                 if not sharded:
-                    b.front(tx.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream,
-                            0 if os.environ.get("SCALCE_BENCH_NO_SIDE") else pipe.side.cuda_stream)
+                    b.front(tx.data_ptr(), nbytes, None, 0, pipe.front.cuda_stream)
                 elif G == 1:
                     state[gslot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_CODER_ASYNC,
                                                          stream=pipe.front.cuda_stream, coder_stream=pipe.coder.cuda_stream,

@@ -176,15 +176,10 @@ int scalce_batch_quality(scalce_batch *b, void *stream);
  * resolved exactly in input order (-T 1 semantics).  d_prior_counts: per-bucket counts of reads
  * assigned by EARLIER shards (bucket order = scalce_bucket_*), or NULL. */
 int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior_counts, void *stream);
-/* The same in pieces, for runs sharded over several GPUs: begin (scan, candidates, first counts), then
- * sweeps -- each re-decides this shard's tie reads against `d_prior_counts` (reads of EARLIER shards per
- * bucket under the current decisions, i.e. the exclusive sum over ranks of SCALCE_OUT_BUCKET_COUNTS) and
- * refreshes SCALCE_OUT_BUCKET_COUNTS -- until no rank reports a change, then end.  The fixed point is the
- * sequential (-T 1) result over the whole run. */
+/* The same in two halves: _begin (both walks, candidates, events, first counts) and _settle (below).  A run sharded over
+ * several GPUs calls _begin on every rank at once and _settle rank by rank: rank r settles against the counts of ranks
+ * 0 .. r-1 (d_prior_counts = their sum per bucket), then hands its own SCALCE_OUT_BUCKET_COUNTS on (scalce_sharded_compress). */
 int scalce_batch_tokenize_begin(scalce_batch *b, void *stream);
-int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior_counts, int *changed, void *stream);
-/* nsweeps (1..16) sweeps against the same prior counts, one look at their flags: *changed = 1 if any of them moved a decision */
-int scalce_batch_tokenize_sweeps(scalce_batch *b, const uint64_t *d_prior_counts, int nsweeps, int *changed, void *stream);
 int scalce_batch_tokenize_end(scalce_batch *b, void *stream);
 /* scalce_batch_tokenize = _begin + _settle: _settle resolves the tie-break of this batch on its own against fixed prior
  * counts (window by window in input order) and ends the tokenization.  Split so that a caller can enqueue other work of the
@@ -263,11 +258,8 @@ int scalce_copy_pieces(scalce_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst, co
 /* all of the above in order */
 int scalce_batch_compress(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2,
                           uint64_t n2, void *stream);
-/* Every stage in front of the entropy coder (ingest .. emit) of a shard resident as text (mate 2: NULL / 0 for single-end).
- * side_stream (may be NULL): the quality statistics run there beside the tie-break and the order stage; `stream` waits for
- * them before anything the caller enqueues next. */
-int scalce_batch_front(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2, void *stream,
-                       void *side_stream);
+/* Every stage in front of the entropy coder (ingest .. emit) of a shard resident as text (mate 2: NULL / 0 for single-end). */
+int scalce_batch_front(scalce_batch *b, const uint8_t *d_text1, uint64_t n1, const uint8_t *d_text2, uint64_t n2, void *stream);
 /* Synchronises `stream`, checks the device error word, fills the host-side result sizes. */
 int scalce_batch_finish(scalce_batch *b, void *stream);
 
@@ -367,6 +359,9 @@ void scalce_comm_destroy(scalce_comm *c);
 const char *scalce_comm_error(const scalce_comm *c);
 int scalce_comm_world(const scalce_comm *c);
 int scalce_comm_rank(const scalce_comm *c);
+/* Largest message handed to the transport in one piece (default 1 GiB: RCCL loses the tail of larger ones between a rank and
+ * itself, comm.cpp); tools/rccl_big_send.py raises it to show where. */
+void scalce_comm_set_piece_bytes(scalce_comm *c, uint64_t bytes);
 int scalce_comm_barrier(scalce_comm *c, void *stream);
 int scalce_comm_all_gather(scalce_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
 int scalce_comm_all_reduce_sum_u64(scalce_comm *c, uint64_t *d_buf, uint64_t count, void *stream);
@@ -437,7 +432,6 @@ void scalce_pipeline_destroy(scalce_pipeline *p);
 const char *scalce_pipeline_error(const scalce_pipeline *p);
 void *scalce_pipeline_front_stream(scalce_pipeline *p);
 void *scalce_pipeline_coder_stream(scalce_pipeline *p, int i);
-void *scalce_pipeline_side_stream(scalce_pipeline *p);  /* a second front stream (scalce_batch_front: side_stream) */
 int scalce_pipeline_acquire(scalce_pipeline *p, int *slot, int *retired);
 int scalce_pipeline_submit(scalce_pipeline *p, int slot, int no_more_shards, int *launched);
 int scalce_pipeline_retire(scalce_pipeline *p, int slot, int *had_shard);

@@ -203,9 +203,9 @@ struct OutFile {
   // reference's own gz gains 2.5 % on it) and the slowest thing zlib can be fed: ~20 MB/s per core at level 6 -- 3.6 of the
   // 5.8 s of a 50 M-read run with -c gz.  A member none of whose sample windows (eight of 16 KiB, spread over the member)
   // shrinks by a tenth at level 1 is therefore Huffman-coded only (Z_HUFFMAN_ONLY: no match search, ~15 x the speed, within
-  // a percent of the size).  SCALCE_GZ_ALWAYS_DEFAULT_LEVEL=1 turns that off; SCALCE_GZ_LEVEL sets another level for the rest.
+  // a percent of the size).  SCALCE_GZ_LEVEL=<n> turns that off and deflates every member at level n.
   static bool hardly_compressible(const uint8_t *src, size_t n) {
-    static const bool off = getenv("SCALCE_GZ_ALWAYS_DEFAULT_LEVEL") != nullptr;
+    static const bool off = getenv("SCALCE_GZ_LEVEL") != nullptr;   // (a level asked for by hand is applied to every member)
     if (off || n < 4096) return false;
     const size_t win = std::min<size_t>(n, 16u << 10), nwin = n >= 8 * win ? 8 : 1;
     std::vector<uint8_t> tmp(compressBound((uLong)win));

@@ -95,6 +95,7 @@ struct scalce_comm {
   size_t map_bytes = 0;
   uint64_t slot_bytes = 0;
   std::vector<uint8_t> stage;
+  uint64_t piece_bytes = 1ull << 30;  // largest single ncclSend / ncclRecv (scalce_comm_set_piece_bytes)
 };
 
 #define CM_HIP(c, expr)                                                                                   \
@@ -119,6 +120,7 @@ static hipError_t cm_sync(const scalce_comm *c, hipStream_t s) { return c->devic
 
 extern "C" const char *scalce_comm_error(const scalce_comm *c) { return c ? c->err.c_str() : "null communicator"; }
 extern "C" int scalce_comm_world(const scalce_comm *c) { return c ? c->world : 1; }
+extern "C" void scalce_comm_set_piece_bytes(scalce_comm *c, uint64_t bytes) { if (c && bytes) c->piece_bytes = bytes; }
 extern "C" int scalce_comm_rank(const scalce_comm *c) { return c ? c->rank : 0; }
 
 extern "C" int scalce_comm_unique_id(uint8_t id[SCALCE_COMM_ID_BYTES]) {
@@ -332,7 +334,12 @@ extern "C" int scalce_comm_all_to_all_vo(scalce_comm *c, const void *d_send, con
     // The usual grouped send / receive pattern, in pieces of at most 1 GiB: RCCL takes a size_t count, but a 5 GB message
     // (the q' bytes of a 50 M-read shard) did not arrive whole -- the coded stream of a world-1 run over RCCL came out 18 %
     // larger than over a plain copy (round 4; sends and receives to one peer match in the order they are issued).
-    static const uint64_t PIECE = getenv("SCALCE_COMM_PIECE") ? strtoull(getenv("SCALCE_COMM_PIECE"), nullptr, 10) : (1ull << 30);  // (tools/rccl_big_send.py)
+    // Why pieces: RCCL 2.26.6 (ROCm 7.0.2) delivers only the first max(n / 2, 1 GiB) + 1 bytes of ONE ncclSend / ncclRecv pair of
+    // n >= 2 GiB between a rank and itself -- the rest of the receive buffer is never written, no error is returned
+    // (tools/rccl_big_send.py, profiles/r05_rccl_big_send.log: 1 GiB arrives whole; 2, 3, 4 GiB lose everything behind 1, 1.5,
+    // 2 GiB + 1 byte).  A 32-bit size somewhere in the self-copy path is our reading; whether a pair between two GPUs does the
+    // same could not be tried on one GPU, so nothing here sends more than 1 GiB at once.
+    const uint64_t PIECE = c->piece_bytes;
     bool any = false;
     for (int r = 0; r < c->world; r++) any = any || send_bytes[r] || recv_bytes[r];
     if (!any) return SCALCE_OK;

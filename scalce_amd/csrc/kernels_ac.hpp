@@ -1375,340 +1375,8 @@ __global__ __launch_bounds__(256) void ac_dec_rows_k(const uint4 *tab, u32 smin,
   if (smin + j >= 1) { const uint4 e = tab[(u64)ctx * AC_D + (smin + j - 1)]; v = make_uint2(e.z, e.w); }
   rows[i] = v;
 }
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void ac_decode_cached_k(AcDecCachedArgs a) {
-  __shared__ uint2 cache[AC_DEC_CACHE_ENTRIES];
-  const u32 W = a.W, S1 = a.S1;
-  for (u32 i = threadIdx.x; i < W * W * S1; i += blockDim.x) {
-    const u32 slot = i / S1, j = i % S1;
-    const u32 ctx = (u32)a.hot[slot / W] * AC_D + a.hot[slot % W];
-    cache[i] = a.rows[(u64)ctx * S1 + j];
-  }
-  __syncthreads();
-  const u32 blk = blockIdx.x * WPB + wave_id();
-  if (blk >= a.nblk) return;
-  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
-  const u32 n = (u32)((a.d.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.d.nsym - boff) : (u64)AC_BLOCK_SYMS);
-  const u8 *in = a.d.in + a.d.blk_off[blk];
-  const u32 insz = a.d.blk_size[blk];
-  u8 *out = a.d.out + boff;
-  const int lane = lane_id();
-  u32 p0 = insz > 0 ? in[0] : 0, p1 = insz > 1 ? in[1] : 0;
-  if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
-  if (p0 >= AC_D) p0 = AC_D - 1;
-  if (p1 >= AC_D) p1 = AC_D - 1;
-  const u32 rk0 = a.rank[lane], rk1 = lane < 16 ? a.rank[64 + lane] : 0xFFu;
-  auto rank_of = [&](u32 sy) -> u32 {  // sy wave-uniform
-    const u32 x0 = __builtin_amdgcn_readlane(rk0, sy & 63), x1 = __builtin_amdgcn_readlane(rk1, sy & 15);
-    return sy < 64 ? x0 : x1;
-  };
-  auto fetch = [&](u32 c0, u32 c1, u32 q0, u32 q1) -> uint2 {
-    uint2 e = make_uint2(0, 0);
-    if ((u32)lane < S1) {
-      if (__builtin_expect(q0 < W && q1 < W, 1)) e = cache[(q0 * W + q1) * S1 + lane];
-      else e = a.rows[(u64)(c0 * AC_D + c1) * S1 + lane];
-    }
-    return e;
-  };
-  AcBitReader br;
-  br.start(in, insz, 2, lane);
-  auto getbits = [&](u32 cnt) -> u32 { return br.get(cnt, lane); };
-  u32 lo = 0, hi = 0xFFFFFFFFu, code = getbits(32);
-  u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
-  u32 r0 = rank_of(p0), r1 = rank_of(p1);
-  uint2 e = fetch(p0, p1, r0, r1);  // zeros in the lanes beyond S1: their bound is 0, never above the code value
-  for (u32 i = 2; i < n; i++) {
-    const u32 R = hi - lo, v = code - lo;
-    const u64 lastm = __ballot((e.x & e.y) == 0xFFFFFFFFu);  // g(hi) = 2^64 - 1 marks the context's last symbol
-    const u32 U = mulfrac_m(R + 1, R == 0xFFFFFFFFu, e.x, e.y);
-    const u64 m = __ballot(v < U) | lastm;
-    const u32 j = m ? (u32)__ffsll((long long)m) - 1 : S1;
-    u32 sidx, A, B;
-    bool is_last;
-    if (__builtin_expect(j == 0 || j >= S1, 0)) {
-      // below or above the symbols the compact rows hold: the full row, as ac_decode_k
-      const uint4 *row = a.d.tab + (u64)(p0 * AC_D + p1) * AC_D;
-      const uint4 f0 = row[lane];
-      const uint4 f1 = lane < 16 ? row[64 + lane] : make_uint4(0, 0, 0, 0);
-      const bool last0 = f0.w == 0xFFFFFFFFu, last1 = f1.w == 0xFFFFFFFFu;
-      const u32 U0 = mulfrac(R, f0.z, f0.w), U1 = mulfrac(R, f1.z, f1.w);
-      const u64 m0 = __ballot(last0 || v < U0);
-      const u64 m1 = __ballot(lane < 16 && (last1 || v < U1));
-      if (m0) {
-        sidx = (u32)__ffsll((long long)m0) - 1;
-        A = __builtin_amdgcn_readlane(U0, sidx);
-        is_last = __builtin_amdgcn_readlane((u32)last0, sidx) != 0;
-        B = sidx ? __builtin_amdgcn_readlane(U0, sidx - 1) : 0u;
-      } else {
-        const u32 t = m1 ? (u32)__ffsll((long long)m1) - 1 : 15u;  // corrupt stream: last symbol
-        sidx = 64 + t;
-        A = __builtin_amdgcn_readlane(U1, t);
-        is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
-        B = t ? __builtin_amdgcn_readlane(U1, t - 1) : __builtin_amdgcn_readlane(U0, 63);
-      }
-    } else {
-      sidx = a.smin - 1 + j;
-      A = __builtin_amdgcn_readlane(U, j);
-      B = __builtin_amdgcn_readlane(U, j - 1);
-      is_last = ((lastm >> j) & 1) != 0;
-    }
-    // the next context is known: ask for its row before anything else
-    p0 = p1;
-    p1 = sidx;
-    r0 = r1;
-    r1 = rank_of(sidx);
-    const uint2 e_next = fetch(p0, p1, r0, r1);
-    ac_dec_renorm(lo, hi, code, lo + B, is_last ? hi : lo + A - 1, br, lane);
-    outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
-    if (__builtin_expect((i & 63) == 63, 0)) out[(i & ~63u) + lane] = (u8)outacc;
-    e = e_next;
-  }
-  const u32 done = n & ~63u;
-  if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
-}
 
-// ---- decoder, the same idea with the loop cut down to its dependency chain (round 3) ----------------------------
-// ac_decode_cached_k spends ~780 cycles per symbol (324 ns) on a chain that needs a quarter of that: its loop is ~110
-// instructions with ten branches and a dozen trips between the vector and the scalar unit (two ballots, four
-// v_readlane, an exec-masked choice between LDS and memory per lane, two v_mul_lo_u32 for an address, ...), and by the cost
-// table of tools/ubench_lds.hip every such trip is ~16 cycles on top of the instruction.  Here:
-//   * every lane fetches an entry of the next row, whatever S1 is: lanes beyond the row read what lies behind it (the
-//     cache and the row table are padded) and the ballot is cut to the row by one scalar AND -- no exec mask;
-//   * the host only takes this kernel when symbol 79 is not in the span (no "last symbol of its context" marker: one
-//     ballot instead of two) -- otherwise ac_decode_cached_k;
-//   * the rank of the decoded symbol (which LDS slot its row lives in) comes from ONE v_readlane of a per-lane constant
-//     (lane l of a row IS symbol smin - 1 + l);
-//   * the address of the next row is scalar arithmetic plus one v_lshl_add;
-//   * whatever is rare -- a code value outside the span, the full 2^32 range, a context outside the cache -- leaves the
-//     loop's path through a scalar branch and runs the generic step.
-// Same arguments and launch shapes as ac_decode_cached_k.
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void ac_decode_fast_k(AcDecCachedArgs a) {
-  __shared__ uint2 cache[AC_DEC_CACHE_ENTRIES + 64];
-  const u32 W = a.W, S1 = a.S1;
-  for (u32 i = threadIdx.x; i < W * W * S1; i += blockDim.x) {
-    const u32 slot = i / S1, j = i % S1;
-    const u32 ctx = (u32)a.hot[slot / W] * AC_D + a.hot[slot % W];
-    cache[i] = a.rows[(u64)ctx * S1 + j];
-  }
-  for (u32 i = W * W * S1 + threadIdx.x; i < W * W * S1 + 64; i += blockDim.x) cache[i] = make_uint2(0, 0);
-  __syncthreads();
-  const u32 blk = blockIdx.x * WPB + wave_id();
-  if (blk >= a.nblk) return;
-  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
-  const u32 n = __builtin_amdgcn_readfirstlane((u32)((a.d.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.d.nsym - boff) : (u64)AC_BLOCK_SYMS));
-  const u8 *in = a.d.in + a.d.blk_off[blk];
-  const u32 insz = a.d.blk_size[blk];
-  u8 *out = a.d.out + boff;
-  const int lane = lane_id();
-  u32 p0 = insz > 0 ? in[0] : 0, p1 = insz > 1 ? in[1] : 0;
-  if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
-  if (p0 >= AC_D) p0 = AC_D - 1;
-  if (p1 >= AC_D) p1 = AC_D - 1;
-  p0 = __builtin_amdgcn_readfirstlane(p0);
-  p1 = __builtin_amdgcn_readfirstlane(p1);
-  // lane l of a compact row is symbol smin - 1 + l: its rank among the cached symbols (0xFF: not cached), constant per lane
-  const u32 my_sym = a.smin - 1u + (u32)lane;  // (lane 0: the bound below the span, never decoded)
-  const u32 my_rank = (lane >= 1 && (u32)lane < S1 && my_sym < AC_D) ? (u32)a.rank[my_sym] : 0xFFu;
-  const u64 span = S1 >= 64 ? ~0ull : ((1ull << S1) - 1);
-  const u32 lane8 = (u32)lane * 8u;
-  auto rank_of = [&](u32 sy) -> u32 {  // sy wave-uniform; only for the two raw symbols and after the generic step
-    return sy < AC_D ? (u32)a.rank[sy] : 0xFFu;
-  };
-  // (LDS and memory through pointers of their own address spaces: left generic, the two loads become ONE flat_load of a
-  //  selected pointer, which waits on both counters and is slower than either)
-  typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-  const u32 cache_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) u32x2 *)cache;
-  const SCALCE_GLOBAL u32x2 *rows_g = (const SCALCE_GLOBAL u32x2 *)a.rows;
-  auto fetch = [&](u32 c0, u32 c1, u32 q0, u32 q1) -> uint2 {  // all lanes; c*, q* wave-uniform
-    if (__builtin_expect(q0 < W && q1 < W, 1)) {
-      const u32 base = (q0 * W + q1) * S1;  // scalar
-      const u32x2 x = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(cache_lds + base * 8u + lane8);
-      return make_uint2(x.x, x.y);
-    }
-    const u32x2 x = rows_g[(u64)(c0 * AC_D + c1) * S1 + lane];  // (the row table is padded by 64 entries)
-    return make_uint2(x.x, x.y);
-  };
-  AcBitReader br;
-  br.start(in, insz, 2, lane);
-  u32 lo = 0, hi = 0xFFFFFFFFu, code = br.get(32, lane);
-  u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
-  u32 q0 = rank_of(p0), q1 = rank_of(p1);
-  uint2 e = fetch(p0, p1, q0, q1);
-  for (u32 i = 2; i < n; i++) {
-    const u32 R = hi - lo, v = code - lo;
-    u32 sidx, A, B, qn;
-    bool is_last = false;
-    const u32 M = R + 1u;
-    // U[l] = floor(M * g[l] / 2^64): what symbol l's upper bound adds to lo (M = 0, the full range, goes the generic way)
-    const u32 U = (u32)(((u64)M * e.y + __umulhi(M, e.x)) >> 32);
-    const u64 m = __ballot(v < U) & span;
-    const u32 j = m ? (u32)__builtin_ctzll(m) : 0u;  // first symbol whose upper bound lies above the code value
-    if (__builtin_expect(M != 0u && j != 0u, 1)) {
-      sidx = a.smin - 1u + j;
-      A = __builtin_amdgcn_readlane(U, j);
-      B = __builtin_amdgcn_readlane(U, j - 1u);
-      qn = __builtin_amdgcn_readlane(my_rank, j);
-    } else {
-      // below or above the symbols the compact rows hold, the last symbol of a context, the full range: the full row
-      const uint4 *row = a.d.tab + (u64)(p0 * AC_D + p1) * AC_D;
-      const uint4 f0 = row[lane];
-      const uint4 f1 = lane < 16 ? row[64 + lane] : make_uint4(0, 0, 0, 0);
-      const bool last0 = f0.w == 0xFFFFFFFFu, last1 = f1.w == 0xFFFFFFFFu;
-      const u32 U0 = mulfrac(R, f0.z, f0.w), U1 = mulfrac(R, f1.z, f1.w);
-      const u64 m0 = __ballot(last0 || v < U0);
-      const u64 m1 = __ballot(lane < 16 && (last1 || v < U1));
-      if (m0) {
-        sidx = (u32)__ffsll((long long)m0) - 1;
-        A = __builtin_amdgcn_readlane(U0, sidx);
-        is_last = __builtin_amdgcn_readlane((u32)last0, sidx) != 0;
-        B = sidx ? __builtin_amdgcn_readlane(U0, sidx - 1) : 0u;
-      } else {
-        const u32 t = m1 ? (u32)__ffsll((long long)m1) - 1 : 15u;  // corrupt stream: last symbol
-        sidx = 64 + t;
-        A = __builtin_amdgcn_readlane(U1, t);
-        is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
-        B = t ? __builtin_amdgcn_readlane(U1, t - 1) : __builtin_amdgcn_readlane(U0, 63);
-      }
-      qn = rank_of(sidx);
-    }
-    // the next context is known: ask for its row before anything else
-    p0 = p1;
-    p1 = sidx;
-    q0 = q1;
-    q1 = qn;
-    const uint2 e_next = fetch(p0, p1, q0, q1);
-    ac_dec_renorm(lo, hi, code, lo + B, is_last ? hi : lo + A - 1, br, lane);
-    outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
-    if (__builtin_expect((i & 63) == 63, 0)) out[(i & ~63u) + lane] = (u8)outacc;
-    e = e_next;
-  }
-  const u32 done = n & ~63u;
-  if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
-}
 
-// ---- decoder, the state cut down to what the chain needs (round 4): ac_decode_fast_k with (lo, M, code - lo) ----------
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void ac_decode_lean_k(AcDecCachedArgs a) {
-  __shared__ uint2 cache[AC_DEC_CACHE_ENTRIES + 64];
-  const u32 W = a.W, S1 = a.S1;
-  for (u32 i = threadIdx.x; i < W * W * S1; i += blockDim.x) {
-    const u32 slot = i / S1, j = i % S1;
-    const u32 ctx = (u32)a.hot[slot / W] * AC_D + a.hot[slot % W];
-    cache[i] = a.rows[(u64)ctx * S1 + j];
-  }
-  for (u32 i = W * W * S1 + threadIdx.x; i < W * W * S1 + 64; i += blockDim.x) cache[i] = make_uint2(0, 0);
-  __syncthreads();
-  const u32 blk = blockIdx.x * WPB + wave_id();
-  if (blk >= a.nblk) return;
-  const u64 boff = (u64)blk * AC_BLOCK_SYMS;
-  const u32 n = __builtin_amdgcn_readfirstlane((u32)((a.d.nsym - boff) < (u64)AC_BLOCK_SYMS ? (a.d.nsym - boff) : (u64)AC_BLOCK_SYMS));
-  const u8 *in = a.d.in + a.d.blk_off[blk];
-  const u32 insz = a.d.blk_size[blk];
-  u8 *out = a.d.out + boff;
-  const int lane = lane_id();
-  u32 p0 = insz > 0 ? in[0] : 0, p1 = insz > 1 ? in[1] : 0;
-  if (lane == 0) { out[0] = (u8)p0; if (n > 1) out[1] = (u8)p1; }
-  if (p0 >= AC_D) p0 = AC_D - 1;
-  if (p1 >= AC_D) p1 = AC_D - 1;
-  p0 = __builtin_amdgcn_readfirstlane(p0);
-  p1 = __builtin_amdgcn_readfirstlane(p1);
-  // lane l of a compact row is symbol smin - 1 + l: its rank among the cached symbols (0xFF: not cached), constant per lane
-  const u32 my_sym = a.smin - 1u + (u32)lane;  // (lane 0: the bound below the span, never decoded)
-  const u32 my_rank = (lane >= 1 && (u32)lane < S1 && my_sym < AC_D) ? (u32)a.rank[my_sym] : 0xFFu;
-  const u64 span = S1 >= 64 ? ~0ull : ((1ull << S1) - 1);
-  const u32 lane8 = (u32)lane * 8u;
-  auto rank_of = [&](u32 sy) -> u32 {  // sy wave-uniform; only for the two raw symbols and after the generic step
-    return sy < AC_D ? (u32)a.rank[sy] : 0xFFu;
-  };
-  // (LDS and memory through pointers of their own address spaces: left generic, the two loads become ONE flat_load of a
-  //  selected pointer, which waits on both counters and is slower than either)
-  typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-  const u32 cache_lds = (u32)(uintptr_t)(__attribute__((address_space(3))) u32x2 *)cache;
-  const SCALCE_GLOBAL u32x2 *rows_g = (const SCALCE_GLOBAL u32x2 *)a.rows;
-  auto fetch = [&](u32 c0, u32 c1, u32 q0, u32 q1) -> uint2 {  // all lanes; c*, q* wave-uniform
-    if (__builtin_expect(q0 < W && q1 < W, 1)) {
-      const u32 base = (q0 * W + q1) * S1;  // scalar
-      const u32x2 x = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(cache_lds + base * 8u + lane8);
-      return make_uint2(x.x, x.y);
-    }
-    const u32x2 x = rows_g[(u64)(c0 * AC_D + c1) * S1 + lane];  // (the row table is padded by 64 entries)
-    return make_uint2(x.x, x.y);
-  };
-  AcBitReader br;
-  br.start(in, insz, 2, lane);
-  // State: lo, M = hi - lo + 1 (0 stands for 2^32) and v = code - lo, all modulo 2^32 -- what the encoder's plain step carries
-  // (acl_step_plain), plus the code value as an offset.  Renormalising by t bits then is lo <<= t, M = (D + 1) << t and
-  // v = ((v - B) << t) | the next t bits: an agreed leading bit leaves lo and the code register alike, and an underflow step
-  // -- lo &= 0x3FFFFFFF, code ^= 0x40000000, both shifted -- moves both by the same 2^30 (arithmetic.cpp:225-239), so their
-  // difference only ever doubles and takes in new bits.  t = clz((nlo mod 2^r) + D) as in the encoder (renorm_count); lo
-  // may keep a stray bit 31, which changes neither t nor any difference.  Valid while no context total exceeds 2^29 (the
-  // host checks): every symbol keeps an interval of two values or more.
-  u32 lo = 0, M = 0, v = br.get(32, lane);
-  u32 outacc = lane == 0 ? (insz > 0 ? (u32)in[0] : 0u) : (lane == 1 ? (insz > 1 ? (u32)in[1] : 0u) : 0u);
-  u32 q0 = rank_of(p0), q1 = rank_of(p1);
-  uint2 e = fetch(p0, p1, q0, q1);
-  for (u32 i = 2; i < n; i++) {
-    u32 sidx, qn;
-    // U[l] = floor(M * g[l] / 2^64): what symbol l's upper bound adds to lo (M = 0, the full range, goes the generic way)
-    const u32 U = (u32)(((u64)M * e.y + __umulhi(M, e.x)) >> 32);
-    const u64 m = __ballot(v < U) & span;
-    const u32 j = m ? (u32)__builtin_ctzll(m) : 0u;  // first symbol whose upper bound lies above the code value
-    uint2 e_next;
-    if (__builtin_expect(M != 0u && j != 0u, 1)) {
-      sidx = a.smin - 1u + j;
-      const u32 A = __builtin_amdgcn_readlane(U, j);
-      const u32 B = __builtin_amdgcn_readlane(U, j - 1u);
-      qn = __builtin_amdgcn_readlane(my_rank, j);
-      p0 = p1; p1 = sidx; q0 = q1; q1 = qn;
-      e_next = fetch(p0, p1, q0, q1);  // the next context is known: ask for its row before anything else
-      const u32 nlo = lo + B, D = A - 1u - B;
-      const u32 t = renorm_count(nlo, D);
-      M = (D + 1u) << t;
-      lo = nlo << t;
-      v = ((v - B) << t) | br.get0(t, lane);
-    } else {
-      // below or above the symbols the compact rows hold, the last symbol of a context, the full range: the full row, on
-      // the reference's own registers (lo without the stray bit, hi, code)
-      if (M == 0u) lo = 0u;
-      else if ((u32)(lo + M - 1u) < lo) lo ^= 0x80000000u;
-      u32 hi = lo + M - 1u, code = lo + v;
-      const u32 R = hi - lo, vv = code - lo;
-      bool is_last = false;
-      u32 A, B;
-      const uint4 *row = a.d.tab + (u64)(p0 * AC_D + p1) * AC_D;
-      const uint4 f0 = row[lane];
-      const uint4 f1 = lane < 16 ? row[64 + lane] : make_uint4(0, 0, 0, 0);
-      const bool last0 = f0.w == 0xFFFFFFFFu, last1 = f1.w == 0xFFFFFFFFu;
-      const u32 U0 = mulfrac(R, f0.z, f0.w), U1 = mulfrac(R, f1.z, f1.w);
-      const u64 m0 = __ballot(last0 || vv < U0);
-      const u64 m1 = __ballot(lane < 16 && (last1 || vv < U1));
-      if (m0) {
-        sidx = (u32)__ffsll((long long)m0) - 1;
-        A = __builtin_amdgcn_readlane(U0, sidx);
-        is_last = __builtin_amdgcn_readlane((u32)last0, sidx) != 0;
-        B = sidx ? __builtin_amdgcn_readlane(U0, sidx - 1) : 0u;
-      } else {
-        const u32 t = m1 ? (u32)__ffsll((long long)m1) - 1 : 15u;  // corrupt stream: last symbol
-        sidx = 64 + t;
-        A = __builtin_amdgcn_readlane(U1, t);
-        is_last = __builtin_amdgcn_readlane((u32)last1, t) != 0;
-        B = t ? __builtin_amdgcn_readlane(U1, t - 1) : __builtin_amdgcn_readlane(U0, 63);
-      }
-      qn = rank_of(sidx);
-      p0 = p1; p1 = sidx; q0 = q1; q1 = qn;
-      e_next = fetch(p0, p1, q0, q1);
-      ac_dec_renorm(lo, hi, code, lo + B, is_last ? hi : lo + A - 1, br, lane);
-      M = hi - lo + 1u;
-      v = code - lo;
-    }
-    outacc = ((u32)lane == (i & 63)) ? sidx : outacc;
-    if (__builtin_expect((i & 63) == 63, 0)) out[(i & ~63u) + lane] = (u8)outacc;
-    e = e_next;
-  }
-  const u32 done = n & ~63u;
-  if ((n & 63) && (u32)lane < (n & 63)) out[done + lane] = (u8)outacc;
-}
 
 // ---- decoder, the loop written for the scalar unit (round 4): ac_decode_lean_k in ~45 instructions per symbol --------
 // ac_decode_lean_k's loop is ~80 instructions as the compiler emits it (230 ns per symbol: a lone wavefront issues one

@@ -398,110 +398,6 @@ struct IngestArgs {
   u64 *consumed;             // text offset behind the last record taken
   u32 *slow;                 // set when a record does not fit the overlap
 };
-__global__ __launch_bounds__(ING_THREADS) void ingest_tiles_k(IngestArgs a) {
-  __shared__ __attribute__((aligned(16))) u8 text[ING_TILE + ING_OVER + 32];
-  __shared__ u16 nl[ING_NLMAX];
-  __shared__ __attribute__((aligned(16))) u8 qt[ING_QCAP];
-  __shared__ u8 lut[128];
-  __shared__ u32 sm[ING_THREADS / 64];
-  __shared__ u32 s_count[2];
-  const int tid = threadIdx.x;
-  const u64 t0 = (u64)blockIdx.x * ING_TILE;                       // text offset of the tile
-  const u64 avail = a.u.nbytes - t0;
-  const u32 len = (u32)(avail < ING_TILE + ING_OVER ? avail : ING_TILE + ING_OVER);
-  if (tid < 128) lut[tid] = a.u.qlut[tid];
-  for (u32 i = (u32)tid * 16; i < len + 8; i += ING_THREADS * 16) {
-    uint4 v;
-    if (t0 + i + 16 <= a.u.nbytes) v = *reinterpret_cast<const uint4 *>(a.u.text + t0 + i);
-    else {
-      u32 w[4] = {0, 0, 0, 0};
-      for (int k = 0; k < 16; k++)
-        if (t0 + i + k < a.u.nbytes) w[k >> 2] |= (u32)a.u.text[t0 + i + k] << (8 * (k & 3));
-      v = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    *reinterpret_cast<uint4 *>(text + i) = v;
-  }
-  __syncthreads();
-  // newline positions, in order: the tile proper (chunk = 64 bytes per thread), then the overlap (first 16 threads)
-  u32 base = 0;
-  for (int part = 0; part < 2; part++) {
-    const u32 off = part ? ING_TILE + (u32)tid * 64 : (u32)tid * 64;
-    u64 m = 0;
-    if ((part == 0 || tid < (int)(ING_OVER / 64)) && off < len) {
-      const uint4 *p = reinterpret_cast<const uint4 *>(text + off);
-#pragma unroll
-      for (int c = 0; c < 4; c++) m |= (u64)newline_mask16(p[c]) << (16 * c);
-      if (off + 64 > len) m &= (len - off >= 64) ? ~0ull : ((1ull << (len - off)) - 1);
-    }
-    u32 tot;
-    u32 at = base + block_exclusive_sum<u32, ING_THREADS / 64>((u32)__popcll(m), &tot, sm);
-    while (m) {
-      const int bpos = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      if (at < ING_NLMAX) nl[at] = (u16)(off + bpos);
-      at++;
-    }
-    base += tot;
-  }
-  if (tid == 0) { s_count[0] = base; }
-  __syncthreads();
-  const u32 count = s_count[0];
-  if (count > ING_NLMAX) { if (tid == 0) atomicExch(a.slow, 1u); return; }
-  // lines: the line that ends at nl[j] is line G0 + j of the text; it starts in this tile iff j > 0 or the tile begins a line
-  const u64 G0 = a.tile_base[(u64)blockIdx.x * (ING_TILE / IDX_TILE)];
-  const bool starts_line = t0 == 0 || a.u.text[t0 - 1] == '\n';
-  const u32 jmin = starts_line ? 0u : 1u;
-  u32 j0 = jmin + (u32)((4 - ((G0 + jmin) & 3)) & 3);               // first name line that starts here
-  const u64 rid0 = (G0 + j0) >> 2;
-  // candidates: name lines that END in tile + overlap; kept below only if they START in the tile proper and are whole
-  const u32 nloc = j0 < count ? (count - j0 + 3) / 4 : 0u;
-  // every thread filters its own record; the q tile needs the number of records taken: count them with a ballot scan
-  const int lane_rec = tid & (ING_HALF - 1);
-  const bool second = tid >= ING_HALF;
-  for (u32 k0 = 0; k0 < nloc; k0 += ING_HALF) {
-    const u32 k = k0 + (u32)lane_rec;
-    const u32 j = j0 + 4 * k;
-    const u64 rid = rid0 + k;
-    bool take = k < nloc && rid < a.u.nrec;
-    u32 ns = 0;
-    if (take) {
-      ns = j ? (u32)nl[j - 1] + 1 : 0u;
-      if (j && j - 1 >= count) take = false;
-      else if (ns >= ING_TILE) take = false;                        // starts in the next tile: that workgroup's record
-    }
-    if (take && j + 3 >= count) {                                   // its four lines must end inside tile + overlap
-      take = false;
-      if (!second) atomicExch(a.slow, 1u);
-    }
-    if (take) {
-      u8 *qrow = qt + (size_t)(k - k0) * a.u.L;
-      const bool al = ((a.u.L & 3) == 0);
-      auto w_lds = [&](u64 at) { return *reinterpret_cast<const u32 *>(text + ((at & ~3ull) - t0)); };
-      auto b_lds = [&](u64 at) { return text[at - t0]; };
-      const u64 p0 = t0 + nl[j], p1 = t0 + nl[j + 1], p2 = t0 + nl[j + 2], p3 = t0 + nl[j + 3];
-      if (second) unpack_record_at<2>(a.u, rid, t0 + ns, p0, p1, p2, p3, lut, w_lds, b_lds, qrow, al);
-      else {
-        unpack_record_at<1>(a.u, rid, t0 + ns, p0, p1, p2, p3, lut, w_lds, b_lds, qrow, al);
-        if (rid + 1 == a.u.nrec) *a.consumed = p3 + 1;
-      }
-    }
-    // records taken in this round are consecutive from k0 on: their q' rows are one contiguous range of the output
-    const u32 ntaken = __syncthreads_count(take && !second);
-    if (ntaken) {
-      const u64 qbytes = (u64)ntaken * a.u.L;
-      u8 *qdst = a.u.q + (rid0 + k0) * (u64)a.u.L;
-      if ((((u64)qdst) & 15) == 0) {
-        for (u64 i = (u64)tid * 16; i < qbytes; i += (u64)ING_THREADS * 16) {
-          if (i + 16 <= qbytes) *reinterpret_cast<uint4 *>(qdst + i) = *reinterpret_cast<const uint4 *>(qt + i);
-          else for (u64 x = i; x < qbytes; x++) qdst[x] = qt[x];
-        }
-      } else {
-        for (u64 i = tid; i < qbytes; i += ING_THREADS) qdst[i] = qt[i];
-      }
-    }
-    __syncthreads();
-  }
-}
 
 // The same pass with the unpack spread over all lanes.  ingest_tiles_k gives a record to two threads that walk its 4-byte
 // groups one after the other: a 16 KB tile holds ~70 records of 100 bp, so 140 of the 256 threads run 25-step loops while

@@ -116,40 +116,6 @@ struct KmerTables {  // views of the 52 KB block in LDS
     return (e & 0x7FFFu) | ((e >> 15) << 31);
   }
 };
-__global__ __launch_bounds__(TOK_THREADS) void tokenize_kmer_k(TokArgs a) {
-  __shared__ u32 tab[KMER_WORDS];
-  for (u32 i = threadIdx.x; i < KMER_WORDS; i += TOK_THREADS) tab[i] = a.kmer[i];
-  __syncthreads();
-  KmerTables km;
-  km.bind(tab, a.id8_first);
-  const u64 r = (u64)blockIdx.x * TOK_THREADS + threadIdx.x;
-  if (r >= a.nrec) return;
-  const u32 *row = reinterpret_cast<const u32 *>(a.packed + r * (u64)a.stride);
-  u32 state = 0, best_lv = 0, best_b = a.root_bucket, best_pos = 0, hits = 0, tie = 0, code = 0;
-  const int nw = (a.L + 15) >> 4;
-  for (int w = 0; w < nw; w++) {
-    const u32 word = row[w];
-    const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
-    for (int k = 0; k < cnt; k++) {
-      const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
-      code = ((code << 2) | c) & 0xFFFFu;  // the last 8 bases, the oldest one in the top bits
-      const u32 t = km.step(reinterpret_cast<const u32 *>(a.next), state, c, code, 16 * w + k);
-      state = t & 0x7FFFFFFFu;
-      if (t >> 31) {
-        const u32 info = a.outinfo[state];
-        const u32 lv = info >> kLevelShiftD, b = info & kBucketMaskD;
-        if (lv > best_lv) {
-          best_lv = lv; best_b = b; best_pos = 16 * w + k; hits = 1; tie = 0;
-        } else if (lv == best_lv) {
-          hits++;
-          if (b != best_b) tie = 1;
-        }
-      }
-    }
-  }
-  a.tok_bucket[r] = best_b;
-  a.tok_pos[r] = best_pos | ((hits > 0x7FFF ? 0x7FFFu : hits) << 16) | (tie << 31);
-}
 
 // tokenize_kmer_k is bound by instruction issue (44 per base at 50 M x 100 bp): the lanes of a wave diverge over its four
 // ways to a transition (global row, 8-mer bit table, rank, 7-mer table) and the compiler walks them one after the other,

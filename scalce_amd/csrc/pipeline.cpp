@@ -25,7 +25,7 @@ struct scalce_pipeline {
   std::vector<scalce_batch *> b;
   int G = 1;
   bool external = false;  // shards arrive with their coder prepared / enqueued by the caller (sharded runs)
-  hipStream_t front = nullptr, side = nullptr;
+  hipStream_t front = nullptr;
   std::vector<hipStream_t> coders;
   hipEvent_t ev_front = nullptr;      // coder streams wait for the front stages through it
   std::vector<hipEvent_t> ev;         // per slot: behind its coder launch
@@ -78,7 +78,6 @@ extern "C" int scalce_pipeline_create(scalce_batch **batches, int nslots, int gr
   p->ev.assign(nslots, nullptr);
   PL_HIP(p, hipGetDevice(&p->device));
   PL_HIP(p, hipStreamCreateWithFlags(&p->front, hipStreamNonBlocking));
-  PL_HIP(p, hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
   for (int i = 0; i < coder_streams; i++) {
     hipStream_t s;
     PL_HIP(p, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -95,13 +94,11 @@ extern "C" void scalce_pipeline_destroy(scalce_pipeline *p) {
   if (p->ev_front) hipEventDestroy(p->ev_front);
   for (hipStream_t s : p->coders) if (s) hipStreamDestroy(s);
   if (p->front) hipStreamDestroy(p->front);
-  if (p->side) hipStreamDestroy(p->side);
   delete p;
 }
 
 extern "C" const char *scalce_pipeline_error(const scalce_pipeline *p) { return p ? p->err.c_str() : "no pipeline"; }
 extern "C" void *scalce_pipeline_front_stream(scalce_pipeline *p) { return p ? p->front : nullptr; }
-extern "C" void *scalce_pipeline_side_stream(scalce_pipeline *p) { return p ? p->side : nullptr; }
 extern "C" void *scalce_pipeline_coder_stream(scalce_pipeline *p, int i) {
   return p && i >= 0 && i < (int)p->coders.size() ? p->coders[i] : nullptr;
 }

@@ -283,59 +283,6 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_key_k(const u64 *keys, 
     if (tile0 + j < ntiles) hist[(u64)d * ntiles + tile0 + j] = h[j][d];
   }
 }
-__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kv_k(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out,
-                                                                u32 n, u32 shift, const u32 *offs, u32 ntiles) {
-  __shared__ u32 wh[4][256];
-  for (int i = threadIdx.x; i < 4 * 256; i += RS_THREADS) (&wh[0][0])[i] = 0;
-  __syncthreads();
-  const int w = wave_id(), lane = lane_id();
-  const u64 lt = (1ull << lane) - 1;
-  const u32 base = blockIdx.x * RS_TILE + w * (64 * RS_ITEMS);
-  u64 key[RS_ITEMS];
-  u32 val[RS_ITEMS], pos[RS_ITEMS];
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++) {
-    const u32 idx = base + r * 64 + lane;
-    const bool valid = idx < n;
-    key[r] = valid ? keys_in[idx] : 0ull;
-    val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
-    const u32 d = (u32)(key[r] >> shift) & 0xFFu;
-    u64 peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const bool bit = (d >> b) & 1;
-      const u64 bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
-    }
-    const u32 rank = __popcll(peers & lt);
-    u32 pre = 0;
-    if (valid && rank == 0) {
-      pre = wh[w][d];
-      wh[w][d] = pre + (u32)__popcll(peers);
-    }
-    const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
-    pre = __shfl(pre, leader, 64);
-    pos[r] = valid ? ((d << 16) | (pre + rank)) : 0xFFFFFFFFu;
-  }
-  __syncthreads();
-  {
-    const u32 d = threadIdx.x;
-    const u32 c0 = wh[0][d], c1 = wh[1][d], c2 = wh[2][d];
-    const u32 g = offs[(u64)d * ntiles + blockIdx.x];
-    wh[0][d] = g;
-    wh[1][d] = g + c0;
-    wh[2][d] = g + c0 + c1;
-    wh[3][d] = g + c0 + c1 + c2;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < RS_ITEMS; r++)
-    if (pos[r] != 0xFFFFFFFFu) {
-      const u32 at = wh[w][pos[r] >> 16] + (pos[r] & 0xFFFFu);
-      keys_out[at] = key[r];
-      vals_out[at] = val[r];
-    }
-}
 // vals_in == nullptr means the identity permutation
 // The same scatter through LDS: the tile's pairs are first put in digit order in LDS, then leave in that order, so that a
 // wavefront's store instruction covers a few runs of consecutive addresses (8 pairs per digit and tile on average) instead
@@ -430,11 +377,7 @@ inline void radix_pass_kv(const u64 *keys_in, const u32 *vals_in, u64 *keys_out,
   const u32 ntiles = (n + RS_TILE - 1) / RS_TILE;
   hipLaunchKernelGGL(radix_hist_key_k, dim3((ntiles + RH_TILES - 1) / RH_TILES), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
   exclusive_scan<u32>(LoadAs<u32, u32>{hist_ws}, (u64)256 * ntiles, StoreTo<u32>{hist_ws}, tile_ws, (u32 *)nullptr, st);
-  static const bool direct = getenv("SCALCE_RADIX_DIRECT") != nullptr;
-  if (!direct) hipLaunchKernelGGL(radix_scatter_kv_staged_k, dim3(ntiles), dim3(RSK_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
-                                  hist_ws, ntiles);
-  else
-  hipLaunchKernelGGL(radix_scatter_kv_k, dim3(ntiles), dim3(RS_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+  hipLaunchKernelGGL(radix_scatter_kv_staged_k, dim3(ntiles), dim3(RSK_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
                      hist_ws, ntiles);
 }
 

@@ -137,7 +137,7 @@ static int upload_tables(scalce_ctx *c) {
         if (depth[t] < 0) { depth[t] = depth[st] + 1; code[t] = (code[st] << 2) | ch; order.push_back(t); }
       }
     }
-    bool ok = order.size() == ns && !getenv("SCALCE_TOKENIZE_WALK");
+    bool ok = order.size() == ns;
     u32 id8 = ns, n8 = 0;
     for (u32 st = 0; st < ns && ok; st++) {  // ids are BFS ranks: depth must not decrease with the id
       if (st && depth[st] < depth[st - 1]) ok = false;
@@ -181,11 +181,10 @@ static int upload_tables(scalce_ctx *c) {
     }
     // Anchor tables (tokenize_anchor_k): a table whose shallow part does not fit the k-mer tables above -- thousands of
     // 8-mers are fine, a million cores of 12-32 bases are not -- is searched from the occurrences' starts instead of by
-    // walking the automaton.  K = min(shortest core, 12); SCALCE_TOK_ANCHOR=1 forces it on any table with cores of 6 bases
-    // and more (tests), SCALCE_TOK_NO_ANCHOR=1 keeps the walk.
+    // walking the automaton.  K = min(shortest core, 12).
     // (the k-mer tables only shortcut transitions out of states of depth <= 7: with 400 000 states and more most of the walk
     //  is deeper than that, whether the tables could be built or not)
-    const bool want = (getenv("SCALCE_TOK_ANCHOR") != nullptr || ns > 400000u) && !getenv("SCALCE_TOK_NO_ANCHOR");
+    const bool want = ns > 400000u;
     if (want && order.size() == ns && A.min_level >= 6 && A.n_buckets > 0) {
       const u32 K = (u32)std::min(A.min_level, 12);
       const size_t nbits = (size_t)1 << (2 * K), nwords = (nbits + 63) / 64;
@@ -404,7 +403,7 @@ struct scalce_batch {
   bool timing = false;
   float stage_ms[ST_COUNT] = {0};
   int stage_launches[ST_COUNT] = {0};
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_group = nullptr, ev_side = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_group = nullptr;
   // HIP-event pairs around every ac_encode_k launch (the dominant kernel); read by scalce_batch_kernel_ms
   bool ktiming = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
@@ -516,7 +515,6 @@ static void free_all(scalce_batch *b) {
   if (b->ac_desc_host) hipHostFree(b->ac_desc_host);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
-  if (b->ev_side) hipEventDestroy(b->ev_side);
   if (b->ev_group) hipEventDestroy(b->ev_group);
   for (auto &pr : b->kev) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
@@ -595,8 +593,7 @@ static int batch_create(scalce_ctx *c, const scalce_params *p, uint64_t max_read
   b->sz_meta = b->L[0] > 255 ? 2 : 1;  // reads.cpp:106-108
   b->qstride[0] = (u32)b->L[0];
   b->qstride[1] = (u32)b->L[1];
-  if (b->nm == 1 && (b->L[0] & 3) == 0 && b->L[0] >= 16 && b->L[0] <= 160 && !getenv("SCALCE_FUSED_ROWS_OFF") &&
-      !getenv("SCALCE_INGEST_PAIRS")) {  // (the two-threads-per-record comparison kernel writes rows back to back)
+  if (b->nm == 1 && (b->L[0] & 3) == 0 && b->L[0] >= 16 && b->L[0] <= 160) {
     b->fused = true;
     b->row_cell_off = (u32)b->L[0];   // where the packed words begin
     b->row_pwords = (u32)(b->L[0] + 15) / 16;
@@ -707,10 +704,6 @@ static int launch_failed(scalce_ctx *c) {
   g_launch_err = hipSuccess;
   return SCALCE_ERR_HIP;
 }
-static bool tok_pipelined() {  // SCALCE_TOK_PLAIN=1: the branching walk (tokenize_kmer_k), for comparisons
-  static const bool v = getenv("SCALCE_TOK_PLAIN") == nullptr;
-  return v;
-}
 static inline u32 cdiv(u64 a, u64 b) {
   const u64 q = (a + b - 1) / b;
   return q > 0x7FFFFFFFull ? 0x7FFFFFFFu : (u32)q;  // callers whose grids can get there use grid-stride kernels
@@ -754,30 +747,13 @@ static int ensure_line_index(scalce_batch *b, int mate, hipStream_t s) {
 }
 
 // the first `nrec` records of the text -> rows [base, base + nrec): 2-bit bases, q', names
-// lines_out != null: the piece has not been counted (piece_count): `nrec` is the capacity in rows, the ingest kernel finds
-// the tiles' line bases itself (ingest_tiles2_k<true>) and *lines_out / *last_out are the text's line count and last byte
-// Measured at 50 M x 100 bp (10.2 GB of text): count pass 1.7 ms + ingest 6.2 ms against 9.2 ms for the one-pass kernel -- a
-// workgroup's wait for the tiles in front of it (they publish their counts at about the same time as it does, so the sum
-// is three polling rounds away) costs more than reading the text a second time at 6 TB/s.  Off unless SCALCE_INGEST_LOOKBACK=1.
-static bool ingest_lookback_ok(const scalce_batch *b, int mate) {
-  const int L = b->L[mate];
-  return getenv("SCALCE_INGEST_LOOKBACK") && L >= 16 && L <= 160 && !getenv("SCALCE_INGEST_INDEXED") && !getenv("SCALCE_INGEST_PAIRS");
-}
-static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s, u64 *lines_out = nullptr,
-                        u8 *last_out = nullptr) {
+// (A one-pass variant -- no count pass, the tiles' line bases by decoupled look-back between the workgroups -- was byte-exact
+// and slower: 9.2 ms against 1.7 + 6.2 at 50 M x 100 bp, rounds 3-4; removed in round 5.)
+static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes, u64 nrec, hipStream_t s) {
   scalce_ctx *c = b->ctx;
   b->piece_text[mate] = d_text;
   b->line_index_ok[mate] = false;
   b->piece_consumed[mate] = 0;
-  const bool lookback = lines_out != nullptr;
-  if (lookback) {
-    *lines_out = 0;
-    *last_out = '\n';
-    if (((uintptr_t)d_text & 15) != 0) { set_err(c, "FASTQ text must be 16-byte aligned"); return SCALCE_ERR_ARG; }
-    if (nbytes > b->max_text) b->max_text = nbytes;
-    b->text_bytes[mate] = nbytes;
-    if (!nbytes) return SCALCE_OK;
-  }
   if (!nrec) return SCALCE_OK;
   UnpackArgs a;
   a.text = d_text; a.nbytes = nbytes; a.line_end = nullptr; a.nrec = nrec;
@@ -792,7 +768,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
   const bool fused_rows = b->fused && mate == 0;
   if (fused_rows) a.packed2 = a.q + b->row_cell_off;  // a copy of the packed words lies behind the row's q'
   a.qlut = b->d_qlut[mate]; a.err = b->d_err;
-  a.q_affine = getenv("SCALCE_INGEST_LUT") ? -1 : b->q_affine[mate];
+  a.q_affine = b->q_affine[mate];
   a.max_namelen = b->d_small + 16;
   u32 *slow = b->d_small + 17;
   u64 *d_consumed = b->d_small64 + 2 + mate;  // (slots 1..3 are the emit stage's, long after this)
@@ -809,10 +785,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
     ia.tile_base = b->tile[mate].as<u64>();
     ia.consumed = d_consumed;
     ia.slow = slow;
-    if (getenv("SCALCE_INGEST_PAIRS")) {  // two threads per record (comparisons)
-      if (lookback) { set_err(c, "internal: ingest path"); return SCALCE_ERR_ARG; }
-      LAUNCH(ingest_tiles_k, cdiv(nbytes, ING_TILE), ING_THREADS, 0, s, ia);
-    } else {
+    {
       const u32 ntiles2 = cdiv(nbytes, ING_TILE);
       ENSURE(b, b->tile_mm[mate], sizeof(u16) * ((size_t)ntiles2 + 8));
       Ingest2Args ga;
@@ -824,37 +797,11 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
       ga.step_kw = (u32)(ING_THREADS / W); ga.step_rw = (u32)(ING_THREADS % W);
       ga.tile_minmax = b->tile_mm[mate].as<u16>();
       ga.ticket = nullptr; ga.status = nullptr; ga.tile_base_out = nullptr;
-      if (lookback) {
-        ENSURE(b, b->tile[mate], (ntiles2 + 8) * sizeof(u64));
-        ENSURE(b, b->scan_ws, ((size_t)ntiles2 + 64) * sizeof(u64));
-        ga.ticket = b->d_small + 18;
-        ga.status = b->scan_ws.as<u64>();
-        ga.tile_base_out = b->tile[mate].as<u64>();
-        ga.i.tile_base = nullptr;
-        HIP_TRY(c, hipMemsetAsync(ga.ticket, 0, sizeof(u32), s));
-        HIP_TRY(c, hipMemsetAsync(ga.status, 0, sizeof(u64) * ntiles2, s));
-        LAUNCH(ingest_tiles2_k<true>, ntiles2, ING_THREADS, 0, s, ga);
-        HIP_TRY(c, hipMemcpyAsync(lines_out, ga.status + (ntiles2 - 1), sizeof(u64), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(last_out, d_text + nbytes - 1, 1, hipMemcpyDeviceToHost, s));
-      } else {
-        LAUNCH(ingest_tiles2_k<false>, ntiles2, ING_THREADS, 0, s, ga);
-      }
+      LAUNCH(ingest_tiles2_k<false>, ntiles2, ING_THREADS, 0, s, ga);
       b->mm_valid[mate] = true;
       b->ws->tile_mm_owner[mate] = b;
     }
     { int rc = read_u32(b, b->d_small + 16, flags, 2, s); if (rc) return rc; }
-    if (lookback) {
-      *lines_out &= LB_MASK;
-      // what the count pass would have said before anything was unpacked: the caller reports it; nothing below may run on
-      // a text that is not whole records, or on more records than the batch has rows for
-      if ((*lines_out & 3) || *last_out != '\n' || *lines_out / 4 > nrec) return SCALCE_OK;
-      nrec = *lines_out / 4;
-      a.nrec = nrec;
-      if (mate == 0) b->N = b->NP = nrec;  // (the line index and the long-name store below are sized by it)
-      else if (nrec != b->N) return SCALCE_OK;  // mates of different length: the caller's error
-      b->piece_consumed[mate] = nbytes;
-      if (!nrec) return SCALCE_OK;
-    }
     if (flags[1]) { fused = false; b->mm_valid[mate] = false; }  // a record longer than the overlap: redo the piece the indexed way
   }
   if (!fused) {
@@ -877,7 +824,7 @@ static int piece_unpack(scalce_batch *b, int mate, const u8 *d_text, u64 nbytes,
     LAUNCH(last_record_end_k, 1, 1, 0, s, a.line_end, nrec, d_consumed);
     { int rc = read_u32(b, b->d_small + 16, flags, 1, s); if (rc) return rc; }
   }
-  if (!lookback) { u64 v = 0; int rc = read_u64(b, d_consumed, &v, 1, s); if (rc) return rc; b->piece_consumed[mate] = v; }
+  { u64 v = 0; int rc = read_u64(b, d_consumed, &v, 1, s); if (rc) return rc; b->piece_consumed[mate] = v; }
   if (mate == 0 && b->p.use_names) {
     // names that do not fit their 16-byte cell go to the long-name store (input order): the text is not needed again
     const u32 maxlen = flags[0];
@@ -928,21 +875,6 @@ extern "C" int scalce_batch_ingest(scalce_batch *b, int mate, const uint8_t *d_t
   if (mate == 0) batch_restart(b);  // one piece = the whole shard
   u64 nlines = 0;
   u8 last = '\n';
-  if (ingest_lookback_ok(b, mate)) {  // one pass: the ingest kernel counts the lines of its tiles itself
-    int rc = piece_unpack(b, mate, d_text, nbytes, b->max_reads, s, &nlines, &last);
-    if (rc) return rc;
-    if ((nlines & 3) || last != '\n' || nlines / 4 > b->max_reads) HIP_TRY(c, hipMemsetAsync(b->d_err, 0, sizeof(DevErr), s));  // (what the kernel made of it)
-    if ((nlines & 3) || last != '\n') {
-      set_err(c, "(ERROR) FASTQ text has %llu lines (not a multiple of 4) or no trailing newline", (unsigned long long)nlines);
-      return SCALCE_ERR_FORMAT;
-    }
-    const u64 nrec1 = nlines / 4;
-    if (nrec1 > b->max_reads) { set_err(c, "%llu records exceed the batch capacity", (unsigned long long)nrec1); return SCALCE_ERR_CAPACITY; }
-    if (mate == 0) { b->N = b->NP = nrec1; }
-    else if (nrec1 != b->N) { set_err(c, "(ERROR) mates have different record counts"); return SCALCE_ERR_FORMAT; }
-    b->ingested[mate] = true;
-    return SCALCE_OK;
-  }
   { int rc = piece_count(b, mate, d_text, nbytes, s, &nlines, &last); if (rc) return rc; }
   HIP_TRY(c, hipStreamSynchronize(s));
   if ((nlines & 3) || last != '\n') {
@@ -1215,11 +1147,10 @@ static int first_walk(scalce_batch *b, u64 row0, u64 n, u64 tok_row0, hipStream_
     anchor_args(c, b, packed0, n, g);
     g.tok_bucket = a.tok_bucket; g.tok_pos = a.tok_pos;
     LAUNCH(tokenize_anchor_k<false>, cdiv(n, 256), 256, 0, s, g);
-  } else if (c->d_kmer && tok_pipelined()) {
+  } else if (c->d_kmer) {
     if (c->kmer_t7_out) LAUNCH(tokenize_kmer_pipe_k<true>, cdiv(n, TOKP_THREADS), TOKP_THREADS, 0, s, a);
     else LAUNCH(tokenize_kmer_pipe_k<false>, cdiv(n, TOKP_THREADS), TOKP_THREADS, 0, s, a);
   }
-  else if (c->d_kmer) LAUNCH(tokenize_kmer_k, cdiv(n, TOK_THREADS), TOK_THREADS, 0, s, a);
   else if (a.lds_states) LAUNCH(tokenize_k<true>, cdiv(n, TOK_THREADS), TOK_THREADS, sh, s, a);
   else LAUNCH(tokenize_k<false>, cdiv(n, TOK_THREADS), TOK_THREADS, 0, s, a);
   return SCALCE_OK;
@@ -1306,10 +1237,10 @@ extern "C" int scalce_batch_tokenize_begin(scalce_batch *b, void *stream) {
       g.ntie = ntie; g.tie_read = a.tie_read; g.tie_off = a.tie_off; g.bucket_level = a.bucket_level;
       g.cand_bucket = a.cand_bucket; g.cand_pos = a.cand_pos; g.tie_ncand = a.tie_ncand;
       LAUNCH(tokenize_anchor_k<true>, cdiv(ntie, 256), 256, 0, s, g);
-    } else if (c->d_kmer && tok_pipelined()) {
+    } else if (c->d_kmer) {
       if (c->kmer_t7_out) LAUNCH(tie_candidates_pipe_k<true>, cdiv(ntie, TOKP_THREADS), TOKP_THREADS, 0, s, a);
       else LAUNCH(tie_candidates_pipe_k<false>, cdiv(ntie, TOKP_THREADS), TOKP_THREADS, 0, s, a);
-    } else if (c->d_kmer) LAUNCH((tie_candidates_k<false, true>), cdiv(ntie, TOK_THREADS), TOK_THREADS, sizeof(u32) * KMER_WORDS, s, a);
+    }
     else if (a.lds_states) LAUNCH(tie_candidates_k<true>, cdiv(ntie, TOK_THREADS), TOK_THREADS, (size_t)a.lds_states * 20, s, a);
     else LAUNCH(tie_candidates_k<false>, cdiv(ntie, TOK_THREADS), TOK_THREADS, 0, s, a);
     HIP_TRY(c, hipMemsetAsync(b->choice.p, 0, sizeof(u32) * ntie, s));
@@ -1402,8 +1333,7 @@ static int tokenize_sweep_enqueue(scalce_batch *b, const uint64_t *d_prior, u32 
   a.changed = flag;
   a.dirty_in = dirty_in; a.dirty_out = dirty_out;
   {
-    static const u32 coarse_sweeps = getenv("SCALCE_JACOBI_COARSE") ? (u32)atoi(getenv("SCALCE_JACOBI_COARSE")) : 8u;
-    a.coarse = b->sweep_no < coarse_sweeps ? 1u : 0u;
+    a.coarse = b->sweep_no < 8u ? 1u : 0u;
     b->sweep_no++;
   }
   HIP_TRY(c, hipMemsetAsync(dirty_out, 0xFF, sizeof(u32) * nb1, s));
@@ -1416,22 +1346,6 @@ static int tokenize_sweep_enqueue(scalce_batch *b, const uint64_t *d_prior, u32 
 
 // One sweep with the given cross-shard prior counts (SCALCE_OUT_BUCKET_COUNTS is current when it returns).
 // *changed = 1 if any decision of THIS shard moved.
-extern "C" int scalce_batch_tokenize_sweep(scalce_batch *b, const uint64_t *d_prior, int *changed, void *stream) {
-  if (!b || !b->tok_open || !changed) return SCALCE_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  scalce_ctx *c = b->ctx;
-  HIP_TRY(c, hipSetDevice(c->device));
-  StageTimer tm(b, ST_TOKENIZE, s);
-  *changed = 0;
-  if (!b->tok_n || !b->ntie) return SCALCE_OK;
-  { int rc = tokenize_sweep_enqueue(b, d_prior, b->d_small + 4, s); if (rc) return rc; }
-  u32 ch = 0;
-  { int rc = read_u32(b, b->d_small + 4, &ch, 1, s); if (rc) return rc; }
-  b->jacobi_iters++;
-  *changed = ch ? 1 : 0;
-  return SCALCE_OK;
-}
-
 // The tie reads decided in input order by one wavefront (tie_sequential_k): what scalce_batch_tokenize falls back to when
 // the sweeps have not reached their fixed point after tie_max_sweeps() of them.  Leaves choice / chosen / G / counts as
 // the converged sweeps would.
@@ -1474,25 +1388,6 @@ static int tokenize_sequential(scalce_batch *b, const uint64_t *d_prior, hipStre
 
 // Several sweeps against the same prior counts with ONE look at their flags (a sweep behind the local fixed point changes
 // nothing and costs next to nothing; a host round trip per sweep leaves the stream idle).  *changed = 1 if any moved.
-extern "C" int scalce_batch_tokenize_sweeps(scalce_batch *b, const uint64_t *d_prior, int nsweeps, int *changed, void *stream) {
-  if (!b || !b->tok_open || !changed || nsweeps < 1 || nsweeps > 16) return SCALCE_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  scalce_ctx *c = b->ctx;
-  HIP_TRY(c, hipSetDevice(c->device));
-  StageTimer tm(b, ST_TOKENIZE, s);
-  *changed = 0;
-  if (!b->tok_n || !b->ntie) return SCALCE_OK;
-  u32 *flags = b->d_small + 32;
-  for (int i = 0; i < nsweeps; i++) { int rc = tokenize_sweep_enqueue(b, d_prior, flags + i, s); if (rc) return rc; }
-  u32 ch[16];
-  { int rc = read_u32(b, flags, ch, nsweeps, s); if (rc) return rc; }
-  for (int i = 0; i < nsweeps; i++) {
-    b->jacobi_iters++;
-    if (ch[i]) *changed = 1;
-  }
-  return SCALCE_OK;
-}
-
 extern "C" int scalce_batch_tokenize_end(scalce_batch *b, void *stream) {
   if (!b || !b->tok_open) return SCALCE_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -1572,7 +1467,9 @@ static int tokenize_windows(scalce_batch *b, const uint64_t *d_prior, bool *sett
   // batches sized for the windows still open, and the host looks at the device's state once per batch.
   const u64 budget = (u64)tie_max_sweeps() * nwin;
   // one launch per sweep (tie_window_fused_k) when a window's words and their ranks fit a workgroup's LDS
-  if (!getenv("SCALCE_TIE_TWO_LAUNCHES")) {
+  // (SCALCE_TIE_WINDOW=<reads>:two_launches: test hook -- the path of windows that do not fit)
+  const char *tw_env = getenv("SCALCE_TIE_WINDOW");
+  if (!(tw_env && strstr(tw_env, ":two_launches"))) {
     TieFusedState *fs = reinterpret_cast<TieFusedState *>(base + 2 * (u64)nb1 + 16);
     u32 *maxw_d = base + 2 * (u64)nb1 + 32;
     LAUNCH(tw_maxwin_k, cdiv(nwin, 256), 256, 0, s, nwin, nb1, cellstart, maxw_d);
@@ -1637,8 +1534,7 @@ extern "C" int scalce_batch_tokenize(scalce_batch *b, const uint64_t *d_prior, v
 }
 
 // The rest of scalce_batch_tokenize behind _begin: the tie-break of this batch on its own (fixed prior counts), then _end.
-// A caller may put other work of the shard beside it (the quality statistics on a second stream were tried: the sweeps are
-// hundreds of small launches -- but bound by the host's launch rate, not by the chip: 95.0 against 94.7 ms per shard).
+// (A caller may put other work of the shard beside it; the quality statistics on a second stream were tried twice: no gain.)
 extern "C" int scalce_batch_tokenize_settle(scalce_batch *b, const uint64_t *d_prior, void *stream) {
   if (!b || !b->tok_open) return SCALCE_ERR_ARG;
   HIP_TRY(b->ctx, hipSetDevice(b->ctx->device));
@@ -1805,7 +1701,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
   // together with thousands of chunks): every pass then reads and writes sequentially.  The index-only passes below
   // gather a digit through the index in every pass: 8 GB of sector fetches per pass at 50 M reads, and the scattered
   // accesses are what slows a coder launch running beside the order stage most (tools/coder_beside.py).
-  const bool by_pairs = two_phase && PREFIX_BITS + cbits + bits <= 64 && !getenv("SCALCE_ORDER_INDEX_ONLY");
+  const bool by_pairs = two_phase && PREFIX_BITS + cbits + bits <= 64;
   u64 *sorted_keys = nullptr;
   const u32 end_bits = (16 + PREFIX_BITS + cbits + bits <= 64) ? 16u : 0u;
   if (by_pairs) {
@@ -1865,7 +1761,7 @@ extern "C" int scalce_batch_order(scalce_batch *b, void *stream) {
       LAUNCH(run_compact_k, cdiv(N, 256), 256, 0, s, (u32)N, head, b->run_rank.as<u32>(), b->run_hcount.as<u32>(), perm1,
              b->run_items_a.as<u32>(), b->run_pos.as<u32>(), b->runid.as<u32>());
       bool small_done = false;
-      if (!getenv("SCALCE_ORDER_RUN_PASSES")) {  // runs of up to 32 members are sorted where they stand (run_small_sort_k)
+      {  // runs of up to 32 members are sorted where they stand (run_small_sort_k)
         u32 *any_large = b->d_small + 10;
         HIP_TRY(c, hipMemsetAsync(any_large, 0, sizeof(u32), s));
         LAUNCH(run_small_sort_k, cdiv(M, 256), 256, 0, s, M, b->run_pos.as<u32>(), head, (u32)N, perm1, sorted_keys, end_bits,
@@ -1921,7 +1817,7 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
     // wants, and emit_names_sorted_k then reads them in sequence (name_outlen_k + emit_names_k gathered twice)
     // (not in lean mode: a run sized for most of HBM has no 16 bytes per read to spare, and allocating and releasing
     //  3 GB costs more than the second gather)
-    const bool cells = b->namecell.p != nullptr && !b->lean && !getenv("SCALCE_EMIT_NAMES_TWO_GATHERS");
+    const bool cells = b->namecell.p != nullptr && !b->lean;
     b->names_from_sorted_cells = cells;
     if (cells) ENSURE(b, b->cell_sorted, 16 * (N + 4));
     if (N && cells) LAUNCH(name_cells_sorted_k, cdiv(N, 256), 256, 0, s, N, b->perm, b->namecell.as<u8>(), b->cell_sorted.as<u8>(), b->outlen.as<u8>());
@@ -1959,10 +1855,6 @@ extern "C" int scalce_batch_emit(scalce_batch *b, void *stream) {
       a.rmagic = ((1ull << 32) + (b->qstride[0] >> 4) - 1) / (b->qstride[0] >> 4);
       a.lmagic = ((1ull << 32) + (u32)b->L[0] - 1) / (u32)b->L[0];
       a.qs = b->qs(0).as<u8>();
-      if (const char *e = getenv("SCALCE_EMIT_ABLATE")) {  // timing experiments only: the output is wrong
-        if (strchr(e, 'q')) a.qs = nullptr;
-        if (strchr(e, 'p')) a.pwords = 0;
-      }
       const size_t rows_lds = 256 * (size_t)b->qstride[0];
       if (rows_lds > 32 * 1024)
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(emit_reads_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
@@ -2057,10 +1949,11 @@ static int ac_prepare(AcJob &j, hipStream_t s, bool framed_output = true, bool f
   j.nblk = (u32)cdiv(j.nsym, AC_BLOCK_SYMS);
   {
     u64 stride = AC_STRIDE;
-    const bool full = getenv("SCALCE_AC_FULL_STRIDE") != nullptr;
+    const char *scale_env = getenv("SCALCE_AC_STRIDE_SCALE");  // test hook: "0" = the reference's full stride, else a factor (too small on purpose)
+    const bool full = scale_env && atof(scale_env) == 0.0;
     if (!full && !full_stride && th[2]) {
       double bytes_per_symbol = (double)th[1] / 256.0 / 8.0 / (double)th[2];
-      if (const char *e = getenv("SCALCE_AC_STRIDE_SCALE")) bytes_per_symbol *= atof(e);  // test hook: too small on purpose
+      if (scale_env) bytes_per_symbol *= atof(scale_env);
       const u64 est = (u64)((double)AC_BLOCK_SYMS * bytes_per_symbol * 1.08) + 65536;
       stride = std::min<u64>(AC_STRIDE, (est + 15) & ~15ull);
     }
@@ -2105,15 +1998,6 @@ static u32 ac_lanes_used() {
   return (u32)(v < 1 || v > 64 ? 32 : v);
 }
 
-// Sets of four waves per workgroup of ac_encode_lanes_k: 2 = eight waves over 2 x lanes_used blocks on one CU -- two thirds of
-// the CU-seconds of a launch and 35 % more latency (730 against 541 ms for three shards alone).  With twelve shards in
-// flight the pipeline is bound by the latency of a launch (slots / latency), so one set is the default:
-// 111 against 87 ms per shard at the driver's 20 steps (tools/sets_bench_r4.sh).
-static int ac_lane_sets() {
-  const char *e = getenv("SCALCE_AC_SETS");
-  return e && atoi(e) == 2 ? 2 : 1;
-}
-
 // ONE launch over the blocks of all jobs.  blocks_per_wg: 1 = ac_encode_k (one job only), 4 / 8 = ac_encode_rows_k,
 // 64 = ac_encode_lanes_k (one block per lane).
 // `ps` = the stream the tables were prepared on: the block descriptors are uploaded there (never behind a coder that
@@ -2133,11 +2017,11 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
   AcEncArgs a;
   memset(&a, 0, sizeof a);
   a.slow_threshold = 32;
-  a.chain_prio = getenv("SCALCE_AC_CHAIN_PRIO") ? (u32)atoi(getenv("SCALCE_AC_CHAIN_PRIO")) : 3u;
-  a.helper_prio = getenv("SCALCE_AC_HELPER_PRIO") ? (u32)atoi(getenv("SCALCE_AC_HELPER_PRIO")) : 0u;
+  a.chain_prio = 3u;
+  a.helper_prio = 0u;
   a.test_poison = getenv("SCALCE_AC_TEST_POISON") ? (u32)atoi(getenv("SCALCE_AC_TEST_POISON")) : 0u;  // test hook
   a.inplace_shift = getenv("SCALCE_AC_INPLACE_TEST") ? 2u : 0u;  // test hook: a block coded in place catches up with its input
-  a.simd_load = getenv("SCALCE_AC_NO_ELECTION") ? nullptr : c->d_simd_load;
+  a.simd_load = c->d_simd_load;
   if (const char *e = getenv("SCALCE_AC_SLOW_THRESHOLD")) a.slow_threshold = (u32)atoi(e);  // test hook
   auto join = [&]() -> int {  // `s` continues behind everything enqueued on `ps` so far
     if (ps == s) return SCALCE_OK;
@@ -2228,21 +2112,14 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
     a.out_cap = (u32)AC_STRIDE;
     { int rc = join(); if (rc) return rc; }
     if (ke0) hipEventRecord(ke0, s);
-    const u32 nwg = cdiv(total, blocks_per_wg == 64 ? std::min<u32>(ac_lanes_used(), ac_lane_sets() == 2 ? 48u : 64u) : (u32)blocks_per_wg);  // (sets of four waves)
+    const u32 nwg = cdiv(total, blocks_per_wg == 64 ? ac_lanes_used() : (u32)blocks_per_wg);
     if (getenv("SCALCE_AC_PROF")) { HIP_TRY(c, hipMalloc(&a.prof, sizeof(u64) * 5 * (nwg + 2))); HIP_TRY(c, hipMemset(a.prof, 0, sizeof(u64) * 5 * (nwg + 2))); }
     if (blocks_per_wg == 64) {
       a.lanes_used = ac_lanes_used();
-      const int sets = ac_lane_sets();
-      a.helper_prio = getenv("SCALCE_AC_LIGHT_PRIO") ? (u32)atoi(getenv("SCALCE_AC_LIGHT_PRIO")) : 2u;
-      a.pairing = getenv("SCALCE_AC_PAIRING") ? (u32)atoi(getenv("SCALCE_AC_PAIRING")) : 0u;
-      if (sets == 2) {  // two sets of four waves per workgroup (kernels_acl.hpp): rows of 48, 40 or 32 lanes
-        if (a.lanes_used > 48) a.lanes_used = 48;
-        const u32 g = cdiv(total, 2 * a.lanes_used);
-        if (a.lanes_used > 40) LAUNCH((ac_encode_lanes_k<true, 2, 48, 3>), g, 512, 0, s, a);
-        else if (a.lanes_used > 32) LAUNCH((ac_encode_lanes_k<true, 2, 40, 4>), g, 512, 0, s, a);
-        else LAUNCH((ac_encode_lanes_k<true, 2, 32, 5>), g, 512, 0, s, a);
-      } else if (getenv("SCALCE_AC_LANES_SHARED")) LAUNCH((ac_encode_lanes_k<false, 1, 64, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);
-      else if (a.lanes_used <= 48) LAUNCH((ac_encode_lanes_k<true, 1, 48, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);  // (rows of 48: LDS for a longer staging ring)
+      // (two sets of four waves per CU -- a chain or sink sharing its SIMD with a light wave of the other set -- cost a third fewer
+      //  CU-seconds and 35 % more latency per launch: 98 against 75 ms per shard with fifteen slots, round 5; waves on shared CUs at
+      //  raised priority: +5 %, round 3.  Both removed.)
+      if (a.lanes_used <= 48) LAUNCH((ac_encode_lanes_k<true, 1, 48, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);  // (rows of 48: LDS for a longer staging ring)
       else LAUNCH((ac_encode_lanes_k<true, 1, 64, 5>), cdiv(total, a.lanes_used), 256, 0, s, a);
     } else if (blocks_per_wg == 8) {
       if (general) LAUNCH((ac_encode_rows_k<true, 8>), cdiv(total, 8), 320, 0, s, a);
@@ -2267,10 +2144,7 @@ static int ac_launch(AcJob *jobs, int njobs, int blocks_per_wg, hipStream_t s, h
 }
 
 // framing: sizes -> offsets -> [u32 size][bytes] per block, all enqueued; the total is read back by entropy_collect
-static bool frames_at_collect() {
-  static const bool v = getenv("SCALCE_AC_FRAME_BEHIND_CODER") == nullptr;
-  return v;
-}
+static bool frames_at_collect() { return true; }  // (behind the coder on its own stream: measured slower)
 static int ac_frame(AcJob &j, hipStream_t s) {
   scalce_batch *b = j.b;
   const int m = j.m;
@@ -2352,7 +2226,7 @@ static int entropy_rerun_from_text(scalce_batch *b, hipStream_t s) {
   for (int m = 0; m < 2; m++) { b->frame_deferred[m] = 0; b->ent_pending[m] = 0; b->in_place_now[m] = false; }
   b->in_place_suspended = true;
   b->reruns++;
-  int rc = scalce_batch_front(b, t1, n1, t2, n2, s, nullptr);
+  int rc = scalce_batch_front(b, t1, n1, t2, n2, s);
   if (!rc) rc = scalce_batch_entropy(b, nullptr, s);
   b->in_place_suspended = false;
   return rc;
@@ -2505,8 +2379,7 @@ extern "C" int scalce_batch_entropy_begin(scalce_batch *b, const uint32_t *d_tab
   if (!b->p.no_ac) {
     u64 blocks = 0;
     for (int m = 0; m < b->nm; m++) blocks += cdiv(N * (u64)b->L[m], AC_BLOCK_SYMS);
-    const u64 one_launch = getenv("SCALCE_AC_ONE_LAUNCH_BLOCKS") ? strtoull(getenv("SCALCE_AC_ONE_LAUNCH_BLOCKS"), nullptr, 10) : AC_WINDOW_BLOCKS;
-    if (blocks > one_launch || getenv("SCALCE_AC_WINDOWED")) return entropy_windowed(b, d_table_override, s);
+    if (blocks > AC_WINDOW_BLOCKS || getenv("SCALCE_AC_WINDOW_BLOCKS")) return entropy_windowed(b, d_table_override, s);  // (the variable: a test hook)
   }
   if (b->nm == 2 && !b->p.no_ac && ac_blocks_per_wg() == 1) {
     // paired reads: both mates' streams in ONE launch (several blocks per chain wave) instead of two launches of the
@@ -2682,34 +2555,19 @@ extern "C" int scalce_batch_compress(scalce_batch *b, const uint8_t *t1, uint64_
   return SCALCE_OK;
 }
 
-// Every stage in front of the entropy coder (ingest .. emit) of a shard that is resident as text, on `stream`.  side_stream
-// (may be NULL): the quality statistics (qualities.cpp:185-198: one pass of LDS atomics over the q' rows, 4 ms per 50 M reads)
-// run there, beside the tie-break's windows -- a few hundred launches of ~13 us each that leave most of the chip idle -- and the
-// order stage; `stream` waits for them before it returns to the caller's next call (the coder's table is built from them).
-extern "C" int scalce_batch_front(scalce_batch *b, const uint8_t *t1, uint64_t n1, const uint8_t *t2, uint64_t n2, void *stream,
-                                  void *side_stream) {
+// Every stage in front of the entropy coder (ingest .. emit) of a shard that is resident as text, on `stream`.
+// (Round 5 ran the quality statistics on a second stream beside the tie-break's windows -- a few hundred launches of ~13 us that
+// leave most of the chip idle: 73.97 against 74.04 ms per shard in the bench, as in round 3.  What the windows leave idle the coder
+// launches of the other shards in flight already use.  One stream.)
+extern "C" int scalce_batch_front(scalce_batch *b, const uint8_t *t1, uint64_t n1, const uint8_t *t2, uint64_t n2, void *stream) {
   if (!b) return SCALCE_ERR_ARG;
-  scalce_ctx *c = b->ctx;
-  hipStream_t s = (hipStream_t)stream, q = (hipStream_t)side_stream;
   int rc;
   if ((rc = scalce_batch_ingest(b, 0, t1, n1, stream))) return rc;
   if (b->nm == 2 && (rc = scalce_batch_ingest(b, 1, t2, n2, stream))) return rc;
-  if (!q || q == s || b->timing) {
-    if ((rc = scalce_batch_quality(b, stream))) return rc;
-    if ((rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
-  } else {
-    if ((rc = scalce_batch_tokenize_begin(b, stream))) return rc;   // both walks, the events: the chip is busy
-    if (!b->ev_side) HIP_TRY(c, hipEventCreateWithFlags(&b->ev_side, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(b->ev_side, s));
-    HIP_TRY(c, hipStreamWaitEvent(q, b->ev_side, 0));
-    if ((rc = scalce_batch_quality(b, side_stream))) return rc;
-    HIP_TRY(c, hipEventRecord(b->ev_side, q));
-    if ((rc = scalce_batch_tokenize_settle(b, nullptr, stream))) return rc;
-  }
+  if ((rc = scalce_batch_quality(b, stream))) return rc;
+  if ((rc = scalce_batch_tokenize(b, nullptr, stream))) return rc;
   if ((rc = scalce_batch_order(b, stream))) return rc;
-  if ((rc = scalce_batch_emit(b, stream))) return rc;
-  if (q && q != s && !b->timing) HIP_TRY(c, hipStreamWaitEvent(s, b->ev_side, 0));
-  return SCALCE_OK;
+  return scalce_batch_emit(b, stream);
 }
 
 extern "C" int scalce_batch_finish(scalce_batch *b, void *stream) {
@@ -2978,7 +2836,8 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
       if (v > 1) { smin = std::min(smin, sy); smax = std::max(smax, sy); tot[sy] += v; }
     }
   uint2 *d_rows = nullptr;
-  const bool cached = smin <= smax && smax - smin + 2 <= 64 && !getenv("SCALCE_AC_DECODE_PLAIN");
+  const char *wpb_env = getenv("SCALCE_AC_DECODE_WPB");  // test hook: chains per workgroup (2, 4, 8, 16); 0 = the plain decoder
+  const bool cached = smin <= smax && smax - smin + 2 <= 64 && !(wpb_env && atoi(wpb_env) == 0);
   if (cached) {
     AcDecCachedArgs ca;
     memset(&ca, 0, sizeof ca);
@@ -2991,7 +2850,6 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
     std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return tot[x] > tot[y]; });
     u32 W = 1;
     while (W < 32 && W < order.size() && (u64)(W + 1) * (W + 1) * ca.S1 <= AC_DEC_CACHE_ENTRIES) W++;
-    if (const char *e = getenv("SCALCE_AC_DECODE_W")) W = std::max<u32>(1, std::min<u32>(W, (u32)atoi(e)));  // (experiments: fewer contexts in LDS)
     ca.W = W;
     memset(ca.rank, 0xFF, sizeof ca.rank);
     for (u32 r = 0; r < W; r++) { ca.hot[r] = (u8)order[r]; ca.rank[order[r]] = (u8)r; }
@@ -3002,36 +2860,26 @@ extern "C" int scalce_ac_decode(scalce_ctx *c, const uint32_t *table_host, const
     // Waves of a workgroup share the LDS cache of hot rows (one workgroup per CU): two chains per workgroup keep the
     // latency of a block lowest; from 512 blocks on, eight per workgroup -- two chains per SIMD interleave their issue
     // slots -- put four times as many blocks in flight.
-    // symbol 79 in the span = rows with a "last symbol of its context" marker: the kernel with the second ballot
-    const bool fast = smax < AC_D - 1 && !getenv("SCALCE_AC_DECODE_OLD");
-    if (fast) {
+    // ONE cached decoder (round 5; rounds 2-4 kept four): ac_decode_tight_k, the loop written by hand for the scalar unit.  It
+    // needs what every table of quality strings gives -- no symbol 79 among those that occur (that symbol marks "last of its
+    // context" in the rows) and no context total above 2^29 (as for the encoder's plain step); any other table takes the plain
+    // decoder below, the reference's own loop (arithmetic.cpp:196-268) a wavefront per block.
+    u64 max_total = 0;
+    for (u32 ctx = 0; ctx < 6400; ctx++) {
+      u64 t = 0;
+      for (u32 sy = 0; sy < AC_D; sy++) t += table_host[(size_t)ctx * AC_D + sy];
+      max_total = std::max(max_total, t);
+    }
+    if (smax < AC_D - 1 && max_total <= (1ull << 29)) {
       int wpb = nblk <= 512 ? 2 : nblk <= 1024 ? 4 : nblk <= 2048 ? 8 : 16;  // 16 = four chains per SIMD: a chain issues one instruction in five cycles
-      if (const char *e = getenv("SCALCE_AC_DECODE_WPB")) wpb = atoi(e);     // (tests: the wide workgroups on a few blocks)
-      // no context total above 2^29 (as for the encoder's plain step): the kernel that carries (lo, range, code - lo)
-      u64 max_total = 0;
-      for (u32 ctx = 0; ctx < 6400; ctx++) {
-        u64 t = 0;
-        for (u32 sy = 0; sy < AC_D; sy++) t += table_host[(size_t)ctx * AC_D + sy];
-        max_total = std::max(max_total, t);
-      }
-      const bool lean = max_total <= (1ull << 29) && !getenv("SCALCE_AC_DECODE_NO_LEAN");
-      if (lean && !getenv("SCALCE_AC_DECODE_NO_TIGHT")) {  // the same step with its loop written for the scalar unit
-        if (wpb == 2) LAUNCH(ac_decode_tight_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
-        else if (wpb == 4) LAUNCH(ac_decode_tight_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
-        else if (wpb == 16) LAUNCH(ac_decode_tight_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
-        else LAUNCH(ac_decode_tight_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
-      } else if (lean) {
-        if (wpb == 2) LAUNCH(ac_decode_lean_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
-        else if (wpb == 4) LAUNCH(ac_decode_lean_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
-        else if (wpb == 16) LAUNCH(ac_decode_lean_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
-        else LAUNCH(ac_decode_lean_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
-      } else if (wpb == 2) LAUNCH(ac_decode_fast_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
-      else if (wpb == 4) LAUNCH(ac_decode_fast_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
-      else if (wpb == 16) LAUNCH(ac_decode_fast_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
-      else LAUNCH(ac_decode_fast_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
-    } else if (nblk <= 512) LAUNCH(ac_decode_cached_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
-    else if (nblk <= 1024) LAUNCH(ac_decode_cached_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
-    else LAUNCH(ac_decode_cached_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
+      if (wpb_env) wpb = atoi(wpb_env);
+      if (wpb == 2) LAUNCH(ac_decode_tight_k<2>, cdiv(nblk, 2), 128, 0, s, ca);
+      else if (wpb == 4) LAUNCH(ac_decode_tight_k<4>, cdiv(nblk, 4), 256, 0, s, ca);
+      else if (wpb == 16) LAUNCH(ac_decode_tight_k<16>, cdiv(nblk, 16), 1024, 0, s, ca);
+      else LAUNCH(ac_decode_tight_k<8>, cdiv(nblk, 8), 512, 0, s, ca);
+    } else {
+      LAUNCH(ac_decode_k, nblk, 64, 0, s, a);
+    }
   } else {
     LAUNCH(ac_decode_k, nblk, 64, 0, s, a);
   }

@@ -37,14 +37,6 @@ __global__ void add_counts_into_k(uint32_t nb1, const u64 *mine, u64 *acc) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb1) acc[b] += mine[b];
 }
-// prior[b] = reads of bucket b held by the ranks before `rank`; gathered = [world][stride] u64
-__global__ void prior_from_gathered_k(uint32_t nb1, const u64 *gathered, uint32_t stride, int rank, u64 *prior) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb1) return;
-  u64 s = 0;
-  for (int r = 0; r < rank; r++) s += gathered[(size_t)r * stride + b];
-  prior[b] = s;
-}
 __global__ void add_ones_k(u64 *table, const uint32_t *keys, uint32_t n) {
   if (threadIdx.x == 0 && blockIdx.x == 0)
     for (uint32_t i = 0; i < n; i++) table[keys[i]] += 1;
@@ -475,15 +467,13 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     // reads against them window by window (scalce_batch_tokenize_settle: the tie-break of a batch on its own, exact given its
     // prior), adds its counts and hands the sum to rank r+1.  A rank only spends its own settle; what the chain adds is a
     // start-up skew of one settle per rank in front -- with several shards in flight the ranks work on different shards.
-    // SCALCE_SHARD_TIE_ROUNDS=1 keeps the rounds (comparisons).
     {
       const uint32_t stride = nb1 + 1;
       u64 *d_msg = nullptr;  // the chain's message: [0] status of the ranks in front (0 = fine), [1 ..] their counts per bucket
       local([&] { d_msg = mem.alloc<u64>(stride); });  // (before the agree(): a rank that cannot even hold the message stops everybody there)
       local([&] { SH_RC(ctx, scalce_batch_tokenize_begin(b, s)); });
       if (W > 1) agree("tokenizer"); else if (local_err.rc) throw local_err;
-      static const bool rounds_mode = getenv("SCALCE_SHARD_TIE_ROUNDS") != nullptr;
-      if (!rounds_mode) {
+      {
         // Everything between the receive and the send runs under local(): whatever fails here -- the receive itself, a copy,
         // the settle, the counts -- this rank still SENDS (status = its error code), so the rank behind never sits in a receive
         // that nobody answers (RCCL has no timeout), and every rank reaches the agree() below and throws there together.
@@ -523,39 +513,6 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
             else if (src) local_err = Fail{std::string("scalce_comm_send (tie-break chain): ") + scalce_comm_error(comm), src};
           }
         }
-      } else {
-      u64 *d_mine = mem.alloc<u64>(stride), *d_all = mem.alloc<u64>((size_t)W * stride), *d_prior = mem.alloc<u64>(nb1);
-      u64 moved = 1;
-      std::vector<u64> flags(W);
-      for (uint32_t round = 0;; round++) {
-        SH_RC(ctx, scalce_batch_output(b, SCALCE_OUT_BUCKET_COUNTS, 0, &dp, &nb));
-        SH_HIP(hipMemcpyAsync(d_mine, dp, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, s));
-        SH_HIP(hipMemcpyAsync(d_mine + nb1, &moved, 8, hipMemcpyHostToDevice, s));
-        SH_HIP(hipStreamSynchronize(s));  // `moved` is a stack variable
-        SH_CM(comm, scalce_comm_all_gather(comm, d_mine, d_all, (size_t)stride * 8, s));
-        for (int r = 0; r < W; r++) SH_HIP(hipMemcpyAsync(&flags[r], d_all + (size_t)r * stride + nb1, 8, hipMemcpyDeviceToHost, s));
-        hipLaunchKernelGGL(prior_from_gathered_k, dim3((nb1 + 255) / 256), dim3(256), 0, s, nb1, d_all, stride, rank, d_prior);
-        SH_HIP(hipStreamSynchronize(s));
-        res->rounds = round + 1;
-        bool any = false;
-        for (int r = 0; r < W; r++) any = any || flags[r] != 0;
-        if (round > 0 && !any) break;  // a whole round with current priors on every rank and no decision moved
-        for (int r = 0; r < W; r++)
-          if (flags[r] >= 2) {  // a rank's sweeps failed: its status came with the flag
-            if (r == rank && local_err.rc) throw local_err;
-            throw Fail{"rank " + std::to_string(r) + " failed (tie-break sweeps); see its message", (int)(flags[r] - 2)};
-          }
-        moved = 0;
-        local([&] {
-          int ch = 0;
-          SH_RC(ctx, scalce_batch_tokenize_sweeps(b, reinterpret_cast<const uint64_t *>(d_prior), 4, &ch, s));
-          res->sweeps += 4;
-          if (ch) moved = 1;
-        });
-        if (local_err.rc) moved = 2 + (u64)local_err.rc;
-        if (res->rounds > total_reads + 8) throw Fail{"tie resolution did not converge", SCALCE_ERR_HIP};
-      }
-      local([&] { SH_RC(ctx, scalce_batch_tokenize_end(b, s)); });  // (its status travels with the order stage's, below)
       }
     }
     mark("tie-break");

@@ -103,7 +103,7 @@ def lib():
     L.scalce_batch_entropy_begin_group.argtypes = [C.POINTER(vp), i32, vp, vp]
     L.scalce_batch_entropy_begin_group_last.argtypes = [C.POINTER(vp), i32, vp, vp, i32]
     L.scalce_batch_compress.argtypes = [vp, vp, u64, vp, u64, vp]
-    L.scalce_batch_front.argtypes = [vp, vp, u64, vp, u64, vp, vp]
+    L.scalce_batch_front.argtypes = [vp, vp, u64, vp, u64, vp]
     L.scalce_batch_finish.argtypes = [vp, vp]
     L.scalce_batch_output.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(u64)]
     L.scalce_batch_set_frame_on_demand.argtypes = [vp, i32]
@@ -122,7 +122,6 @@ def lib():
     L.scalce_memcpy_h2d.argtypes = [vp, vp, vp, u64]
     L.scalce_memcpy_d2d.argtypes = [vp, vp, vp, u64, vp]
     L.scalce_batch_tokenize_begin.argtypes = [vp, vp]
-    L.scalce_batch_tokenize_sweep.argtypes = [vp, vp, C.POINTER(i32), vp]
     L.scalce_batch_tokenize_end.argtypes = [vp, vp]
     L.scalce_batch_tokenize_settle.argtypes = [vp, vp, vp]
     L.scalce_batch_set_chunks.argtypes = [vp, C.POINTER(u64), C.c_uint32]
@@ -460,14 +459,6 @@ class Batch:
     def tokenize_begin(self, stream=0):
         self._check(self.L.scalce_batch_tokenize_begin(self.h, stream))
 
-    def tokenize_sweep(self, d_prior_counts=None, stream=0):
-        ch = C.c_int(0)
-        self._check(self.L.scalce_batch_tokenize_sweep(self.h, d_prior_counts, C.byref(ch), stream))
-        return ch.value
-
-    def tokenize_settle(self, d_prior_counts=None, stream=0):
-        self._check(self.L.scalce_batch_tokenize_settle(self.h, d_prior_counts, stream))
-
     def tokenize_end(self, stream=0):
         self._check(self.L.scalce_batch_tokenize_end(self.h, stream))
 
@@ -500,10 +491,9 @@ class Batch:
     def entropy_stream_prepare(self, mate, d_table, d_symbols, nsym, stream=0):
         self._check(self.L.scalce_batch_entropy_stream_prepare(self.h, mate, d_table, d_symbols, int(nsym), stream))
 
-    def front(self, d_text1, n1, d_text2=None, n2=0, stream=0, side_stream=0):
-        """Every stage before the entropy coder (ingest .. emit) on `stream` (scalce_batch_front); side_stream: the quality
-        statistics run there beside the tie-break."""
-        self._check(self.L.scalce_batch_front(self.h, d_text1, int(n1), d_text2, int(n2), stream, side_stream))
+    def front(self, d_text1, n1, d_text2=None, n2=0, stream=0):
+        """Every stage before the entropy coder (ingest .. emit) on `stream` (scalce_batch_front)."""
+        self._check(self.L.scalce_batch_front(self.h, d_text1, int(n1), d_text2, int(n2), stream))
 
     def compress(self, d_text1, n1, d_text2=None, n2=0, stream=0):
         self._check(self.L.scalce_batch_compress(self.h, d_text1, int(n1), d_text2, int(n2), stream))

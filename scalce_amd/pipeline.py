@@ -37,9 +37,8 @@ class ShardPipeline:
         L.scalce_pipeline_destroy.restype = None
         L.scalce_pipeline_error.argtypes = [C.c_void_p]
         L.scalce_pipeline_error.restype = C.c_char_p
-        for f in (L.scalce_pipeline_front_stream, L.scalce_pipeline_coder_stream, L.scalce_pipeline_side_stream):
+        for f in (L.scalce_pipeline_front_stream, L.scalce_pipeline_coder_stream):
             f.restype = C.c_void_p
-        L.scalce_pipeline_side_stream.argtypes = [C.c_void_p]
         L.scalce_pipeline_front_stream.argtypes = [C.c_void_p]
         L.scalce_pipeline_coder_stream.argtypes = [C.c_void_p, C.c_int]
         L.scalce_pipeline_acquire.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -54,7 +53,6 @@ class ShardPipeline:
         self._check(rc)
         # the library's streams as torch streams (callers enqueue torch work and their own C ABI calls on them)
         self.front = torch.cuda.ExternalStream(L.scalce_pipeline_front_stream(self.h))
-        self.side = torch.cuda.ExternalStream(L.scalce_pipeline_side_stream(self.h))
         self.coders = [torch.cuda.ExternalStream(L.scalce_pipeline_coder_stream(self.h, i)) for i in range(max(1, int(coder_streams)))]
         self.coder = self.coders[0]
         self.on_retire = on_retire

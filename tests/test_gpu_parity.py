@@ -561,7 +561,7 @@ def test_decoder_compact_rows_and_lds_cache(case, ctx, monkeypatch):
         sym[100:103] = (5, 5, 70)
     table = table.reshape(-1)
     if case == "plain_kernel":
-        monkeypatch.setenv("SCALCE_AC_DECODE_PLAIN", "1")
+        monkeypatch.setenv("SCALCE_AC_DECODE_WPB", "0")
     want = O.AcStat(table).encode_stream(sym)
     b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
     d_sym = torch.from_numpy(sym).to("cuda:0")
@@ -606,8 +606,7 @@ def test_coder_block_that_outgrows_its_buffer_is_coded_again(variant, ctx, monke
     monkeypatch.setenv("SCALCE_AC_STRIDE_SCALE", "0.5")
     got = run()
     assert len(got) == len(want) and (got == want).all()
-    monkeypatch.setenv("SCALCE_AC_STRIDE_SCALE", "1.0")
-    monkeypatch.setenv("SCALCE_AC_FULL_STRIDE", "1")
+    monkeypatch.setenv("SCALCE_AC_STRIDE_SCALE", "0")   # the reference's 10 MiB per block
     got = run()
     assert len(got) == len(want) and (got == want).all()
 
@@ -791,8 +790,7 @@ def test_lanes_coder_shapes_write_the_same_bytes(ctx, monkeypatch):
     first = d_sym[:BLK].cpu().numpy()
     want0 = O.AcStat(table).encode_stream(first)
     ref = None
-    for sets, lanes, poison in (("1", "48", "0"), ("1", "64", "0"), ("2", "48", "0"), ("2", "40", "0"), ("2", "32", "7"), ("1", "40", "7")):
-        monkeypatch.setenv("SCALCE_AC_SETS", sets)
+    for sets, lanes, poison in (("1", "48", "0"), ("1", "64", "0"), ("1", "32", "0"), ("1", "32", "7"), ("1", "40", "7")):
         monkeypatch.setenv("SCALCE_AC_LANES_USED", lanes)
         monkeypatch.setenv("SCALCE_AC_TEST_POISON", poison)
         b = host.Batch(ctx, 100, max_reads=1024, max_text=1 << 20)
@@ -828,13 +826,10 @@ def test_lanes_coder_block_edges(nsym, ctx, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["indexed_kernels", "records_longer_than_the_overlap", "short_reads_L16", "tile_edges",
-                                  "tile_edges_record_pairs", "odd_length_L75", "short_reads_L16_record_pairs",
-                                  "tile_edges_lookback", "records_longer_than_the_overlap_lookback", "short_reads_L16_lookback"])
+@pytest.mark.parametrize("case", ["indexed_kernels", "records_longer_than_the_overlap", "short_reads_L16", "tile_edges", "odd_length_L75"])
 def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
     """The ingest stage reads the text once behind the newline count (ingest_tiles2_k: 16 KB tiles + 1 KB overlap in LDS,
-    the unpack dealt to the lanes word by word; lookback: no count pass, the tiles' line bases by look-back between the
-    workgroups; SCALCE_INGEST_PAIRS=1: ingest_tiles_k, two threads per record) and
+    the unpack dealt to the lanes word by word) and
     falls back to the indexed kernels (index_write_k + unpack_tiled_k) for read lengths outside 16..160 or when a record
     does not fit the overlap.  All paths, the fallback trigger, the shortest fused read length, a read length that is not
     a multiple of four and records that straddle tile boundaries in every phase against the oracle."""
@@ -846,10 +841,6 @@ def test_ingest_paths_agree(case, ctx, oracle_trie, monkeypatch):
     if case == "odd_length_L75":
         L = 75
     bases, quals = synth.reads_and_quals(n, L, seed=55, n_frac=0.004, dup_frac=0.1)
-    if case.endswith("record_pairs"):
-        monkeypatch.setenv("SCALCE_INGEST_PAIRS", "1")
-    if case.endswith("lookback"):      # no count pass in front (index_count_k): the tiles' line bases by look-back inside the ingest kernel
-        monkeypatch.setenv("SCALCE_INGEST_LOOKBACK", "1")
     if case == "indexed_kernels":
         monkeypatch.setenv("SCALCE_INGEST_INDEXED", "1")
     if case.startswith("records_longer_than_the_overlap"):   # names of up to 255 characters, repeated on the '+' line

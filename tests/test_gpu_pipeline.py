@@ -44,8 +44,7 @@ def test_pipelined_shards_equal_one_shot_compress(group, slots, shared, patterns
         for i, (t, nb, n) in enumerate(shards):
             slot, b = pipe.acquire()
             with torch.cuda.stream(pipe.front):
-                # (second pass: the quality statistics on the pipeline's side stream, beside the tie-break)
-                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream, pipe.side.cuda_stream if rep else 0)
+                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream)
             pipe.submit(slot, tag=(rep, i), flush=(i + 1 == len(shards)))
     pipe.drain()
     assert len(got) == 2 * len(shards)
@@ -101,7 +100,7 @@ def test_coding_in_place_writes_the_same_streams(bpw, overflow, patterns_blob, m
         for i, (t, nb, n) in enumerate(shards):
             slot, b = pipe.acquire()
             with torch.cuda.stream(pipe.front):
-                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream, pipe.side.cuda_stream)
+                b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream)
             pipe.submit(slot, tag=(rep, i), flush=(i + 1 == len(shards)))
     pipe.drain()
     assert len(got) == 2 * len(shards)

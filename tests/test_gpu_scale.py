@@ -63,9 +63,6 @@ def test_tie_break_windows(kind, window, monkeypatch):
     """The tie-break in windows of W tie reads (tie_window_fused_k, one launch per sweep; two_launches: tie_window_sweep_k +
     tie_window_tail_k; SCALCE_TIE_WINDOW=0: the global sweeps): windows much smaller than the input, so that hundreds of
     them hand their counts on, give the oracle's tokens on the inputs of test_tie_break_stress."""
-    if window.endswith(":two_launches"):
-        monkeypatch.setenv("SCALCE_TIE_TWO_LAUNCHES", "1")
-        window = window.split(":")[0]
     rng = np.random.default_rng(23)
     n, L = 60_000, 100
     text = {"fourmers": "\n".join("".join(x) for x in itertools.product("ACGT", repeat=4)) + "\n",

@@ -153,7 +153,6 @@ def test_windowed_coder_equals_one_launch(paired, patterns_blob, monkeypatch):
     outs = []
     for windowed in (False, True):
         if windowed:
-            monkeypatch.setenv("SCALCE_AC_WINDOWED", "1")
             monkeypatch.setenv("SCALCE_AC_WINDOW_BLOCKS", "1")
         b = host.Batch(ctx, L, n + 8, max(len(t) for t in texts) + 64, paired=paired, read_len2=L)
         b.compress(dev[0].data_ptr(), len(texts[0]), dev[1].data_ptr() if paired else None, len(texts[1]) if paired else 0)

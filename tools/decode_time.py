@@ -22,7 +22,7 @@ out = torch.zeros(nsym, dtype=torch.uint8, device=dev)
 qp, qn = b.output_ptr(host.OUT_QSTREAM, 0)
 want = torch.empty(nsym, dtype=torch.uint8, device=dev)
 ctx.copy_d2d(want.data_ptr(), qp, qn, 0)
-variants = (("tight loop (round 4)", {}), ("tight loop, 8 x 8 contexts in LDS", {"SCALCE_AC_DECODE_W": "8"}), ("tight loop, 2 x 2 contexts in LDS", {"SCALCE_AC_DECODE_W": "2"}), ("lean (compiler's loop)", {"SCALCE_AC_DECODE_NO_TIGHT": "1"}), ("plain kernel", {"SCALCE_AC_DECODE_PLAIN": "1"}))
+variants = (("tight loop (round 4)", {}), ("plain kernel", {"SCALCE_AC_DECODE_WPB": "0"}))
 if len(sys.argv) > 2:
     variants = variants[:int(sys.argv[2])]
 for name, env in variants:

@@ -8,11 +8,14 @@ both sides on the SAME file at that size and compares SHA-256 of every archive f
 
   se   : N x 100 bp single-end (default 50 M = configs[1]; the text of bench.py's shard, seed 20261003)
   pe   : P pairs x 150 bp, -r (default 30 M pairs: >= 3 chunks, factor 2)
+  lossy: M x 150 bp single-end with -p 30 (round 5; default off, 30 M: >= 3 chunks, factor 2 -- the lossy quality map of
+         qualities.cpp:117-174 and the table scaling of compress.cpp:297-313 at a size where both matter; BASELINE configs[4]'s
+         workload on one GPU)
 
   reference : oracle/_ref/ref_full compress -c no -T 1   (the reference's own objects; ~42 MB/s)
   product   : scalce_amd/bin/scalce -c no
 
-usage: tools/full_size_ref_check.py [--se N] [--pe P] [--dir /dev/shm/scalce_refcheck] [--log profiles/r04_full_size_ref_check.log]
+usage: tools/full_size_ref_check.py [--se N] [--pe P] [--lossy M] [--dir /dev/shm/scalce_refcheck] [--log profiles/r04_full_size_ref_check.log]
 Both reference runs go side by side (one thread each); a progress line a minute keeps the GPU box's watchdog quiet.
 """
 import argparse
@@ -73,6 +76,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--se", type=int, default=50_000_000)
     ap.add_argument("--pe", type=int, default=30_000_000)
+    ap.add_argument("--lossy", type=int, default=0, help="reads of the 150 bp single-end -p 30 case (0 = skip)")
     ap.add_argument("--dir", default="/dev/shm/scalce_refcheck")
     ap.add_argument("--log", default=None)
     ap.add_argument("--json", default=None, help="write the result object here as well")
@@ -102,6 +106,12 @@ def main():
             sz = gen(args.pe, 150, f1, 41, pair_suffix=1) + gen(args.pe, 150, f2, 42, pair_suffix=2)
             say(f"pe: generated {args.pe} pairs x 150 bp, {sz} bytes, {time.time() - t0:.0f} s")
             cases.append(("pe", [f1], ["-r"], sz, 2, args.pe, 150))
+        if args.lossy > 0:
+            f = os.path.join(d, "lossy_1.fq")
+            t0 = time.time()
+            sz = gen(args.lossy, 150, f, 51, pair_suffix=0)
+            say(f"lossy: generated {args.lossy} x 150 bp, {sz} bytes, {time.time() - t0:.0f} s")
+            cases.append(("lossy", [f], ["-p", "30"], sz, 1, args.lossy, 150))
         # the reference, both cases side by side
         procs = []
         for name, files, flags, sz, mates, n, L in cases:

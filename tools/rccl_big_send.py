@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Where does a large RCCL send / receive stop?  (round 4 found that a 5 GB ncclSend / ncclRecv of one rank to itself did not
-arrive whole; comm.cpp sends in pieces of 1 GiB since.)  One rank, the library's own communicator, SCALCE_COMM_PIECE set so
-large that every message goes out as ONE ncclSend / ncclRecv pair: for several sizes around 2^32 bytes, how many leading
+arrive whole; comm.cpp sends in pieces of 1 GiB since.)  One rank, the library's own communicator, its piece size raised so
+far that every message goes out as ONE ncclSend / ncclRecv pair: for several sizes around 2^32 bytes, how many leading
 bytes of the message arrived and where the first wrong byte is.
 usage (GPU box):  python tools/rccl_big_send.py"""
+import ctypes as C
 import os
 import sys
 
-os.environ["SCALCE_COMM_PIECE"] = str(1 << 40)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
@@ -18,6 +18,9 @@ from scalce_amd import host  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     comm = host.Comm(0, 1, 0, unique_id=host.Comm.unique_id())
+    comm.L.scalce_comm_set_piece_bytes.argtypes = [C.c_void_p, C.c_uint64]
+    comm.L.scalce_comm_set_piece_bytes.restype = None
+    comm.L.scalce_comm_set_piece_bytes(comm.h, 1 << 40)   # every message as ONE ncclSend / ncclRecv pair
     G = 1 << 30
     for n in (G, 2 * G - 4096, 2 * G, 2 * G + (1 << 20), 3 * G, 4 * G - 4096, 4 * G, 4 * G + (1 << 20), 5 * G + 12345):
         src = (torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 >> 7).to(torch.uint8)
