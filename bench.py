@@ -475,7 +475,7 @@ def main():
     bpw_env = int(os.environ.get("SCALCE_AC_BLOCKS_PER_WG", "0") or 0)
     nblk_launch = G * ((n * L + 10 * 1024 * 1024 - 1) // (10 * 1024 * 1024))
     kname = "ac_encode_k" if G == 1 else ("ac_encode_rows_k" if bpw_env in (4, 8) or (bpw_env == 0 and nblk_launch < 900) else "ac_encode_lanes_k")
-    tag = os.environ.get("SCALCE_PROFILE_TAG", "r04_final")
+    tag = os.environ.get("SCALCE_PROFILE_TAG", "r05_final")
     pmc = os.path.join(ROOT, "profiles", f"{tag}_bench50m_pmc_fetch_write.json")
     sqf = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq.json")
     k_traffic, step_traffic, traffic_src, instr_per_symbol, issue_src = None, None, None, None, None
