@@ -293,6 +293,7 @@ struct AnchorArgs {
   const u64 *bits;       // 4^K bits
   const u32 *rank;       // per 64-bit word: set bits in front of it
   const u32 *child;      // bit 4 s + c: transition c of state s is a trie edge
+  const uint4 *single;   // per depth-K node (index: state - idK): {length | bucket << 6, suffix lo, suffix hi, 0} of the ONE core below it, or 0
   u32 K, idK;
   const u8 *packed;
   u64 nrec;
@@ -363,7 +364,24 @@ __global__ __launch_bounds__(256) void tokenize_anchor_k(AnchorArgs a) {
       const u32 kc = kmer_at(i);
       const u64 wdk = a.bits[kc >> 6];
       // a core may start at p = i + 1 - K: down the trie along the read
-      u32 s = a.idK + a.rank[kc >> 6] + (u32)__popcll(wdk & ((1ull << (kc & 63u)) - 1ull));
+      const u32 jnode = a.rank[kc >> 6] + (u32)__popcll(wdk & ((1ull << (kc & 63u)) - 1ull));
+      const uint4 one = a.single[jnode];
+      if (one.x) {  // ONE core below this K-mer: its bases behind the K-mer against the read's, in one comparison
+        const u32 len = one.x & 63u, m = len - K;
+        if (i + m < L) {
+          bool same = true;
+          if (m) {
+            const u32 bp = 2 * (i + 1), wi = bp >> 5, sh = bp & 31u;
+            const u64 hi64 = ((u64)__builtin_bswap32(row[wi]) << 32) | __builtin_bswap32(row[wi + 1]);
+            const u64 lo = (u64)__builtin_bswap32(row[wi + 2]);   // (bits past the row's last base are shifted out below)
+            const u64 win = sh ? ((hi64 << sh) | (lo >> (32 - sh))) : hi64;   // the 32 bases from base i + 1 on
+            same = (win >> (64 - 2 * m)) == (((u64)one.z << 32) | one.y);
+          }
+          if (same) occurrence(len, one.x >> 6, i + m);
+        }
+        continue;
+      }
+      u32 s = a.idK + jnode;
       u32 d = K, pos = i;                   // depth of s, index of its last base
       bool has_out = true;                  // (the anchor's own output is not known from a transition word: look)
       for (;;) {

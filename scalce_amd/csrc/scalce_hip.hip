@@ -36,6 +36,7 @@ struct scalce_ctx {
   // anchor tables of tokenize_anchor_k (core tables too large for the k-mer tables in LDS), or null
   u64 *d_anchor_bits = nullptr;
   u32 *d_anchor_rank = nullptr, *d_child_bits = nullptr;
+  uint4 *d_anchor_single = nullptr;  // per depth-K node: the ONE core below it (length, bucket, packed suffix), or 0 = walk
   u32 anchor_K = 0, anchor_idK = 0;
 };
 
@@ -89,6 +90,8 @@ static void free_tables(scalce_ctx *c) {
   if (c->d_anchor_bits) hipFree(c->d_anchor_bits);
   if (c->d_anchor_rank) hipFree(c->d_anchor_rank);
   if (c->d_child_bits) hipFree(c->d_child_bits);
+  if (c->d_anchor_single) hipFree(c->d_anchor_single);
+  c->d_anchor_single = nullptr;
   c->d_anchor_bits = nullptr; c->d_anchor_rank = nullptr; c->d_child_bits = nullptr; c->anchor_K = 0;
   c->d_next = nullptr; c->d_outinfo = nullptr; c->d_bucket_pattern = nullptr; c->d_bucket_level = nullptr;
 }
@@ -213,6 +216,35 @@ static int upload_tables(scalce_ctx *c) {
             const u32 t = A.next[(size_t)st * 4 + ch];
             if (depth[t] == depth[st] + 1) child[((size_t)st * 4 + ch) >> 5] |= 1u << (((size_t)st * 4 + ch) & 31);
           }
+        // One probe for most anchors (round 5).  Below 97 % of the depth-K nodes of a million-core table hangs exactly ONE core,
+        // on a path without branches: for those the walk down the trie (three dependent loads per base, up to 20 bases) is one
+        // 16-byte record -- length, bucket, the bases behind the K-mer packed like the K-mer itself -- and one comparison with
+        // the read's own bits.  Any other node (branches, a core that is a prefix of another) keeps record 0 and is walked.
+        std::vector<uint4> single(nK, make_uint4(0, 0, 0, 0));
+        for (u32 j = 0; j < nK; j++) {
+          u32 st = idK + j, d = K, cores = 0, bucket = 0, len = 0;
+          u64 suf = 0;
+          bool simple = true;
+          for (;;) {
+            const u32 info = A.outinfo[st];
+            if (info != kNoOutD && (info >> kLevelShiftD) == d) { cores++; bucket = info & kBucketMaskD; len = d; }
+            u32 nch = 0, chv = 0, nxt = 0;
+            for (u32 ch = 0; ch < 4; ch++) {
+              const u32 t = A.next[(size_t)st * 4 + ch];
+              if (depth[t] == depth[st] + 1) { nch++; chv = ch; nxt = t; }
+            }
+            if (nch == 0) break;
+            if (nch > 1 || cores) { simple = false; break; }   // a branch, or a core with more cores below it
+            suf = (suf << 2) | chv;
+            st = nxt;
+            d++;
+            if (d > 44) { simple = false; break; }
+          }
+          if (simple && cores == 1 && len == d && len - K <= 32 && len < 64 && bucket < (1u << 26))
+            single[j] = make_uint4(len | (bucket << 6), (u32)suf, (u32)(suf >> 32), 0);
+        }
+        HIP_TRY(c, hipMalloc(&c->d_anchor_single, sizeof(uint4) * (size_t)nK));
+        HIP_TRY(c, hipMemcpy(c->d_anchor_single, single.data(), sizeof(uint4) * (size_t)nK, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMalloc(&c->d_anchor_bits, sizeof(u64) * nwords));
         HIP_TRY(c, hipMalloc(&c->d_anchor_rank, sizeof(u32) * nwords));
         HIP_TRY(c, hipMalloc(&c->d_child_bits, sizeof(u32) * child.size()));
@@ -1126,6 +1158,7 @@ static void anchor_args(const scalce_ctx *c, const scalce_batch *b, const u8 *pa
   memset(&a, 0, sizeof a);
   a.next = reinterpret_cast<const u32 *>(c->d_next); a.outinfo = c->d_outinfo;
   a.bits = c->d_anchor_bits; a.rank = c->d_anchor_rank; a.child = c->d_child_bits; a.K = c->anchor_K; a.idK = c->anchor_idK;
+  a.single = c->d_anchor_single;
   a.packed = packed; a.nrec = nrec; a.L = b->L[0]; a.stride = b->stride[0]; a.root_bucket = (u32)c->A.n_buckets;
   a.tok_bucket = b->tok_bucket.as<u32>(); a.tok_pos = b->tok_pos.as<u32>();
 }
