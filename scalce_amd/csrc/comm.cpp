@@ -78,7 +78,10 @@ struct ShmHeader {
   uint64_t sizes[64][64];  // all_to_all_v: sizes[src][dst]
   uint64_t box_state[64];  // point-to-point mailbox of every receiver: 0 = empty, else bytes + 1 of the message in it
 };
-constexpr size_t SHM_BOX_BYTES = 16u << 20;  // one message of up to 16 MiB per receiver (behind the slots)
+// one message per receiver (behind the slots): 64 MiB holds the tie-break chain's message of the largest core table the
+// reference's loader admits (5 M cores: 40 MB of counts, reads.cpp:336)
+constexpr size_t SHM_BOX_BYTES = 64u << 20;
+constexpr long SHM_SPINS = 6000000;          // x 100 us = ten minutes: the ranks in front may be settling 50 M-read shards
 
 }  // namespace
 
@@ -277,7 +280,7 @@ extern "C" int scalce_comm_send(scalce_comm *c, const void *d_buf, uint64_t byte
   if (bytes > SHM_BOX_BYTES) { c->err = "shm transport: point-to-point message larger than a mailbox"; return SCALCE_ERR_CAPACITY; }
   uint8_t *box = c->slots + (size_t)c->world * c->slot_bytes + (size_t)peer * SHM_BOX_BYTES;
   for (long tries = 0; __atomic_load_n(&c->hdr->box_state[peer], __ATOMIC_ACQUIRE) != 0; tries++) {
-    if (tries > 600000) { c->err = "shm transport: the receiver never emptied its mailbox"; return SCALCE_ERR_HIP; }
+    if (tries > SHM_SPINS) { c->err = "shm transport: the receiver never emptied its mailbox"; return SCALCE_ERR_HIP; }
     usleep(100);
   }
   CM_HIP(c, cm_copy(c, box, d_buf, bytes, hipMemcpyDeviceToHost, s));
@@ -296,7 +299,7 @@ extern "C" int scalce_comm_recv(scalce_comm *c, void *d_buf, uint64_t bytes, int
   uint8_t *box = c->slots + (size_t)c->world * c->slot_bytes + (size_t)c->rank * SHM_BOX_BYTES;
   uint64_t st = 0;
   for (long tries = 0; (st = __atomic_load_n(&c->hdr->box_state[c->rank], __ATOMIC_ACQUIRE)) == 0; tries++) {
-    if (tries > 600000) { c->err = "shm transport: no message arrived"; return SCALCE_ERR_HIP; }
+    if (tries > SHM_SPINS) { c->err = "shm transport: no message arrived"; return SCALCE_ERR_HIP; }
     usleep(100);
   }
   if (st - 1 != bytes) { c->err = "shm transport: a message of another size than expected"; return SCALCE_ERR_ARG; }

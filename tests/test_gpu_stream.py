@@ -217,3 +217,32 @@ def test_stream_compress_entry_point(case, patterns_blob):
     for which, m in [(host.OUT_READS, 0), (host.OUT_NAMES, 0), (host.OUT_QUAL, 0)] + ([(host.OUT_READS, 1), (host.OUT_QUAL, 1)] if paired else []):
         x, y = whole.output(which, m), b.output(which, m)
         assert len(x) == len(y) and (x == y).all(), (which, m)
+
+
+def test_reused_batch_virtual_frames_do_not_leak_into_the_windowed_path(patterns_blob, monkeypatch):
+    """a batch with frames on demand that coded a small shard through a grouped launch keeps the LAYOUT of that
+    shard's frames (frame_virtual / frame_off_host); if its next shard goes window by window (entropy_windowed writes the
+    framed stream itself) scalce_batch_qual_window / SCALCE_OUT_QUAL must not serve the stale layout."""
+    from gpu_util import device_bytes
+    ctx = host.Context(0, patterns_bin=patterns_blob)
+    L = 100
+    small = synth.fastq_bytes_fast(*synth.reads_and_quals(30_000, L, seed=81))
+    big = synth.fastq_bytes_fast(*synth.reads_and_quals(230_000, L, seed=82))
+    t_small, t_big = device_bytes(small), device_bytes(big)
+    fresh = host.Batch(ctx, L, 230_008, len(big) + 64)
+    fresh.compress(t_big.data_ptr(), len(big))
+    fresh.finish()
+    want = fresh.output(host.OUT_QUAL, 0).copy()
+    b = host.Batch(ctx, L, 230_008, len(big) + 64)
+    b.set_frame_on_demand(True)
+    b.front(t_small.data_ptr(), len(small))
+    host.entropy_begin_group([b])          # virtual frames of the small shard
+    b.finish()
+    assert len(b.output(host.OUT_QUAL, 0)) > 0
+    monkeypatch.setenv("SCALCE_AC_WINDOW_BLOCKS", "1")
+    b.compress(t_big.data_ptr(), len(big))   # three windows of one block: the framed stream is written by the windows
+    b.finish()
+    got = b.output(host.OUT_QUAL, 0)
+    assert len(got) == len(want) and (got == want).all()
+    n = b.qual_bytes(0)
+    assert n == len(want)

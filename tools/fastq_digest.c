@@ -2,7 +2,12 @@
  * step): count, sum and xor of a 64-bit hash per record.  Two files hold the same multiset of records (pairs) iff --
  * up to hash collisions -- their digests agree; used to check the decompressed output of full-size runs against the
  * input, where sorting hundreds of millions of records is not an option.
- * usage: fastq_digest FILE_1 [FILE_2]      build: gcc -O2 -msse4.2 -o fastq_digest fastq_digest.c */
+ * usage: fastq_digest FILE_1 [FILE_2]      build: gcc -O2 -msse4.2 -o fastq_digest fastq_digest.c
+ *        fastq_digest --lossy MAPFILE FILE_1   (round 5) digest of what a LOSSY archive must decode to: MAPFILE holds the
+ *        offset and the 128 values of the quality map (text: 129 integers, qualities.cpp:99-174); every record goes through
+ *        q' = map[q] - offset, an upper-case 'N' forces q' = 0 (qualities.cpp:183), a base whose q' is 0 comes back as 'N',
+ *        any other base as A C G T by getval (const.cpp:47-49: a c g t like A C G T, every other letter like A), the quality
+ *        character as q' + offset (decompress.cpp:340-355) -- the transformation the reference's own round trip applies */
 #include <nmmintrin.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -36,10 +41,20 @@ static uint64_t mix(uint64_t h, const char *s, size_t n) {
   return (a << 32) ^ b ^ (n * 0xD6E8FEB86659FD93ull);
 }
 int main(int argc, char **argv) {
-  if (argc < 2) { fprintf(stderr, "usage: fastq_digest FILE_1 [FILE_2]\n"); return 2; }
+  int lossy = 0, off = 0, map[128];
+  if (argc >= 4 && !strcmp(argv[1], "--lossy")) {
+    FILE *m = fopen(argv[2], "r");
+    if (!m || fscanf(m, "%d", &off) != 1) { fprintf(stderr, "cannot read the quality map\n"); return 2; }
+    for (int i = 0; i < 128; i++) if (fscanf(m, "%d", &map[i]) != 1) { fprintf(stderr, "short quality map\n"); return 2; }
+    fclose(m);
+    lossy = 1; argv += 2; argc -= 2;
+  }
+  if (argc < 2) { fprintf(stderr, "usage: fastq_digest [--lossy MAPFILE] FILE_1 [FILE_2]\n"); return 2; }
   Rd r[2];
   int nf = argc > 2 ? 2 : 1;
+  if (lossy && nf != 1) { fprintf(stderr, "--lossy takes one file\n"); return 2; }
   for (int i = 0; i < nf; i++) rd_open(&r[i], argv[1 + i]);
+  static char bases[1 << 16], quals[1 << 16];
   uint64_t cnt = 0, sum = 0, x = 0;
   for (;;) {
     uint64_t h = 0x243F6A8885A308D3ull;
@@ -50,6 +65,25 @@ int main(int argc, char **argv) {
         char *s = rd_line(&r[i], &n);
         if (!s) { if (l || i) { fprintf(stderr, "truncated record / mates of different length\n"); return 2; } end = 1; break; }
         if (l == 2) { s = "+\n"; n = 2; }  /* the '+' line may repeat the name: canonical form */
+        if (lossy && l == 1) {               /* held back until the quality line says which bases come back as 'N' */
+          if (n > sizeof bases) { fprintf(stderr, "line too long\n"); return 2; }
+          memcpy(bases, s, n);
+          continue;
+        }
+        if (lossy && l == 3) {
+          for (size_t k = 0; k + 1 < n; k++) {
+            int q = bases[k] == 'N' ? 0 : map[(unsigned char)s[k] & 127] - off;
+            const char c = bases[k] & 0xDF;   /* getval: only C, G, T (either case) are not 0 */
+            bases[k] = q == 0 ? 'N' : (c == 'C' || c == 'G' || c == 'T') ? c : 'A';
+            quals[k] = (char)(q + off);
+          }
+          quals[n - 1] = '\n';
+          h = mix(h, bases, n);
+          h = mix(h, "+\n", 2);
+          h = mix(h, quals, n);
+          continue;
+        }
+        if (lossy && l == 2) continue;
         h = mix(h, s, n);
       }
     if (end) break;
