@@ -351,14 +351,21 @@ def main():
                 texts[i] = None
         torch.cuda.empty_cache()
         tv0 = time.perf_counter()
+        vtrace = os.environ.get("SCALCE_VERIFY_TRACE")
+        if vtrace:
+            print("  [verify, rank %d] batches closed %.2f s after the timed loop" % (rank, time.perf_counter() - t0 - dt), file=sys.stderr, flush=True)
         mine = {"want": None, "got": None, "error": None}
         try:
             mine["want"] = verify.record_digest(texts[last_slot])
+            if vtrace:
+                print("  [verify, rank %d] input digest at %.2f s" % (rank, time.perf_counter() - tv0), file=sys.stderr, flush=True)
         except Exception as ex:  # noqa: BLE001
             mine["error"] = "input digest: " + repr(ex)[:200]
         try:   # (collective calls inside: a rank that failed above still takes part)
             back = verify.sharded_records_text(comm, ctx, batches[last_slot], state[last_slot], L, off, dev)
             mine["got"] = verify.record_digest(back)
+            if vtrace:
+                print("  [verify, rank %d] output digest at %.2f s" % (rank, time.perf_counter() - tv0), file=sys.stderr, flush=True)
             del back
         except Exception as ex:  # noqa: BLE001
             mine["error"] = (mine["error"] or "") + " decode: " + repr(ex)[:200]

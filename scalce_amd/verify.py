@@ -133,8 +133,19 @@ def sharded_records_text(comm, ctx, batch, res, read_len, phred, device):
     back.  Returns that text (uint8 device tensor); the caller sums record_digest() of it over the ranks and compares with
     the sum over the inputs -- records change owner between ranks, the multiset of the run does not."""
     import ctypes as C
+    import os
+    import sys
+    import time
 
     import torch
+    t_mark = [time.perf_counter()]
+
+    def mark(what):   # SCALCE_VERIFY_TRACE=1: where the check's time goes
+        if os.environ.get("SCALCE_VERIFY_TRACE"):
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            print("  [verify, rank %d] %-22s %8.2f s" % (comm.rank, what, now - t_mark[0]), file=sys.stderr, flush=True)
+            t_mark[0] = now
     W, rank, nb1 = comm.world, comm.rank, int(res.nb1)
     counts = np.ctypeslib.as_array(res.counts, shape=(W * nb1,)).copy().reshape(W, nb1)
     send, recv, lo, hi, psrc, pdst = host.shard_plan_blocks(W, rank, nb1, counts, read_len)
@@ -146,6 +157,7 @@ def sharded_records_text(comm, ctx, batch, res, read_len, phred, device):
     if nmine:
         p, nbytes = batch.output_ptr(host.OUT_QUAL, 0)
         ctx.ac_decode(batch.output(host.OUT_TABLE, 0, np.uint32), p, nbytes, nmine, sym.data_ptr())
+    mark("decode my blocks")
     # pieces of my range -> what every source rank sent, source-major (the layout the forward all-to-all delivered)
     recv_total = int(recv.sum())
     assert recv_total == nmine
@@ -157,11 +169,13 @@ def sharded_records_text(comm, ctx, batch, res, read_len, phred, device):
         ctx.copy_pieces(sym.data_ptr(), got.data_ptr(), src_off.data_ptr(), dst_off.data_ptr(), len(order), recv_total)
     torch.cuda.synchronize()
     del sym
+    mark("pieces out of my range")
     back = torch.empty(n_local * read_len + 64, dtype=torch.uint8, device=device)
     assert int(send.sum()) == n_local * read_len
     comm.all_to_all_v(got.data_ptr(), recv, back.data_ptr(), send)   # sizes swapped: the way back
     torch.cuda.synchronize()
     del got
+    mark("symbols back to owners")
     reads = batch.output(host.OUT_READS, 0)
     names = batch.output(host.OUT_NAMES, 0)
     L = ctx.L
@@ -172,6 +186,7 @@ def sharded_records_text(comm, ctx, batch, res, read_len, phred, device):
         ctx._check(L.scalce_fastq_records(ctx.h, read_len, 1, reads.ctypes.data, len(reads), n_local, back.data_ptr(), int(phred),
                                           names.ctypes.data, len(names), b"", 0, out.data_ptr(), cap, C.byref(nb), None, 0))
         torch.cuda.synchronize()
+    mark("records -> text")
     return out[: nb.value]
 
 
