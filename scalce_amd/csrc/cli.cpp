@@ -1148,6 +1148,9 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
         library.assign((const char *)Nn[m].v.data() + Nn[m].pos, Nn[m].v.size() - Nn[m].pos);
       }
   }
+  // A mate's text comes down and is written by a thread of its own while the next mate is read, decoded and turned into text:
+  // writing 63 GB of FASTQ per mate (200 M pairs x 150 bp) is most of the run, and the two mates are two files.
+  std::vector<std::thread> writers;
   for (int m = 0; m < nm; m++) {
     const int L = len[m];
     // qualities: arithmetic decoder on the device, or the raw q - offset bytes of a -A archive
@@ -1187,28 +1190,34 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
                                    &text_bytes, o.split ? roff.data() : nullptr, nullptr));
     hipFree(d_q);
     // the text comes down in slices through two pinned buffers while the previous slice is being written
-    Downloader down;
-    char fn[4096];
-    int part = 1;
-    auto part_name = [&](int F) {
-      if (o.out == "-") snprintf(fn, sizeof fn, "-");
-      else if (o.split) snprintf(fn, sizeof fn, "%s.%d_%d.fastq", o.out.c_str(), part, F + 1);
-      else snprintf(fn, sizeof fn, "%s_%d.fastq", o.out.c_str(), F + 1);
+    auto write_out = [&o, m, nrec, text_bytes, d_text, roff = std::move(roff)]() {
+      HIPOK(hipSetDevice(0));
+      Downloader down;
+      char fn[4096];
+      int part = 1;
+      auto part_name = [&](int F) {
+        if (o.out == "-") snprintf(fn, sizeof fn, "-");
+        else if (o.split) snprintf(fn, sizeof fn, "%s.%d_%d.fastq", o.out.c_str(), part, F + 1);
+        else snprintf(fn, sizeof fn, "%s_%d.fastq", o.out.c_str(), F + 1);
+      };
+      const uint64_t per = o.split ? (uint64_t)o.split : (nrec ? nrec : 1);
+      for (uint64_t k0 = 0; k0 < nrec || k0 == 0; k0 += per, part++) {  // decompress.cpp:276-287: a new file every -S reads
+        const uint64_t k1 = std::min<uint64_t>(nrec, k0 + per);
+        const uint64_t b0 = o.split ? roff[(size_t)k0] : 0, b1 = o.split ? roff[(size_t)k1] : text_bytes;
+        OutFile fo;
+        part_name(m);
+        fo.open(fn, false);
+        down.range_to_file(static_cast<const uint8_t *>(d_text) + b0, b1 - b0, fo);
+        fo.close();
+        LOG("Created %s with %lld reads\n", fn, (long long)(k1 - k0));
+        if (!nrec) break;
+      }
+      hipFree(d_text);
     };
-    const uint64_t per = o.split ? (uint64_t)o.split : (nrec ? nrec : 1);
-    for (uint64_t k0 = 0; k0 < nrec || k0 == 0; k0 += per, part++) {  // decompress.cpp:276-287: a new file every -S reads
-      const uint64_t k1 = std::min<uint64_t>(nrec, k0 + per);
-      const uint64_t b0 = o.split ? roff[(size_t)k0] : 0, b1 = o.split ? roff[(size_t)k1] : text_bytes;
-      OutFile fo;
-      part_name(m);
-      fo.open(fn, false);
-      down.range_to_file(static_cast<const uint8_t *>(d_text) + b0, b1 - b0, fo);
-      fo.close();
-      LOG("Created %s with %lld reads\n", fn, (long long)(k1 - k0));
-      if (!nrec) break;
-    }
-    hipFree(d_text);
+    if (nm == 2 && o.out != "-") writers.emplace_back(std::move(write_out));  // (stdout takes one mate: decompress.cpp refuses -r with "-")
+    else write_out();
   }
+  for (auto &t : writers) t.join();
   LOG("\tTime elapsed: %.2f s\n", now() - t0);
   return 0;
 }
