@@ -575,9 +575,17 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   const uint8_t magic[8] = {'s', 'c', 'a', 'l', 'c', 'e', '2', '2'};
   const bool gz = o.container == 1;
   uint64_t new_size = 0;
-  Downloader down;
   char fn[4096];
-  for (int m = 0; m < nm; m++) {
+  // the files of a mate are written by a thread of its own (paired runs: two mates, two sets of files, two threads)
+  auto per_mate = [&](auto &&body) {
+    if (nm == 1) { body(0); return; }
+    std::vector<std::thread> ts;
+    for (int m = 0; m < nm; m++) ts.emplace_back([&body, m]() { HIPOK(hipSetDevice(0)); body(m); });
+    for (auto &t : ts) t.join();
+  };
+  per_mate([&](int m) {
+    Downloader down;
+    char fn[4096];
     OutFile fR, fN;
     snprintf(fn, sizeof fn, "%s_%d.scalcer", o.out.c_str(), m + 1); fR.open(fn, gz);
     const int32_t noac = o.no_ac, len32 = p.read_len[m];
@@ -590,11 +598,13 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
     if (o.use_names) down.to_file(ctx, b, SCALCE_OUT_NAMES, 0, fN);  // mate 2 repeats mate 1's names (:450-454)
     else { const int64_t z = 0; fN.write(&z, 8); fN.write(o.library.data(), o.library.size()); }
     fN.close();
-  }
+  });
   const double t2b = now();
   SCOK(ctx, scalce_batch_finish(b, s_ent));  // the coder is through: sizes of the coded streams, device error word
   const double t2c = now();
-  for (int m = 0; m < nm; m++) {
+  per_mate([&](int m) {
+    Downloader down;
+    char fn[4096];
     OutFile fQ;
     snprintf(fn, sizeof fn, "%s_%d.scalceq", o.out.c_str(), m + 1); fQ.open(fn, o.no_ac ? gz : false);  // :249
     const int64_t phred = p.qmap[0].offset;  // mate 1's offset for both (compress.cpp:294,816-817)
@@ -607,12 +617,13 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
     }
     down.qual_to_file(ctx, b, m, fQ);
     fQ.close();
+  });
+  for (int m = 0; m < nm; m++)
     for (const char *ext : {"r", "q", "n"}) {
       snprintf(fn, sizeof fn, "%s_%d.scalce%s", o.out.c_str(), m + 1, ext);
       struct stat st;
       if (stat(fn, &st) == 0) new_size += (uint64_t)st.st_size;
     }
-  }
   hipStreamDestroy(s_ent);
   const void *dc = nullptr;
   uint64_t nc = 0;
