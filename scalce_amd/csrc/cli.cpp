@@ -18,6 +18,7 @@
 #include <sys/time.h>
 #include <zlib.h>
 #include <atomic>
+#include <memory>
 #include <thread>
 #include <algorithm>
 
@@ -276,7 +277,11 @@ static std::vector<uint8_t> fetch(scalce_ctx *ctx, scalce_batch *b, int which, i
 }
 
 // A device stream to a file: slices come down into two pinned buffers in turn, the write (or deflate) of one slice runs
-// while the next is on its way.
+// while the next is on its way.  ONE writer per file: write(2) to tmpfs moves 6 GB/s from one thread on the bench host and
+// holds the inode's lock -- four threads with a slice each and pwrite at the slices' offsets measured 0.9 s against 0.5 for
+// the 1.9 GB of a quality stream, threads copying into a shared mapping 3-4 GB/s (tools/write_bench.cpp).  The framing
+// kernel's stores into the pinned slice are not what limits the quality stream either: framed into HBM and brought down by
+// the copy engine, the same 0.5 s.
 struct Downloader {
   static constexpr size_t SLICE = 64u << 20;
   uint8_t *pin[2] = {nullptr, nullptr};
@@ -583,8 +588,10 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
     for (int m = 0; m < nm; m++) ts.emplace_back([&body, m]() { HIPOK(hipSetDevice(0)); body(m); });
     for (auto &t : ts) t.join();
   };
+  std::unique_ptr<Downloader> downs[2];  // (a mate's pinned slices serve both of its passes)
   per_mate([&](int m) {
-    Downloader down;
+    downs[m].reset(new Downloader);
+    Downloader &down = *downs[m];
     char fn[4096];
     OutFile fR, fN;
     snprintf(fn, sizeof fn, "%s_%d.scalcer", o.out.c_str(), m + 1); fR.open(fn, gz);
@@ -603,7 +610,7 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   SCOK(ctx, scalce_batch_finish(b, s_ent));  // the coder is through: sizes of the coded streams, device error word
   const double t2c = now();
   per_mate([&](int m) {
-    Downloader down;
+    Downloader &down = *downs[m];
     char fn[4096];
     OutFile fQ;
     snprintf(fn, sizeof fn, "%s_%d.scalceq", o.out.c_str(), m + 1); fQ.open(fn, o.no_ac ? gz : false);  // :249
@@ -617,7 +624,9 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
     }
     down.qual_to_file(ctx, b, m, fQ);
     fQ.close();
+    downs[m].reset();
   });
+  const double t2d = now();
   for (int m = 0; m < nm; m++)
     for (const char *ext : {"r", "q", "n"}) {
       snprintf(fn, sizeof fn, "%s_%d.scalce%s", o.out.c_str(), m + 1, ext);
@@ -639,9 +648,9 @@ static int do_compress(const Options &o, const std::vector<std::string> &files, 
   LOG("\tLossy percentage: %d\n", o.lossy);
   LOG("\tSpill chunks: %u, pieces streamed: %llu\n", st4[3], (unsigned long long)ss.rounds);
   LOG("\tTime elapsed: %.2f s (sample %.2f; stream %.2f = waiting for the reader %.2f + for uploads %.2f + ingest/count/tokenize %.2f; "
-      "order %.2f, emit %.2f; reads+names down and written beside the coder %.2f, waiting for the coder %.2f, qualities down and written %.2f)\n",
+      "order %.2f, emit %.2f; reads+names down and written beside the coder %.2f, waiting for the coder %.2f, qualities down and written %.2f, device buffers released %.2f)\n",
       t3 - t0, t1 - t0, ss.total_s - ss.order_s - ss.emit_s, ss.read_wait_s, ss.h2d_wait_s, ss.front_s, ss.order_s, ss.emit_s,
-      t2b - t2, t2c - t2b, t3 - t2c);
+      t2b - t2, t2c - t2b, t2d - t2c, t3 - t2d);
   LOG("\tOriginal size: %.2lfM, new size: %.2lfM, compression factor: %.2lf\n", original / (1024.0 * 1024.0),
       new_size / (1024.0 * 1024.0), new_size ? (double)original / (double)new_size : 0.0);
   return 0;
@@ -1162,8 +1171,12 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
   // A mate's text comes down and is written by a thread of its own while the next mate is read, decoded and turned into text:
   // writing 63 GB of FASTQ per mate (200 M pairs x 150 bp) is most of the run, and the two mates are two files.
   std::vector<std::thread> writers;
+  const double t_files = now() - t0;
+  double t_decode = 0, t_records = 0;
+  std::atomic<double> t_write{0};
   for (int m = 0; m < nm; m++) {
     const int L = len[m];
+    const double ta = now();
     // qualities: arithmetic decoder on the device, or the raw q - offset bytes of a -A archive
     void *d_q = nullptr;
     uint64_t total = 0;
@@ -1193,6 +1206,8 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
     const uint64_t cap = scalce_fastq_text_bytes(L, nrec, nbytes_names, names ? nullptr : library.c_str());
     void *d_text = nullptr;
     HIPOK(hipMalloc(&d_text, cap + 64));
+    const double tb = now();
+    t_decode += tb - ta;
     uint64_t text_bytes = 0;
     std::vector<uint64_t> roff;
     if (o.split) roff.resize((size_t)nrec + 1);
@@ -1200,8 +1215,10 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
                                    phred[m], npay, nbytes_names, library.c_str(), o.paired ? '1' + m : 0, (uint8_t *)d_text, cap,
                                    &text_bytes, o.split ? roff.data() : nullptr, nullptr));
     hipFree(d_q);
-    // the text comes down in slices through two pinned buffers while the previous slice is being written
-    auto write_out = [&o, m, nrec, text_bytes, d_text, roff = std::move(roff)]() {
+    t_records += now() - tb;
+    // the text comes down in slices through pinned buffers while the previous slices are being written
+    auto write_out = [&o, &t_write, m, nrec, text_bytes, d_text, roff = std::move(roff)]() {
+      const double tw = now();
       HIPOK(hipSetDevice(0));
       Downloader down;
       char fn[4096];
@@ -1224,12 +1241,15 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
         if (!nrec) break;
       }
       hipFree(d_text);
+      const double dt = now() - tw;
+      for (double cur = t_write.load(); !t_write.compare_exchange_weak(cur, cur + dt);) {}
     };
     if (nm == 2 && o.out != "-") writers.emplace_back(std::move(write_out));  // (stdout takes one mate: decompress.cpp refuses -r with "-")
     else write_out();
   }
   for (auto &t : writers) t.join();
-  LOG("\tTime elapsed: %.2f s\n", now() - t0);
+  LOG("\tTime elapsed: %.2f s (archive files read %.2f; qualities up and decoded %.2f; records to text %.2f; text down and written %.2f%s)\n",
+      now() - t0, t_files, t_decode, t_records, t_write.load(), nm == 2 ? ", a thread per mate beside the next mate's decode" : "");
   return 0;
 }
 

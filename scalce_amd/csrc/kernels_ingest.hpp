@@ -116,7 +116,7 @@ struct UnpackArgs {
 __device__ __forceinline__ u32 pack4(u32 v) {
   const u32 up = v & 0xDFDFDFDFu;                                // fold case
   const u32 code = ((v >> 1) ^ (v >> 2)) & 0x03030303u;          // A0 C1 G2 T3 on the letters themselves
-  u32 ok = zero_bytes(up ^ 0x43434343u) | zero_bytes(up ^ 0x47474747u) | zero_bytes(up ^ 0x54545454u);
+  u32 ok = zero_bytes((up & 0xFBFBFBFBu) ^ 0x43434343u) | zero_bytes(up ^ 0x54545454u);  // C, G (they differ in bit 2 only) | T
   ok = (ok >> 7) | (ok >> 6);                                     // 0x80 flag -> 0x03 mask per byte (no multiply: quarter rate)
   return __builtin_amdgcn_udot4(code & ok, 0x01041040u, 0u, false);  // first base x 64 + second x 16 + third x 4 + fourth
 }
@@ -411,10 +411,6 @@ struct Ingest2Args {
   u64 magic_s, magic_w;   // ceil(2^32 / S), ceil(2^32 / W): S = words per packed row, W = 16-symbol units per read
   u32 step_ks, step_rs, step_kw, step_rw;  // 256 / S, 256 % S, 256 / W, 256 % W
   u16 *tile_minmax;       // per tile: min | max << 8 of its q' symbols (255 | 0 << 8: none), or null
-  // LOOKBACK (no count pass in front): ticket counter and one status word per tile, both zeroed; the tiles' line bases out
-  u32 *ticket;
-  u64 *status;
-  u64 *tile_base_out;
 };
 constexpr u32 ING2_RECMAX = ING_NLMAX / 4 + 4;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -429,13 +425,6 @@ __device__ __forceinline__ u32 lds_fetch_u32(const u8 *text, u32 at) {  // unali
   const u32 *p = reinterpret_cast<const u32 *>(text + (at & ~3u));
   return __builtin_amdgcn_alignbyte(p[1], p[0], at & 3u);
 }
-// LOOKBACK: no count pass in front (index_count_k read the whole text once more for the tiles' line bases).  The tiles are
-// taken in ticket order; a workgroup publishes the newline count of its tile as soon as it has it and adds up what the
-// tiles in front of it have published -- their counts, down to the first one that already knows its own base (decoupled
-// look-back: one 8-byte word {state, value} per tile, written by one store, polled by wave 0, 64 tiles at a time).  A tile
-// only ever waits for tiles with smaller tickets, and those are running or done.
-constexpr u64 LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1;
-template <bool LOOKBACK>
 __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   const IngestArgs &a = g.i;
   __shared__ __attribute__((aligned(16))) u8 text[ING_TILE + ING_OVER + 32];
@@ -445,15 +434,8 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   __shared__ u32 sm[ING_THREADS / 64];
   __shared__ u32 s_count[2];
   __shared__ u32 s_mm[2 * (ING_THREADS / 64)];
-  __shared__ u64 s_g0;
-  __shared__ u32 s_ticket;
   const int tid = threadIdx.x;
-  u32 ti = blockIdx.x;                                             // the tile
-  if (LOOKBACK) {
-    if (tid == 0) s_ticket = atomicAdd(g.ticket, 1u);
-    __syncthreads();
-    ti = s_ticket;
-  }
+  const u32 ti = blockIdx.x;                                       // the tile
   const u64 t0 = (u64)ti * ING_TILE;                               // text offset of the tile
   const u64 avail = a.u.nbytes - t0;
   const u32 len = (u32)(avail < ING_TILE + ING_OVER ? avail : ING_TILE + ING_OVER);
@@ -471,60 +453,50 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
     *reinterpret_cast<uint4 *>(text + i) = v;
   }
   __syncthreads();
-  // newline positions, in order: the tile proper (chunk = 64 bytes per thread), then the overlap (first 16 threads)
-  u32 base = 0;
-  for (int part = 0; part < 2; part++) {
-    const u32 off = part ? ING_TILE + (u32)tid * 64 : (u32)tid * 64;
+  // newline positions, in order: the tile proper (chunk = 64 bytes per thread), then the overlap -- sixteen chunks, all of
+  // wave 0's, which scans them by itself (as a second round of the whole workgroup it was a seventh of the kernel's instructions)
+  u32 base;
+  {
+    const u32 off = (u32)tid * 64;
     u64 m = 0;
-    if ((part == 0 || tid < (int)(ING_OVER / 64)) && off < len) {
+    if (off < len) {
       const uint4 *p = reinterpret_cast<const uint4 *>(text + off);
 #pragma unroll
       for (int c = 0; c < 4; c++) m |= (u64)newline_mask16(p[c]) << (16 * c);
-      if (off + 64 > len) m &= (len - off >= 64) ? ~0ull : ((1ull << (len - off)) - 1);
+      if (off + 64 > len) m &= (1ull << (len - off)) - 1;
     }
-    u32 tot;
-    u32 at = base + block_exclusive_sum<u32, ING_THREADS / 64>((u32)__popcll(m), &tot, sm);
+    u32 at = block_exclusive_sum<u32, ING_THREADS / 64>((u32)__popcll(m), &base, sm);
     while (m) {
       const int bpos = __ffsll((long long)m) - 1;
       m &= m - 1;
       if (at < ING_NLMAX) nl[at] = (u16)(off + bpos);
       at++;
     }
-    base += tot;
-    if (LOOKBACK && part == 0 && wave_id() == 0) {  // the tile's own count is known: publish it, then add up the tiles in front
-      const int lane = lane_id();
-      unsigned long long *st = reinterpret_cast<unsigned long long *>(g.status);
-      u64 excl = 0;
-      if (ti == 0) {
-        if (lane == 0) __hip_atomic_store(&st[0], LB_PREFIX | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (lane == 0) __hip_atomic_store(&st[ti], LB_AGG | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (long long j = (long long)ti - 1;;) {
-          const long long idx = j - lane;
-          const u64 v = idx >= 0 ? (u64)__hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;  // in front of tile 0: nothing
-          const u64 not_ready = __ballot((v >> 62) == 0), has_prefix = __ballot((v >> 62) == 2);
-          const int first_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : 64;
-          const int first_missing = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
-          if (first_missing < first_prefix) { __builtin_amdgcn_s_sleep(2); continue; }  // a tile in front has not counted yet
-          u64 mine = lane <= first_prefix ? (v & LB_MASK) : 0ull;
-          for (int o = 32; o; o >>= 1) mine += (u64)__shfl_xor((long long)mine, o);
-          excl += mine;
-          if (first_prefix < 64) break;
-          j -= 64;
-        }
-        if (lane == 0) __hip_atomic_store(&st[ti], LB_PREFIX | (excl + (u64)tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0) {
-        s_g0 = excl;
-        g.tile_base_out[ti] = excl;   // (index_write_k wants the line bases when a name is longer than a cell)
-      }
-    }
   }
-  if (tid == 0) { s_count[0] = base; }
+  if (wave_id() == 0) {
+    const int lane = lane_id();
+    const u32 off = ING_TILE + (u32)lane * 64;
+    u64 m = 0;
+    if (lane < (int)(ING_OVER / 64) && off < len) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(text + off);
+#pragma unroll
+      for (int c = 0; c < 4; c++) m |= (u64)newline_mask16(p[c]) << (16 * c);
+      if (off + 64 > len) m &= (1ull << (len - off)) - 1;
+    }
+    const u32 cnt = (u32)__popcll(m), inc = wave_inclusive_sum(cnt);
+    u32 at = base + inc - cnt;
+    while (m) {
+      const int bpos = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      if (at < ING_NLMAX) nl[at] = (u16)(off + bpos);
+      at++;
+    }
+    if (lane == 63) s_count[0] = base + inc;
+  }
   __syncthreads();
   const u32 count = s_count[0];
   if (count > ING_NLMAX) { if (tid == 0) atomicExch(a.slow, 1u); return; }
-  const u64 G0 = LOOKBACK ? s_g0 : a.tile_base[(u64)ti * (ING_TILE / IDX_TILE)];
+  const u64 G0 = a.tile_base[(u64)ti * (ING_TILE / IDX_TILE)];
   const bool starts_line = t0 == 0 || a.u.text[t0 - 1] == '\n';
   const u32 jmin = starts_line ? 0u : 1u;
   const u32 j0 = jmin + (u32)((4 - ((G0 + jmin) & 3)) & 3);         // first name line that starts here
@@ -599,46 +571,46 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
   // Units are dealt to the threads in order, 256 apart: (record, word) of a thread's next unit follow from the last one by
   // additions (step_k, step_r = 256 / n, 256 % n from the host), and both outputs are back to back in memory -- unit u of
   // the tile is word u behind the tile's first row.
-  // bases: one unit = one word of a packed row = 16 bases (zero behind the read)
+  // bases: one unit = one word of a packed row = 16 bases (zero behind the read).  The last unit of a read is packed like
+  // the others -- the bytes behind the line (its newline, the '+' line, the first qualities: all inside the record, which ends
+  // inside tile + overlap) go through pack4 with it -- and the codes behind the read are masked off afterwards (a path of
+  // its own for that unit ran in every wave beside the common one: a wave's 64 units hold eight or nine last ones).
+  const u32 wfull = (u32)L / 16, W = ((u32)L + 15) / 16, ntail = (u32)L - 16 * wfull;  // ntail: bases / symbols of a last unit
   {
-    const u32 S = (u32)a.u.stride / 4, units = ntake * S, wfull = (u32)L / 16;
+    const u32 S = (u32)a.u.stride / 4, units = ntake * S;
+    u32 tailmask = 0;  // first base of a byte in its bits 7-6 (pack4): byte m keeps its top 2 * (ntail - 4 m) bits
+    for (u32 m = 0; m < 4; m++) {
+      const int rem = (int)ntail - 4 * (int)m;
+      if (rem > 0) tailmask |= (rem >= 4 ? 0xFFu : (0xFF00u >> (2 * rem)) & 0xFFu) << (8 * m);
+    }
     u32 k = (u32)(((u64)(u32)tid * g.magic_s) >> 32), w = (u32)tid - k * S;
     u32 *dst = reinterpret_cast<u32 *>(a.u.packed + rid0 * (u64)a.u.stride);
-    const u32 w2n = ((u32)L + 15) / 16;  // words of the copy inside the fused row
     for (u32 u = (u32)tid; u < units; u += ING_THREADS) {
       const u32 sb = rec_sb[k];
       if (sb != 0xFFFFu) {
         u32 acc = 0;
-        if (w < wfull) {  // sixteen bases of the read: five aligned words of the tile, four bytes of the row
+        if (w < W) {  // sixteen bases: five aligned words of the tile, four bytes of the row
           const u32 at = sb + 16 * w, sh = at & 3u;
           const u32 *p = reinterpret_cast<const u32 *>(text + (at & ~3u));
           const u32 d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
           acc = pack4(__builtin_amdgcn_alignbyte(d1, d0, sh)) | (pack4(__builtin_amdgcn_alignbyte(d2, d1, sh)) << 8) |
                 (pack4(__builtin_amdgcn_alignbyte(d3, d2, sh)) << 16) | (pack4(__builtin_amdgcn_alignbyte(d4, d3, sh)) << 24);
-        } else {
-          const int i0 = 16 * (int)w;
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const int i = i0 + 4 * m, rem = L - i;
-            if (rem > 0) {
-              u32 vb = lds_fetch_u32(text, sb + (u32)i);
-              if (rem < 4) vb &= (1u << (8 * rem)) - 1;             // bytes behind the line are not part of the read
-              acc |= pack4(vb) << (8 * m);
-            }
-          }
+          if (w >= wfull) acc &= tailmask;
         }
         dst[u] = acc;
-        if (a.u.packed2 && w < w2n) reinterpret_cast<u32 *>(a.u.packed2 + (rid0 + k) * (u64)a.u.qstride)[w] = acc;
+        if (a.u.packed2 && w < W) reinterpret_cast<u32 *>(a.u.packed2 + (rid0 + k) * (u64)a.u.qstride)[w] = acc;
       }
       k += g.step_ks; w += g.step_rs;
       if (w >= S) { w -= S; k++; }
     }
   }
-  // qualities: one unit = sixteen symbols (the last unit of a read: what is left); q' (qualities.cpp:183): exactly 'N' forces
-  // the offset, i.e. symbol 0
-  u32 lo_e = 0x00FF00FFu, lo_o = 0x00FF00FFu, hi_e = 0, hi_o = 0;   // smallest / largest symbol, even and odd bytes apart
+  // qualities: one unit = sixteen symbols (the last unit of a read: what is left, computed like a whole one and cut when it
+  // is stored); q' (qualities.cpp:183): exactly 'N' forces the offset, i.e. symbol 0
+  // smallest / largest symbol: packed 16-bit min / max order their halves by the HIGH byte, so a word as it is gives the
+  // range of its odd bytes and the word shifted up by one byte that of its even bytes -- no masks
+  u32 lo_e = 0xFFFFFFFFu, lo_o = 0xFFFFFFFFu, hi_e = 0, hi_o = 0;
   {
-    const u32 W = ((u32)L + 15) / 16, units = ntake * W, wfull = (u32)L / 16;
+    const u32 units = ntake * W;
     const bool al = (L & 3) == 0;
     const u32 aff = (u32)(a.u.q_affine >= 0 ? a.u.q_affine : 0) * 0x01010101u;
     u32 k = (u32)(((u64)(u32)tid * g.magic_w) >> 32), w = (u32)tid - k * W;
@@ -656,23 +628,23 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
       return ~(zN | (zN - (zN >> 7)));
     };
     auto range = [&](u32 ql, u32 qh) {  // ql: bytes that are not symbols hold 0xFF; qh: they hold 0
-      lo_e = pk_min_u16(lo_e, ql & 0x00FF00FFu); lo_o = pk_min_u16(lo_o, (ql >> 8) & 0x00FF00FFu);
-      hi_e = pk_max_u16(hi_e, qh & 0x00FF00FFu); hi_o = pk_max_u16(hi_o, (qh >> 8) & 0x00FF00FFu);
+      lo_o = pk_min_u16(lo_o, ql); lo_e = pk_min_u16(lo_e, ql << 8);
+      hi_o = pk_max_u16(hi_o, qh); hi_e = pk_max_u16(hi_e, qh << 8);
     };
     for (u32 u = (u32)tid; u < units; u += ING_THREADS) {
       const u32 sb = rec_sb[k];
       if (sb != 0xFFFFu) {
         const u32 sq = rec_sq[k];
+        const u32 ab = sb + 16 * w, aq = sq + 16 * w, shb = ab & 3u, shq = aq & 3u;
+        const u32 *pb = reinterpret_cast<const u32 *>(text + (ab & ~3u)), *pq = reinterpret_cast<const u32 *>(text + (aq & ~3u));
+        const u32 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
+        const u32 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
+        const u32 r0 = quality(__builtin_amdgcn_alignbyte(q1, q0, shq)) & not_n(__builtin_amdgcn_alignbyte(b1, b0, shb));
+        const u32 r1 = quality(__builtin_amdgcn_alignbyte(q2, q1, shq)) & not_n(__builtin_amdgcn_alignbyte(b2, b1, shb));
+        const u32 r2 = quality(__builtin_amdgcn_alignbyte(q3, q2, shq)) & not_n(__builtin_amdgcn_alignbyte(b3, b2, shb));
+        const u32 r3 = quality(__builtin_amdgcn_alignbyte(q4, q3, shq)) & not_n(__builtin_amdgcn_alignbyte(b4, b3, shb));
+        u8 *qdst = qtile + qoff;
         if (w < wfull) {
-          const u32 ab = sb + 16 * w, aq = sq + 16 * w, shb = ab & 3u, shq = aq & 3u;
-          const u32 *pb = reinterpret_cast<const u32 *>(text + (ab & ~3u)), *pq = reinterpret_cast<const u32 *>(text + (aq & ~3u));
-          const u32 b0 = pb[0], b1 = pb[1], b2 = pb[2], b3 = pb[3], b4 = pb[4];
-          const u32 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
-          const u32 r0 = quality(__builtin_amdgcn_alignbyte(q1, q0, shq)) & not_n(__builtin_amdgcn_alignbyte(b1, b0, shb));
-          const u32 r1 = quality(__builtin_amdgcn_alignbyte(q2, q1, shq)) & not_n(__builtin_amdgcn_alignbyte(b2, b1, shb));
-          const u32 r2 = quality(__builtin_amdgcn_alignbyte(q3, q2, shq)) & not_n(__builtin_amdgcn_alignbyte(b3, b2, shb));
-          const u32 r3 = quality(__builtin_amdgcn_alignbyte(q4, q3, shq)) & not_n(__builtin_amdgcn_alignbyte(b4, b3, shb));
-          u8 *qdst = qtile + qoff;
           if (al) {
             u32x4a v;
             v.x = r0; v.y = r1; v.z = r2; v.w = r3;
@@ -682,15 +654,17 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
             for (int x = 0; x < 16; x++) qdst[x] = (u8)(rr[x >> 2] >> (8 * (x & 3)));
           }
           range(r0, r0); range(r1, r1); range(r2, r2); range(r3, r3);
-        } else {
-          for (u32 i = 16 * w; i < (u32)L; i += 4) {
-            const int rem = L - (int)i;
-            const u32 keep = rem < 4 ? (1u << (8 * rem)) - 1 : 0xFFFFFFFFu;
-            const u32 qq = quality(lds_fetch_u32(text, sq + i) & keep) & not_n(lds_fetch_u32(text, sb + i) & keep) & keep;
-            u8 *qdst = qtile + qoff + (i - 16 * w);
-            if (al) *reinterpret_cast<u32 *>(qdst) = qq;
-            else for (int x = 0; x < (rem < 4 ? rem : 4); x++) qdst[x] = (u8)(qq >> (8 * x));
-            range(qq | ~keep, qq);
+        } else {  // the last unit of a read: ntail symbols (the same for every read: the trip count is the wave's)
+          const u32 rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+          for (int x = 0; x < 4; x++) {
+            const int rem = (int)ntail - 4 * x;
+            if (rem > 0) {
+              const u32 keep = rem < 4 ? (1u << (8 * rem)) - 1 : 0xFFFFFFFFu, qq = rr[x] & keep;
+              if (al) *reinterpret_cast<u32 *>(qdst + 4 * x) = qq;
+              else for (int y = 0; y < (rem < 4 ? rem : 4); y++) qdst[4 * x + y] = (u8)(qq >> (8 * y));
+              range(qq | ~keep, qq);
+            }
           }
         }
       }
@@ -698,9 +672,8 @@ __global__ __launch_bounds__(ING_THREADS) void ingest_tiles2_k(Ingest2Args g) {
       if (w >= W) { w -= W; k++; qoff += qwrap; }
     }
   }
-  u32 lo = pk_min_u16(lo_e, lo_o), hi = pk_max_u16(hi_e, hi_o);
-  lo = min(lo & 0xFFFFu, lo >> 16);
-  hi = max(hi & 0xFFFFu, hi >> 16);
+  u32 lo = min(min((lo_o >> 8) & 0xFFu, lo_o >> 24), min((lo_e >> 8) & 0xFFu, lo_e >> 24));
+  u32 hi = max(max((hi_o >> 8) & 0xFFu, hi_o >> 24), max((hi_e >> 8) & 0xFFu, hi_e >> 24));
   for (int o = 32; o; o >>= 1) {
     lo = min(lo, (u32)__shfl_xor((int)lo, o));
     hi = max(hi, (u32)__shfl_xor((int)hi, o));

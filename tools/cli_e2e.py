@@ -53,8 +53,10 @@ for cont in ("no", "gz"):
     asz = sum(os.path.getsize(f"{out}_1.scalce{e}") for e in "nrq")
     print(f"compress -c {cont}: {dt:.2f} s wall = {size / dt / 1e6:.0f} MB/s of FASTQ ({size / 1e6:.0f} MB in, "
           f"{asz / 1e6:.0f} MB out)  [{line}]", flush=True)
-    dt, _ = run("-d", "-o", os.path.join(d, "back_" + cont), out + "_1.scalcen", "--patterns-bin", pbin)
-    print(f"decompress ({cont}): {dt:.2f} s wall = {size / dt / 1e6:.0f} MB/s of FASTQ", flush=True)
+    dt, line = run("-d", "-o", os.path.join(d, "back_" + cont), out + "_1.scalcen", "--patterns-bin", pbin)
+    print(f"decompress ({cont}): {dt:.2f} s wall = {size / dt / 1e6:.0f} MB/s of FASTQ  [{line}]", flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "nodigest":  # (the record digests are a Python loop: minutes at 50 M records)
+    sys.exit(0)
 want = digest(fq)
 for cont in ("no", "gz"):
     got = digest(os.path.join(d, f"back_{cont}_1.fastq"))
