@@ -769,7 +769,8 @@ __global__ void tri_prev_k(const u8 *q0, u32 L, u32 qstride, u64 symbols_before,
   else { prev[0] = carried0; prev[1] = carried1; }
 }
 
-// range[0] = smallest symbol < 80 to lay out, range[1] = A = span (0: none): the symbols of the piece and the two in front
+// range[0] = smallest symbol < 80 to lay out, range[1] = A = span (0: none): the symbols of the piece and the two in front;
+// range[2] = 1 when no symbol of the piece lies outside them
 __global__ void tri_range_k(const u32 *minmax, const u32 *prev, u32 *range) {
   if (threadIdx.x || blockIdx.x) return;
   u32 lo = minmax[0], hi = minmax[1];
@@ -783,6 +784,7 @@ __global__ void tri_range_k(const u32 *minmax, const u32 *prev, u32 *range) {
     }
   range[0] = any ? lo : 0;
   range[1] = any ? hi - lo + 1 : 0;
+  range[2] = minmax[1] < 80 ? 1u : 0u;  // every symbol of the piece lies inside the range: the counting loop need not test
 }
 
 // Work is handed out in 64 KB tiles per WAVE through a global counter (one per pass), not by a fixed stride: while
@@ -809,6 +811,7 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
   const u32 lo = range[0], A = range[1];
   if (A == 0) return;
   const u32 AA = A * A, width = (2 * TRI_CAP) / AA;  // leading symbols per pass (>= 9)
+  const bool fast = range[2] != 0 && width >= A;        // (range[2]: no symbol outside [lo, lo + A), see tri_range_k)
   for (; pass < pass_end; pass++) {
   const u32 d0 = pass * width;
   if (d0 >= A) return;                          // the alphabet is done
@@ -865,6 +868,41 @@ __global__ __launch_bounds__(TRI_THREADS) void trigram_pass_k(const u8 *q, u64 n
       }
       row += adv_r; col += adv_c;
       if (col >= L) { col -= L; row++; }
+    }
+    if (fast && t != 0 && cnt == 16) {  // (the piece's first unit: its two symbols in front may be "none"; its last: short)
+      // every symbol lies in [lo, lo + A) and the whole alphabet is this pass: no range tests, and the index of a trigram
+      // follows from the last one's parts -- i = t A + c with t = (a - lo) A + (b - lo), next t = (b - lo) A + c
+      // (v_mad_u32_u24 by hand: full rate; the compiler turns every form of this into v_mad_u64_u32, a quarter of it)
+      const u32 lo4 = lo * 0x01010101u;
+      auto mad24 = [](u32 x, u32 y, u32 z) -> u32 {  // x y + z, x and y below 2^24
+        u32 r;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(y), "v"(z));
+        return r;
+      };
+      u32 cp = b - lo, t2 = mad24(a - lo, A, cp);  // cp: the symbol in front, t2 = the two in front as one number
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {  // four adds on their way before the first answer is looked at
+        const u32 wv = w[g4] - lo4;      // (no byte below lo: no borrow)
+        u32 ii[4], old[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 c = (wv >> (8 * k)) & 255u;
+          ii[k] = mad24(t2, A, c);
+          t2 = mad24(cp, A, c);
+          cp = c;
+          old[k] = atomicAdd(&tab[ii[k] >> 1], 1u << ((ii[k] & 1u) * 16));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 i = ii[k], sh = (i & 1u) * 16;
+          if (((old[k] >> sh) & 0xFFFFu) == 0x7FFFu) {  // the field just reached 2^15
+            atomicSub(&tab[i >> 1], 0x8000u << sh);
+            const u32 d = i / AA, rem = i - d * AA, bb = rem / A, cc = rem - bb * A;
+            atomicAdd(&freq4[((u64)(lo + d) * 80 + lo + bb) * 80 + lo + cc], 32768ull);
+          }
+        }
+      }
+      continue;
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
