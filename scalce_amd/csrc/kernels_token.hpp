@@ -453,10 +453,22 @@ __global__ __launch_bounds__(TOKP_THREADS) void tie_candidates_pipe_k(TieArgs a)
     k += add ? 1u : 0u;
   };
   const int nw = (a.L + 15) >> 4;
+  // The row comes in whole, up front (strides are multiples of 16 bytes): a tie read's row is one of 9 M scattered over the
+  // array, a wave's 64 rows are 64 different lines, and with a word asked for every sixteen bases the line had left the
+  // cache in between -- 720 bytes fetched per tie read for a row of 28 (counters, round 5).
+  const uint4 *row4 = reinterpret_cast<const uint4 *>(row);
+  const uint4 q0 = row4[0], q1 = a.stride > 16 ? row4[1] : make_uint4(0, 0, 0, 0), q2 = a.stride > 32 ? row4[2] : make_uint4(0, 0, 0, 0);
+  auto word = [&](int w) -> u32 {
+    u32 v = q0.x;
+    v = w == 1 ? q0.y : v; v = w == 2 ? q0.z : v; v = w == 3 ? q0.w : v;
+    v = w == 4 ? q1.x : v; v = w == 5 ? q1.y : v; v = w == 6 ? q1.z : v; v = w == 7 ? q1.w : v;
+    v = w == 8 ? q2.x : v; v = w == 9 ? q2.y : v; v = w == 10 ? q2.z : v; v = w == 11 ? q2.w : v;
+    return v;
+  };
   u32 prevs = 0;
   for (int w = 0; w < nw; w++) {
     const int cnt = (a.L - 16 * w) < 16 ? (a.L - 16 * w) : 16;
-    const u32 curs = __builtin_bswap32(row[w]);
+    const u32 curs = __builtin_bswap32(w < 12 && 4 * w + 4 <= a.stride ? word(w) : row[w]);
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
       if (kk < cnt) {
