@@ -336,67 +336,96 @@ __global__ __launch_bounds__(256) void tokenize_anchor_k(AnchorArgs a) {
     const u64 two = ((u64)__builtin_bswap32(row[wi]) << 32) | __builtin_bswap32(row[wi + 1]);  // (rows are padded by a spare word)
     return (u32)(two >> (64 - sh - 2 * K)) & kmask;
   };
+  // A hit of the bitmap costs a chain of dependent loads (word + rank -> node -> its record, or a walk down the trie), and a
+  // wave waits for the lane with the most of them: taken word by word as they were found, a read cost the sum over its words
+  // of the busiest lane's hits in each.  So the probes of 128 positions go first (a bit per position that can start a core),
+  // then every lane works through ITS hits four at a time -- four words and ranks asked for together, then four records --
+  // and reports what it finds in the order of the positions, as before.
   u32 code = 0;
   const u32 nw = (L + 15) >> 4;
-  for (u32 w = 0; w < nw; w++) {
-    const u32 word = row[w];  // byte j of the row = bases 4j..4j+3, first base in bits 7-6
-    const u32 cnt = (L - 16 * w) < 16 ? (L - 16 * w) : 16;
-    // sixteen probes of the bitmap, all issued before any is looked at (a probe behind a branch waits for the one before)
-    u32 hitmask = 0;
-    {
-      u64 wd[16];
-      u32 sh[16];
+  for (u32 seg = 0; seg < nw; seg += 8) {
+    u32 hm0 = 0, hm1 = 0, hm2 = 0, hm3 = 0;  // hits of positions 128 seg' .. +127, 32 per word
+    for (u32 w = seg; w < nw && w < seg + 8; w++) {
+      const u32 word = row[w];  // byte j of the row = bases 4j..4j+3, first base in bits 7-6
+      const u32 cnt = (L - 16 * w) < 16 ? (L - 16 * w) : 16;
+      // sixteen probes of the bitmap, all issued before any is looked at (a probe behind a branch waits for the one before)
+      u32 hitmask = 0;
+      {
+        u64 wd[16];
+        u32 sh[16];
 #pragma unroll
-      for (u32 k = 0; k < 16; k++) {
-        const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
-        code = ((code << 2) | c) & kmask;
-        const bool on = k < cnt && 16 * w + k + 1 >= K;
-        wd[k] = a.bits[on ? code >> 6 : 0u];
-        sh[k] = on ? (code & 63u) : 64u;
+        for (u32 k = 0; k < 16; k++) {
+          const u32 c = (word >> (8 * (k >> 2) + 6 - 2 * (k & 3))) & 3u;
+          code = ((code << 2) | c) & kmask;
+          const bool on = k < cnt && 16 * w + k + 1 >= K;
+          wd[k] = a.bits[on ? code >> 6 : 0u];
+          sh[k] = on ? (code & 63u) : 64u;
+        }
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) hitmask |= (sh[k] < 64u ? (u32)((wd[k] >> sh[k]) & 1ull) : 0u) << k;
       }
-#pragma unroll
-      for (u32 k = 0; k < 16; k++) hitmask |= (sh[k] < 64u ? (u32)((wd[k] >> sh[k]) & 1ull) : 0u) << k;
+      const u32 q = (w - seg) >> 1, hs = hitmask << (16 * ((w - seg) & 1u));
+      hm0 |= q == 0 ? hs : 0u; hm1 |= q == 1 ? hs : 0u; hm2 |= q == 2 ? hs : 0u; hm3 |= q == 3 ? hs : 0u;
     }
-    while (hitmask) {
-      const u32 k = (u32)__builtin_ctz(hitmask);
-      hitmask &= hitmask - 1;
-      const u32 i = 16 * w + k;             // a K-mer that is a trie node ends here
-      const u32 kc = kmer_at(i);
-      const u64 wdk = a.bits[kc >> 6];
-      // a core may start at p = i + 1 - K: down the trie along the read
-      const u32 jnode = a.rank[kc >> 6] + (u32)__popcll(wdk & ((1ull << (kc & 63u)) - 1ull));
-      const uint4 one = a.single[jnode];
-      if (one.x) {  // ONE core below this K-mer: its bases behind the K-mer against the read's, in one comparison
-        const u32 len = one.x & 63u, m = len - K;
-        if (i + m < L) {
-          bool same = true;
-          if (m) {
-            const u32 bp = 2 * (i + 1), wi = bp >> 5, sh = bp & 31u;
-            const u64 hi64 = ((u64)__builtin_bswap32(row[wi]) << 32) | __builtin_bswap32(row[wi + 1]);
-            const u64 lo = (u64)__builtin_bswap32(row[wi + 2]);   // (bits past the row's last base are shifted out below)
-            const u64 win = sh ? ((hi64 << sh) | (lo >> (32 - sh))) : hi64;   // the 32 bases from base i + 1 on
-            same = (win >> (64 - 2 * m)) == (((u64)one.z << 32) | one.y);
-          }
-          if (same) occurrence(len, one.x >> 6, i + m);
-        }
-        continue;
+    while (hm0 | hm1 | hm2 | hm3) {
+      u32 pi[4], kc[4], rk[4];
+      u64 wdk[4];
+      bool pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {  // the next hit of this lane (none: position of the segment's first K-mer, looked at by nobody)
+        const u32 q = hm0 ? 0u : hm1 ? 1u : hm2 ? 2u : 3u;
+        const u32 m = hm0 ? hm0 : hm1 ? hm1 : hm2 ? hm2 : hm3;
+        pv[u] = m != 0;
+        pi[u] = pv[u] ? 16 * seg + 32 * q + (u32)__builtin_ctz(m) : K - 1;
+        hm0 &= q == 0 ? hm0 - 1 : 0xFFFFFFFFu; hm1 &= q == 1 ? hm1 - 1 : 0xFFFFFFFFu;
+        hm2 &= q == 2 ? hm2 - 1 : 0xFFFFFFFFu; hm3 &= (q == 3 && m) ? hm3 - 1 : 0xFFFFFFFFu;
+        kc[u] = kmer_at(pi[u]);
+        wdk[u] = a.bits[kc[u] >> 6];
+        rk[u] = a.rank[kc[u] >> 6];
       }
-      u32 s = a.idK + jnode;
-      u32 d = K, pos = i;                   // depth of s, index of its last base
-      bool has_out = true;                  // (the anchor's own output is not known from a transition word: look)
-      for (;;) {
-        if (has_out) {
-          const u32 info = a.outinfo[s];
-          if (info != kNoOutD && (info >> kLevelShiftD) == d) occurrence(d, info & kBucketMaskD, pos);
+      uint4 one[4];
+      u32 jn[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        jn[u] = rk[u] + (u32)__popcll(wdk[u] & ((1ull << (kc[u] & 63u)) - 1ull));
+        one[u] = a.single[pv[u] ? jn[u] : 0u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (!pv[u]) continue;
+        const u32 i = pi[u];                  // a K-mer that is a trie node ends here: a core may start at p = i + 1 - K
+        if (one[u].x) {  // ONE core below this K-mer: its bases behind the K-mer against the read's, in one comparison
+          const u32 len = one[u].x & 63u, m = len - K;
+          if (i + m < L) {
+            bool same = true;
+            if (m) {
+              const u32 bp = 2 * (i + 1), wi = bp >> 5, sh = bp & 31u;
+              const u64 hi64 = ((u64)__builtin_bswap32(row[wi]) << 32) | __builtin_bswap32(row[wi + 1]);
+              const u64 lo = (u64)__builtin_bswap32(row[wi + 2]);   // (bits past the row's last base are shifted out below)
+              const u64 win = sh ? ((hi64 << sh) | (lo >> (32 - sh))) : hi64;   // the 32 bases from base i + 1 on
+              same = (win >> (64 - 2 * m)) == (((u64)one[u].z << 32) | one[u].y);
+            }
+            if (same) occurrence(len, one[u].x >> 6, i + m);
+          }
+          continue;
         }
-        if (pos + 1 >= L) break;
-        const u32 cn = (rowb[(pos + 1) >> 2] >> (6 - 2 * ((pos + 1) & 3))) & 3u;
-        const u32 e = 4 * s + cn;
-        if (!((a.child[e >> 5] >> (e & 31u)) & 1u)) break;
-        const u32 tr = a.next[e];
-        s = tr & 0x7FFFFFFFu;
-        has_out = (tr >> 31) != 0;
-        d++; pos++;
+        u32 s = a.idK + jn[u];                // several cores below it: down the trie along the read
+        u32 d = K, pos = i;                   // depth of s, index of its last base
+        bool has_out = true;                  // (the anchor's own output is not known from a transition word: look)
+        for (;;) {
+          if (has_out) {
+            const u32 info = a.outinfo[s];
+            if (info != kNoOutD && (info >> kLevelShiftD) == d) occurrence(d, info & kBucketMaskD, pos);
+          }
+          if (pos + 1 >= L) break;
+          const u32 cn = (rowb[(pos + 1) >> 2] >> (6 - 2 * ((pos + 1) & 3))) & 3u;
+          const u32 e = 4 * s + cn;
+          if (!((a.child[e >> 5] >> (e & 31u)) & 1u)) break;
+          const u32 tr = a.next[e];
+          s = tr & 0x7FFFFFFFu;
+          has_out = (tr >> 31) != 0;
+          d++; pos++;
+        }
       }
     }
   }
@@ -896,9 +925,11 @@ __global__ __launch_bounds__(TWF_THREADS) void tie_window_fused_k(TieFusedArgs g
   const u32 *base_in = g.base2 + (u64)sel * g.nb1;
   const bool settled = moved == 0;
   if (settled) {
-    if (first_wg) {  // the settled window's choices count for every window behind it
+    {  // the settled window's choices count for every window behind it: every workgroup folds its share of the buckets (the
+       // window's words no longer move, so all copies of their ranks agree; one workgroup walking a million buckets made
+       // this launch 0.36 ms long)
       u32 *base_out = g.base2 + (u64)(1 - sel) * g.nb1;
-      for (u32 b = threadIdx.x; b < g.nb1; b += TWF_THREADS) {
+      for (u32 b = blockIdx.x * TWF_THREADS + threadIdx.x; b < g.nb1; b += gridDim.x * TWF_THREADS) {
         const u64 cell = (u64)w * g.nb1 + b;
         const u32 cs = g.cellstart[cell], ce = g.cellstart[cell + 1];
         base_out[b] = base_in[b] + (ce > cs ? rank(ce) - rank(cs) : 0u);
@@ -1082,6 +1113,48 @@ __global__ __launch_bounds__(256) void seg_rescan_k(u32 nb1, const u32 *seg, con
     running += tot;
   }
   if (threadIdx.x == 0) counts[b] = (u64)fixed_total[b] + (u64)running;
+}
+
+// The same for tables with more buckets than events per bucket (a million cores: three events per bucket, and a million
+// workgroups that each find nothing to do took 0.44 ms): a workgroup takes 256 consecutive buckets, a thread walks its own
+// bucket's segment when that is short, and the long ones are done by the whole workgroup one after the other.
+__global__ __launch_bounds__(256) void seg_rescan_many_k(u32 nb1, const u32 *seg, const u32 *dirty, const u8 *chosen, u32 *G,
+                                                        const u32 *fixed_total, u64 *counts) {
+  __shared__ u32 sm[4];
+  __shared__ u32 longs[256];
+  __shared__ u32 nlong;
+  if (threadIdx.x == 0) nlong = 0;
+  __syncthreads();
+  const u32 b = blockIdx.x * 256 + threadIdx.x;
+  if (b < nb1 && dirty[b] != 0xFFFFFFFFu) {
+    const u32 start = seg[b], end = seg[b + 1];
+    if (end - start <= 64) {
+      u32 run = 0;
+      for (u32 p = start; p < end; p++) { G[p] = run; run += (u32)chosen[p]; }
+      counts[b] = (u64)fixed_total[b] + (u64)run;
+    } else {
+      longs[atomicAdd(&nlong, 1u)] = b;
+    }
+  }
+  __syncthreads();
+  const u32 nl = nlong;
+  for (u32 li = 0; li < nl; li++) {
+    const u32 bb = longs[li];
+    const u32 start = seg[bb], end = seg[bb + 1];
+    u32 running = 0;
+    for (u32 base = start; base < end; base += 256 * 16) {
+      const u32 p0 = base + threadIdx.x * 16;
+      u32 f[16], mine = 0;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { f[i] = (p0 + i < end) ? (u32)chosen[p0 + i] : 0u; mine += f[i]; }
+      u32 tot;
+      u32 ex = running + block_exclusive_sum<u32, 4>(mine, &tot, sm);
+#pragma unroll
+      for (int i = 0; i < 16; i++) { if (p0 + i < end) G[p0 + i] = ex; ex += f[i]; }
+      running += tot;
+    }
+    if (threadIdx.x == 0) counts[bb] = (u64)fixed_total[bb] + (u64)running;
+  }
 }
 
 __global__ __launch_bounds__(256) void add_counts_k(u32 n, const u64 *x, const u64 *y, u64 *out) {
