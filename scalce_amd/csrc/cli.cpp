@@ -1254,6 +1254,7 @@ static int do_decompress(const Options &o, const std::string &path, scalce_ctx *
 }
 
 int main(int argc, char **argv) {
+  const double t_main = now();
   Options o;
   LOG("SCALCE %s [MI355X / HIP]\n", SCALCE_VERSION);
   static struct option long_opt[] = {{"help", 0, 0, 'h'}, {"lossy-percentage", 1, 0, 'p'}, {"decompress", 0, 0, 'd'},
@@ -1330,8 +1331,10 @@ int main(int argc, char **argv) {
     const int hw = (int)std::thread::hardware_concurrency();
     g_threads = o.threads > 0 ? o.threads : std::max(1, std::min(64, hw - 1));
   }
+  const double t_ready = now();
   const int rc = o.decompress ? do_decompress(o, files[0], ctx) : do_compress(o, files, ctx);
   scalce_ctx_destroy(ctx);
+  LOG("\tProcess: device and core table ready %.2f s after main() began, %.2f s in all\n", t_ready - t_main, now() - t_main);
   LOG("Done!\n");
   return rc;
 }

@@ -31,8 +31,8 @@ def run(*a):
     r = subprocess.run([cli, *a], capture_output=True, text=True)
     dt = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-1500:]
-    line = [x for x in r.stderr.splitlines() if "Time elapsed" in x]
-    return dt, (line[0].strip() if line else "")
+    line = [x.strip() for x in r.stderr.splitlines() if "Time elapsed" in x or "Process:" in x]
+    return dt, " | ".join(line)
 
 
 def digest(path):  # order-independent digest of the 4-line records
