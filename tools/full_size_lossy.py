@@ -63,6 +63,9 @@ def main():
         print(r.stderr[-2000:])
         return 1
     dt2 = time.time() - t2
+    for line in r.stderr.splitlines():
+        if "Time elapsed" in line or "Process:" in line:
+            print("   " + line, flush=True)
     print(f"decompress: {dt2:.1f} s wall = {size / dt2 / 1e6:.0f} MB/s of FASTQ", flush=True)
     got = subprocess.run([dig, os.path.join(D, "back_1.fastq")], capture_output=True, text=True).stdout.strip()
     print("input as it is             :", plain)
