@@ -352,7 +352,7 @@ def main():
                 texts[i] = None
         torch.cuda.empty_cache()
         tv0 = time.perf_counter()
-        vtrace = os.environ.get("SCALCE_VERIFY_TRACE")
+        vtrace = os.environ.get("SCALCE_TRACE")
         if vtrace:
             print("  [verify, rank %d] batches closed %.2f s after the timed loop" % (rank, time.perf_counter() - t0 - dt), file=sys.stderr, flush=True)
         mine = {"want": None, "got": None, "error": None}

@@ -235,8 +235,8 @@ extern "C" int scalce_sharded_compress(scalce_comm *comm, scalce_ctx *ctx, scalc
     ~StreamScratch() { if (on) scalce_batch_set_stream_scratch(b, 0); }
   } stream_scratch{b, scalce_batch_set_stream_scratch(b, 1) == SCALCE_OK};
   static thread_local std::string last_error;
-  // SCALCE_SHARD_TRACE=1: where a rank's time goes (the stream is drained at every mark: for looking, not for timing runs)
-  const bool trace = getenv("SCALCE_SHARD_TRACE") != nullptr;
+  // SCALCE_TRACE=1: where a rank's time goes (the stream is drained at every mark: for looking, not for timing runs)
+  const bool trace = getenv("SCALCE_TRACE") != nullptr;
   double t_last = 0;
   auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
   auto mark = [&](const char *what) {

@@ -140,8 +140,8 @@ def sharded_records_text(comm, ctx, batch, res, read_len, phred, device):
     import torch
     t_mark = [time.perf_counter()]
 
-    def mark(what):   # SCALCE_VERIFY_TRACE=1: where the check's time goes
-        if os.environ.get("SCALCE_VERIFY_TRACE"):
+    def mark(what):   # SCALCE_TRACE=1: where the check's time goes
+        if os.environ.get("SCALCE_TRACE"):
             torch.cuda.synchronize()
             now = time.perf_counter()
             print("  [verify, rank %d] %-22s %8.2f s" % (comm.rank, what, now - t_mark[0]), file=sys.stderr, flush=True)
