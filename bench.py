@@ -17,6 +17,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
   parity_checked -- the run proves its own output: the LAST timed shard is decoded on the device back to FASTQ text whose
                     record multiset equals the input's, and the sample of the CPU leg gives byte-identical archives
                     through the `scalce` binary and through the reference
+One GPU on its own plans its coder launches for the length of the run (--launch-plan waves, config.launch_plan): a launch
+takes ~0.5 s whether it holds five shards or fifteen, so the remainder of the run goes first and every later launch fills
+all slots and all CUs; --launch-plan eager is the pipeline of a stream of unknown length (a launch per six shards).
 """
 import argparse
 import json
@@ -54,6 +57,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> archive leg (the `scalce` binary on the same shard written to a file)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the last timed shard (device decode + record digest)")
     ap.add_argument("--no-table-scale", action="store_true", help="skip the tokenizer leg on a core table of a million cores")
+    ap.add_argument("--launch-plan", choices=("waves", "eager"), default="waves",
+                    help="one GPU on its own: `waves` = coder launches that fill every slot, the remainder of the run first (a launch takes "
+                         "~0.5 s whatever it holds); `eager` = a launch as soon as `--group` shards are ready, side by side (what a stream of "
+                         "unknown length gets; rounds 1-5a)")
     ap.add_argument("--shared-input", action="store_true",
                     help="every shard in flight reads the SAME text tensor (rounds 1-3; more shards fit).  Default: one distinct text per shard in flight")
     ap.add_argument("--ref-full-shard", action="store_true",
@@ -243,7 +250,29 @@ def main():
     # as many coder streams as groups fit the slots (every launch takes ~0.6 s whatever it holds: with a stream per group in
     # rotation no group waits for another's launch to end; 3 / 4 / 12 measured 88.1 ms per shard against 90.0 at 3 / 3 / 12)
     n_coder_streams = int(os.environ.get("SCALCE_BENCH_CODER_STREAMS", str(min(2 if G >= 6 else 6, DF // G)) if (G > 1 and DF >= 2 * G) else "1"))
-    pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=G, sharded=sharded, trace=mark if trace else None,
+    # The launch plan of a run of k shards on D slots (one GPU on its own).  A coder launch takes ~0.5 s whether it holds five
+    # shards or fifteen, and its CUs are lost to the front stages beside it: launches of six as they fill up leave the chip to
+    # a last launch of two for 0.35 s at the driver's 20 steps.  `waves`: every launch but the first takes ALL D slots --
+    # nothing can run beside it anyway, so it is spread over every CU (scalce_pipeline_submit: flush_now 1) -- and the
+    # remainder k mod D goes FIRST, beside the front stages of the first full wave: 20 steps = 5 + 15.
+    # (tools: SCALCE_BENCH_GROUPS-style sweeps in DESIGN.md section 7: 72.2 ms per shard eager, 69.2 as 5 + 15, 67.9 with the
+    #  last launch on all CUs; 36 steps: 71.0 eager, 69.3 as 6 + 15 + 15; 16 steps: 84.6 eager, 71.8 as 1 + 15)
+    waves = args.launch_plan == "waves" and not sharded and F == 1 and auto_group and G > 1 and D >= 2 * G
+
+    def launch_plan(k):
+        r = k % D
+        return ([r] if r else []) + [D] * (k // D)
+
+    if waves and not os.environ.get("SCALCE_AC_LANES_USED"):
+        # blocks per workgroup of the one-block-per-lane coder: as few as let a full wave take the chip in ONE round (the library
+        # picks that by itself for a launch that has the chip to itself; here the first, smaller launch gets the same shape --
+        # it has to be through before the front stages of the wave behind it want its slots: 28 against 32 blocks: 67.9 against
+        # 69.2 ms per shard at 20 steps)
+        blocks_per_shard = -(-(n * L) // (10 << 20))
+        n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        os.environ["SCALCE_AC_LANES_USED"] = str(max(8, min(64, -(-(D * blocks_per_shard) // n_cus))))
+
+    pipes = [ShardPipeline(batches[f * DF:(f + 1) * DF], group=(D if waves else G), sharded=sharded, trace=mark if trace else None,
                            coder_streams=n_coder_streams)
              for f in range(F)]
     pipe = pipes[0]
@@ -275,6 +304,12 @@ def main():
     def run_on(pipe, k):
         fr = front_of_pipe[id(pipe)]
         comm, ctx = comms[fr], ctxs[fr]
+        ends = {}
+        if waves:   # shard index behind which a launch goes out -> 1: alone on the chip (a full wave, the end), 2: beside front stages
+            at = 0
+            for g in launch_plan(k):
+                at += g
+                ends[at - 1] = 1 if (g == D or at == k) else 2
         for j in range(k):
             slot, b = pipe.acquire()
             mark(f"shard {j}: front (slot {slot})")
@@ -291,7 +326,7 @@ def main():
                     state[gslot] = host.sharded_compress(comm, ctx, b, tx.data_ptr(), nbytes, flags=host.SHARD_PREPARE_ONLY,
                                                          stream=pipe.front.cuda_stream, result=state.get(gslot))
             mark(f"shard {j}: front done")
-            pipe.submit(slot, tag=j, flush=j + 1 == k)
+            pipe.submit(slot, tag=j, flush=ends.get(j, 0) if waves else (j + 1 == k))
         pipe.drain()
 
     torch.cuda.synchronize()  # the synthetic shard was generated on the default stream
@@ -546,7 +581,11 @@ def main():
                        "core_table": "tests/golden/patterns.bin (15600 cores)", "parallelism": f"shard{world}" + ("" if not sharded else f": read ranges per rank, ONE archive; run-wide -B chunks / tie-break / quality model / 10 MiB blocks over {comm.world} rank(s) of " + ("shared memory (rehearsal)" if os.environ.get("SCALCE_COMM") == "shm" else "RCCL (all-gather, all-reduce, send/recv)")),
                        "bucket_set_size": B, "spill_chunks": stats["chunks"],
                        "tie_reads": stats["tie_reads"], "jacobi_iters": stats["jacobi_iters"],
-                       "shards_in_flight": D, "shards_per_coder_launch": G, "coder_streams": n_coder_streams, "front_threads": F,
+                       "shards_in_flight": D, "shards_per_coder_launch": (round(args.steps / max(len(launch_plan(args.steps)), 1), 2) if waves else G),
+                       "launch_plan": ({"kind": "waves", "launches": launch_plan(args.steps),
+                                        "what": "every coder launch but the first takes all slots and all CUs; the remainder of the run goes first, beside the front stages of the first full wave"}
+                                       if waves else {"kind": "eager", "shards_per_launch": G}),
+                       "coder_streams": n_coder_streams, "front_threads": F,
                        "coded_in_place": bool(in_place),
                        "inputs": ("one text tensor per shard in flight: %d distinct synthetic shards of the same shape (seeds %d + 7919 k), "
                                   "each resident in HBM before the timed region; step j reads the text of slot j mod %d" % (D, SEED0, D)) if own_text
@@ -560,7 +599,8 @@ def main():
                          "frac": round(step_ach / (HBM_PEAK_GBS * world), 5),
                          "traffic": step_traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_step": alg_step, "bytes_per_read": round(alg_step / n, 1),
-                         "kernel": {"name": kname, "launch_ms": round(per_launch_ms, 3), "shards_per_launch": G,
+                         "kernel": {"name": kname, "launch_ms": round(per_launch_ms, 3),
+                                    "shards_per_launch": (round(args.steps / max(len(launch_plan(args.steps)), 1), 2) if waves else G),
                                     "bound": "issue",
                                     "achieved": round(k_ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k_ach / HBM_PEAK_GBS, 6),
                                     "alg_bytes_per_launch": int(k_alg), "traffic": k_traffic,
@@ -572,9 +612,10 @@ def main():
             "decode": (dict(decode, cpu_baseline=(cpu or {}).get("decompress")) if decode else None),
             "e2e": e2e,
             "table_scale": table_scale,
-            "note": "value = device-resident steady state with %d shards (independent jobs of the configs[1] size, each with its own "
-                    "input text) in flight; value_single_job = one such job alone, input already in HBM; decode = the inverse path on "
-                    "the last shard; e2e = the scalce binary, file in, archive out" % D,
+            "note": "value = %d shards (independent jobs of the configs[1] size) through the device-resident hot path, %d in flight, each "
+                    "with an input text of its own, fill and drain of the pipeline inside the timed region%s; value_single_job = one such job "
+                    "alone, input already in HBM; decode = the inverse path on the last shard; e2e = the scalce binary, file in, archive out"
+                    % (args.steps, D, (" (coder launches planned for a run of this length: %s shards)" % " + ".join(str(x) for x in launch_plan(args.steps))) if waves else ""),
         }
         print(json.dumps(line))
     if world > 1:

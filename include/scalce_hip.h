@@ -420,12 +420,18 @@ int scalce_shard_plan_blocks(int world, int rank, uint32_t nb1, const uint64_t *
  * (arithmetic.cpp:349-357, compress.cpp:781-786).  The device-side counterpart for a caller with MANY shards: `nslots`
  * batches (usually sharing one scalce_workspace), the front stages (scalce_batch_ingest .. _emit) of the next shards on one
  * stream beside the coder launches of the previous ones on `coder_streams` others, `group` shards per coder launch
- * (nslots >= 2 * group), a shard retired on an event behind its launch.  external_coder != 0: the caller enqueues or prepares
- * the coder itself (scalce_sharded_compress with SCALCE_SHARD_CODER_ASYNC / _PREPARE_ONLY).
+ * (nslots >= 2 * group for launches that go out as they fill up), a shard retired on an event behind its launch.
+ * external_coder != 0: the caller enqueues or prepares the coder itself (scalce_sharded_compress with
+ * SCALCE_SHARD_CODER_ASYNC / _PREPARE_ONLY).
  *     for every shard:  scalce_pipeline_acquire(p, &slot, &retired);   (retired: take the outputs of the shard that was there)
  *                       ... front stages of the shard into batches[slot] on scalce_pipeline_front_stream(p) ...
- *                       scalce_pipeline_submit(p, slot, no_more_shards, &launched);
- *     scalce_pipeline_drain(p);          (the caller walks the slots for their outputs, or retires them one by one before) */
+ *                       scalce_pipeline_submit(p, slot, flush_now, &launched);
+ *     scalce_pipeline_drain(p);          (the caller walks the slots for their outputs, or retires them one by one before)
+ * flush_now: 0 = the launch goes out when `group` shards are pending; 1 = what is pending goes out now and nothing will run
+ * beside it (the end of a run, or a wave that fills every slot -- `group` may be as large as nslots for a caller that plans
+ * its launches): it is shaped for its own latency, on every CU; 2 = it goes out now, front stages of further shards follow
+ * beside it.  A coder launch takes ~0.5 s whether it holds five 50 M-read shards or fifteen: a caller that knows the length
+ * of its run puts the remainder first and then launches whole waves (bench.py --launch-plan waves). */
 typedef struct scalce_pipeline scalce_pipeline;
 int scalce_pipeline_create(scalce_batch **batches, int nslots, int group, int coder_streams, int external_coder, scalce_pipeline **out);
 void scalce_pipeline_destroy(scalce_pipeline *p);
@@ -433,7 +439,7 @@ const char *scalce_pipeline_error(const scalce_pipeline *p);
 void *scalce_pipeline_front_stream(scalce_pipeline *p);
 void *scalce_pipeline_coder_stream(scalce_pipeline *p, int i);
 int scalce_pipeline_acquire(scalce_pipeline *p, int *slot, int *retired);
-int scalce_pipeline_submit(scalce_pipeline *p, int slot, int no_more_shards, int *launched);
+int scalce_pipeline_submit(scalce_pipeline *p, int slot, int flush_now, int *launched);
 int scalce_pipeline_retire(scalce_pipeline *p, int slot, int *had_shard);
 int scalce_pipeline_flush_last(scalce_pipeline *p);  /* what is pending goes out as the last launch of a run */
 int scalce_pipeline_drain(scalce_pipeline *p);

@@ -68,7 +68,7 @@ int flush(scalce_pipeline *p, int last, int *launched) {
 extern "C" int scalce_pipeline_create(scalce_batch **batches, int nslots, int group, int coder_streams, int external_coder,
                                       scalce_pipeline **out) {
   if (!batches || nslots < 1 || group < 1 || coder_streams < 1 || !out) return SCALCE_ERR_ARG;
-  if (group > 1 && nslots < 2 * group) return SCALCE_ERR_ARG;  // the front stages of one group run while the previous one is coded
+  if (group > 1 && nslots < group) return SCALCE_ERR_ARG;  // (a caller that lets launches fill up needs 2 * group slots: the front stages of one group run while the previous one is coded)
   scalce_pipeline *p = new scalce_pipeline;
   *out = p;
   p->b.assign(batches, batches + nslots);
@@ -132,7 +132,9 @@ extern "C" int scalce_pipeline_acquire(scalce_pipeline *p, int *slot, int *retir
 }
 
 // The front stages of `slot` are enqueued on the front stream: launch the coder now or with the next shards.
-// flush != 0: the caller has no further shards (the end of a run).
+// flush_now 1: launch what is pending now, and nothing will run beside that launch (the end of a run, or a wave of shards
+// that fills every slot: the next front stages wait for these slots anyway) -- it is shaped for its own latency;
+// flush_now 2: launch what is pending now, front stages of further shards follow beside it.
 extern "C" int scalce_pipeline_submit(scalce_pipeline *p, int slot, int flush_now, int *launched) {
   if (!p || slot < 0 || slot >= (int)p->b.size()) return SCALCE_ERR_ARG;
   if (launched) *launched = 0;
@@ -152,7 +154,7 @@ extern "C" int scalce_pipeline_submit(scalce_pipeline *p, int slot, int flush_no
     return SCALCE_OK;
   }
   p->pending.push_back(slot);
-  if ((int)p->pending.size() >= p->G || flush_now) return flush(p, flush_now, launched);
+  if ((int)p->pending.size() >= p->G || flush_now) return flush(p, flush_now == 1, launched);
   return SCALCE_OK;
 }
 

@@ -28,8 +28,8 @@ class ShardPipeline:
         self.batches = list(batches)
         self.D = len(self.batches)
         self.G = max(1, int(group))
-        if self.G > 1 and self.D < 2 * self.G:
-            raise ValueError("a grouped pipeline needs at least 2 * group batches")
+        if self.G > 1 and self.D < self.G:
+            raise ValueError("a grouped pipeline needs at least `group` batches (2 * group when launches are left to fill up)")
         self.L = host.lib()
         L = self.L
         L.scalce_pipeline_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -104,10 +104,11 @@ class ShardPipeline:
     # -- coder launches ------------------------------------------------------------------------------------
     def submit(self, slot, tag=None, flush=False):
         """The front stages of `slot` are enqueued on `self.front`: launch the coder now or with the next shards.
-        flush: the caller has no further shards -- the last launch of a run is picked for its own latency."""
+        flush: True / 1 = launch what is pending now and nothing runs beside it (the end of a run, a wave that fills every
+        slot): shaped for its own latency; 2 = launch now, front stages of further shards follow beside it."""
         self._tag[slot] = tag
         launched = C.c_int()
-        self._check(self.L.scalce_pipeline_submit(self.h, slot, 1 if flush else 0, C.byref(launched)))
+        self._check(self.L.scalce_pipeline_submit(self.h, slot, 1 if flush is True else int(flush), C.byref(launched)))
         if launched.value and self.trace:
             self.trace("coder launched")
 

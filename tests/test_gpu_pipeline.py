@@ -53,6 +53,54 @@ def test_pipelined_shards_equal_one_shot_compress(group, slots, shared, patterns
             assert len(g[w]) == len(want[i][w]) and (g[w] == want[i][w]).all(), f"shard {i} (pass {rep}): {name} differ"
 
 
+def test_launches_in_waves_write_the_same_streams(patterns_blob, monkeypatch):
+    """bench.py's launch plan for one GPU on its own: the pipeline's group is ALL its slots and the caller says when a launch
+    goes out -- the remainder of the run first, beside the next front stages (flush 2), then waves that fill every slot and
+    have the chip to themselves (flush 1: as few blocks per workgroup as all CUs allow).  Same streams as one shard at a
+    time.  (SCALCE_AC_BLOCKS_PER_WG=64: the one-block-per-lane kernel whatever the size, so that its shape is what varies.)"""
+    import torch
+    from gpu_util import device_bytes
+    ctx = host.Context(0, patterns_bin=patterns_blob)
+    L = 100
+    sizes = [230_000, 40_000, 120_000, 5_000, 60_000, 110_000, 90_000]
+    shards = []
+    for i, n in enumerate(sizes):
+        bases, quals = synth.reads_and_quals(n, L, seed=300 + i, dup_frac=0.1)
+        fq = synth.fastq_bytes_fast(bases, quals, prefix=f"w{i}.")
+        shards.append((device_bytes(fq), len(fq), n))
+    want = []
+    for t, nb, n in shards:
+        b = host.Batch(ctx, L, n + 8, nb + 64)
+        b.compress(t.data_ptr(), nb)
+        b.finish()
+        want.append({w: b.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)})
+    monkeypatch.setenv("SCALCE_AC_BLOCKS_PER_WG", "64")
+    slots = 5
+    nmax, bmax = max(sizes), max(s[1] for s in shards)
+    ws = host.Workspace(ctx)
+    batches = [host.Batch(ctx, L, nmax + 8, bmax + 64, workspace=ws) for _ in range(slots)]
+    for b in batches:
+        b.set_code_in_place(True)
+    got = {}
+
+    def on_retire(slot, batch, tag):
+        got[tag] = {w: batch.output(w, 0).copy() for w in (host.OUT_QUAL, host.OUT_READS, host.OUT_NAMES)}
+
+    pipe = ShardPipeline(batches, group=slots, on_retire=on_retire, coder_streams=2)
+    torch.cuda.synchronize()
+    plan = {1: 2, 6: 1}   # 7 shards on 5 slots: 2 + 5
+    for i, (t, nb, n) in enumerate(shards):
+        slot, b = pipe.acquire()
+        with torch.cuda.stream(pipe.front):
+            b.front(t.data_ptr(), nb, None, 0, pipe.front.cuda_stream)
+        pipe.submit(slot, tag=i, flush=plan.get(i, 0))
+    pipe.drain()
+    assert len(got) == len(shards)
+    for i, g in got.items():
+        for w, name in ((host.OUT_QUAL, "qualities"), (host.OUT_READS, "reads"), (host.OUT_NAMES, "names")):
+            assert len(g[w]) == len(want[i][w]) and (g[w] == want[i][w]).all(), f"shard {i}: {name} differ"
+
+
 @pytest.mark.parametrize("bpw,overflow", [("", False), ("64", False), ("8", False), ("64", True), ("", True)])
 def test_coding_in_place_writes_the_same_streams(bpw, overflow, patterns_blob, monkeypatch):
     """scalce_batch_set_code_in_place: the coder's blocks go over the symbols they were coded from (no block buffers: 3.2 GB less
