@@ -148,8 +148,8 @@ def main():
     # `fronts`: host threads, each with a front stream, a context, a set of front-stage buffers, D / fronts of the slots and -- in
     # a sharded run -- a communicator of its own.  One is right for a GPU on its own (two measured the same, round 3).  For a rank
     # among several, TWO hide what a shard waits for between ranks -- the tie-break's chain (a settle per rank in front of it), the
-    # rows and q' bytes on the wire -- behind the other pipeline's work (5.8 x one GPU projected at eight ranks
-    # against 3.5 x with one).  SCALCE_BENCH_FRONTS=2 asks for it; it is rehearsed over the shared-memory transport
+    # rows and q' bytes on the wire -- behind the other pipeline's work (5.6 x one GPU projected at eight ranks
+    # against 3.4 x with one).  SCALCE_BENCH_FRONTS=2 asks for it; it is rehearsed over the shared-memory transport
     # (tests, profiles/r05_sharded_w1_w2.log) but stays opt-in: two RCCL communicators driven from two threads of every rank
     # have never run on real peers here, and a run the driver cannot see the end of is worse than a slower one.
     F = max(1, int(os.environ.get("SCALCE_BENCH_FRONTS", "1")))
