@@ -539,7 +539,7 @@ struct EventArgs {
   const u32 *ev_off;
   u32 *ev_bucket;        // (may be null together with ev_init: the sort on (key, event) pairs carries both in the key)
   u8 *ev_init;           // initial "chosen" flag: fixed reads 1, first candidate 1, others 0
-  u64 *ev_key;           // bucket << 2 | candidate of a tie read << 1 | initial flag: what the sort by bucket carries along
+  u32 *ev_key;           // bucket << 2 | candidate of a tie read << 1 | initial flag: what the sort by bucket carries along (32 bits: buckets < 2^30)
 };
 __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
   const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,12 +550,12 @@ __global__ __launch_bounds__(256) void events_fill_k(EventArgs a) {
     for (u32 j = 0; j < k; j++) {
       const u32 bk = a.cand_bucket[off + j];
       if (a.ev_bucket) { a.ev_bucket[e + j] = bk; a.ev_init[e + j] = j == 0; }
-      if (a.ev_key) a.ev_key[e + j] = ((u64)bk << 2) | 2u | (j == 0 ? 1u : 0u);
+      if (a.ev_key) a.ev_key[e + j] = (bk << 2) | 2u | (j == 0 ? 1u : 0u);
     }
   } else {
     const u32 bk = a.tok_bucket[r];
     if (a.ev_bucket) { a.ev_bucket[e] = bk; a.ev_init[e] = 1; }
-    if (a.ev_key) a.ev_key[e] = ((u64)bk << 2) | 1u;
+    if (a.ev_key) a.ev_key[e] = (bk << 2) | 1u;
   }
 }
 
@@ -618,10 +618,10 @@ __global__ __launch_bounds__(256) void events_segments_k(u32 nev, const u32 *sor
 //   cidx[p]       compact index of sorted position p (exclusive scan of the tie bit)
 //   ev_place[e]   sorted position of event e
 struct TieBitOfKey {
-  const u64 *keys;
-  __device__ u32 operator()(u64 i) const { return (u32)(keys[i] >> 1) & 1u; }
+  const u32 *keys;
+  __device__ u32 operator()(u64 i) const { return (keys[i] >> 1) & 1u; }
 };
-__global__ __launch_bounds__(256) void events_place_keys_k(u32 nev, const u32 *sorted, const u64 *keys, const u32 *cidx, u32 *ev_place,
+__global__ __launch_bounds__(256) void events_place_keys_k(u32 nev, const u32 *sorted, const u32 *keys, const u32 *cidx, u32 *ev_place,
                                                           u8 *chosen_t) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nev) return;
@@ -642,11 +642,11 @@ __global__ __launch_bounds__(256) void events_compact_segments_k(u32 nb1, const 
     fixed_total[b] = (s1 - s0) - (c1 - c0);
   }
 }
-__global__ __launch_bounds__(256) void events_segments_keys_k(u32 nev, const u64 *keys, u32 nb, u32 *seg) {
+__global__ __launch_bounds__(256) void events_segments_keys_k(u32 nev, const u32 *keys, u32 nb, u32 *seg) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > nev) return;
-  const u32 cur = i < nev ? (u32)(keys[i] >> 2) : nb;
-  const u32 prev = i ? (u32)(keys[i - 1] >> 2) : 0xFFFFFFFFu;
+  const u32 cur = i < nev ? keys[i] >> 2 : nb;
+  const u32 prev = i ? keys[i - 1] >> 2 : 0xFFFFFFFFu;
   if (i == 0) {
     for (u32 b = 0; b <= cur && b <= nb; b++) seg[b] = 0;
   } else if (cur != prev) {

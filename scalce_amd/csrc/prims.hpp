@@ -263,7 +263,8 @@ inline void radix_pass(const u32 *in, u32 *out, u32 n, D digit, u32 *hist_ws, u3
 // workgroup of one tile wrote 256 single words a whole row apart -- 64 bytes of HBM write per word.  Sixteen tiles make
 // every digit's words one 64-byte run.
 constexpr int RH_TILES = 16;
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_key_k(const u64 *keys, u32 n, u32 shift, u32 *hist, u32 ntiles) {
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_key_k(const K *keys, u32 n, u32 shift, u32 *hist, u32 ntiles) {
   __shared__ u32 h[RH_TILES][256];
   for (int i = threadIdx.x; i < RH_TILES * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
   __syncthreads();
@@ -292,9 +293,10 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_key_k(const u64 *keys, 
 constexpr int RSK_THREADS = 512;
 constexpr int RSK_ITEMS = RS_TILE / RSK_THREADS;
 constexpr int RSK_WAVES = RSK_THREADS / 64;
-__global__ __launch_bounds__(RSK_THREADS) void radix_scatter_kv_staged_k(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out,
+template <typename K>
+__global__ __launch_bounds__(RSK_THREADS) void radix_scatter_kv_staged_k(const K *keys_in, const u32 *vals_in, K *keys_out, u32 *vals_out,
                                                                         u32 n, u32 shift, const u32 *offs, u32 ntiles) {
-  __shared__ u64 keys_s[RS_TILE];
+  __shared__ K keys_s[RS_TILE];
   __shared__ u32 vals_s[RS_TILE], dest_s[RS_TILE];
   __shared__ u32 wh[RSK_WAVES][256];
   __shared__ u32 gbase[256];
@@ -304,13 +306,13 @@ __global__ __launch_bounds__(RSK_THREADS) void radix_scatter_kv_staged_k(const u
   const int w = wave_id(), lane = lane_id();
   const u64 lt = (1ull << lane) - 1;
   const u32 tile0 = blockIdx.x * RS_TILE, base = tile0 + w * (64 * RSK_ITEMS);
-  u64 key[RSK_ITEMS];
+  K key[RSK_ITEMS];
   u32 val[RSK_ITEMS], pos[RSK_ITEMS];
 #pragma unroll
   for (int r = 0; r < RSK_ITEMS; r++) {
     const u32 idx = base + r * 64 + lane;
     const bool valid = idx < n;
-    key[r] = valid ? keys_in[idx] : 0ull;
+    key[r] = valid ? keys_in[idx] : K(0);
     val[r] = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
     const u32 d = (u32)(key[r] >> shift) & 0xFFu;
     u64 peers = __ballot(valid);
@@ -371,13 +373,14 @@ __global__ __launch_bounds__(RSK_THREADS) void radix_scatter_kv_staged_k(const u
   }
 }
 
-inline void radix_pass_kv(const u64 *keys_in, const u32 *vals_in, u64 *keys_out, u32 *vals_out, u32 n, u32 shift, u32 *hist_ws,
+template <typename K>
+inline void radix_pass_kv(const K *keys_in, const u32 *vals_in, K *keys_out, u32 *vals_out, u32 n, u32 shift, u32 *hist_ws,
                           u32 *tile_ws, hipStream_t st) {
   if (!n) return;
   const u32 ntiles = (n + RS_TILE - 1) / RS_TILE;
-  hipLaunchKernelGGL(radix_hist_key_k, dim3((ntiles + RH_TILES - 1) / RH_TILES), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
+  hipLaunchKernelGGL(radix_hist_key_k<K>, dim3((ntiles + RH_TILES - 1) / RH_TILES), dim3(RS_THREADS), 0, st, keys_in, n, shift, hist_ws, ntiles);
   exclusive_scan<u32>(LoadAs<u32, u32>{hist_ws}, (u64)256 * ntiles, StoreTo<u32>{hist_ws}, tile_ws, (u32 *)nullptr, st);
-  hipLaunchKernelGGL(radix_scatter_kv_staged_k, dim3(ntiles), dim3(RSK_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
+  hipLaunchKernelGGL(radix_scatter_kv_staged_k<K>, dim3(ntiles), dim3(RSK_THREADS), 0, st, keys_in, vals_in, keys_out, vals_out, n, shift,
                      hist_ws, ntiles);
 }
 
